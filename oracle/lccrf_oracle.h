@@ -1,0 +1,121 @@
+/*
+ * lccrf_oracle.h -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * Scalar C restatement of the CPU arithmetic of LC-CRF-SLAM's dense-CRF
+ * mean-field hot path (reference: Thirdparty/DenseCRF/include/*.h as compiled
+ * by g++ on x86-64, i.e. the SSE2 code path, plus the feature/unary assembly
+ * of src/Tracking.cc).  It exists so that tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg have a checker that travels to the GPU box.
+ * Nothing under lc-crf-slam_amd/ may include, link or call it.
+ *
+ * Parity status:
+ *   - rows a4..a15 of SURVEY.md section 8(a) (lattice, filter, mean-field):
+ *     PINNED.  Bit-identical to the reference headers compiled in place
+ *     (oracle/_ref, see oracle/Makefile) on every committed fixture in
+ *     tests/golden/, and reproduces the reference's own known-answer image
+ *     Thirdparty/DenseCRF/examples/res1_cpu.ppm byte for byte
+ *     (tests/test_oracle_golden.py).
+ *   - rows a2, a3 (Tracking::ComputeMapPointErrAndObserv, RroughClassify):
+ *     PARITY UNPINNED.  src/Tracking.cc needs OpenCV/Eigen/g2o, which this
+ *     image lacks, and the reference holds no test or fixture for them; the
+ *     restatement follows Tracking.cc:1803-1839 and :1961-2013 literally and
+ *     is checked only against hand-derived known answers.
+ *
+ * Every function cites the reference file:line it follows (paths relative to
+ * /root/reference/).
+ */
+#ifndef LCCRF_ORACLE_H
+#define LCCRF_ORACLE_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- permutohedral lattice (permutohedral_cpu.h:173-761, SSE variant) ---- */
+typedef struct orc_lattice {
+    int N;            /* number of real points                                  */
+    int Npad;         /* N rounded up to a multiple of 4 (phantom points, Q1)   */
+    int d;            /* feature dimensions                                     */
+    int V;            /* lattice vertices (reference M_), phantoms included     */
+    int *offset;      /* [Npad*(d+1)] vertex id of simplex corner `rem`         */
+    float *bary;      /* [Npad*(d+1)] barycentric weight of that corner         */
+    int *nbr;         /* [(d+1)*V*2]  {n1,n2} per (axis, vertex), -1 = absent   */
+    int16_t *keys;    /* [V*d]        lattice key of every vertex               */
+} orc_lattice;
+
+int  orc_lattice_init(orc_lattice *lat, const float *feature, int d, int N);
+void orc_lattice_compute(const orc_lattice *lat, float *out, const float *in,
+                         int value_size);
+void orc_lattice_free(orc_lattice *lat);
+
+/* ---- dense CRF (densecrf_base.h, densecrf3d.h, pairwise3d.h) ---- */
+#define ORC_MAX_KERNELS 8
+
+typedef struct orc_pairwise {
+    orc_lattice lat;
+    float w;
+    float *norm;      /* [N] */
+} orc_pairwise;
+
+typedef struct orc_crf {
+    int N, L, K;
+    float *unary, *current, *next, *tmp;   /* [N*L] AoS, densecrf3d.h:23-28 */
+    int16_t *map;                          /* [N], lazily allocated        */
+    orc_pairwise *pw[ORC_MAX_KERNELS];
+} orc_crf;
+
+orc_crf *orc_crf_create(int N, int L);
+void orc_crf_destroy(orc_crf *crf);
+void orc_crf_set_unary(orc_crf *crf, const float *unary);
+void orc_crf_set_unary_from_label(orc_crf *crf, const int16_t *label,
+                                  const float *conf /* [L] */);
+int  orc_crf_add_pairwise(orc_crf *crf, const float *features, int d, float w);
+void orc_crf_start_inference(orc_crf *crf);
+void orc_crf_step_inference(orc_crf *crf, float relax);
+void orc_crf_build_map(orc_crf *crf);
+void orc_crf_inference(orc_crf *crf, int n_iter, int with_map, float relax);
+
+float orc_fast_exp(float x);
+void  orc_exp_and_normalize(float *out, const float *in, int N, int L,
+                            float scale, float relax);
+
+/* ---- feature assembly (pairwise3d.h:37-71, pairwise_cpu.h:33-51) ---- */
+void orc_appearance_features(int N, const float *vobserv, const float *verror,
+                             float sd_observ, float sd_error, float *out /* [N*2] */);
+void orc_smooth_features(int N, const float *xy /* [N*2] */, float sd2d,
+                         float *out /* [N*2] */);
+void orc_image_features(int W, int H, float posdev, const uint8_t *rgb /* or NULL */,
+                        int C, float featuredev, float *out /* [W*H*(2+C)] */);
+
+/* ---- unary builder on the SLAM side (src/Tracking.cc) ---- */
+typedef struct orc_crf_params {   /* Tracking.cc:151-171, TUM3.yaml:78-101 */
+    float w1, w2;
+    float u_alpha, stdev_alpha;   /* reprojection error mean / stdev */
+    float u_beta, stdev_beta;     /* observation count mean / stdev  */
+    float u_gamma, stdev_gamma;   /* epipolar prior (read, unused in RroughClassify) */
+    float point3d_stdev, point2d_stdev;
+    float u_depth, pth, confidence;
+} orc_crf_params;
+
+void orc_default_params(orc_crf_params *p);
+
+/* Tracking.cc:1961-2013.  match_prob == NULL means mvFeatureMatchProb.empty(). */
+void orc_rough_classify(int N, const float *vobservs, const float *verrors,
+                        const float *vdepths, const double *match_prob,
+                        const orc_crf_params *p, int16_t *label_out);
+
+/* Tracking.cc:1803-1839 for one map point with `n_obs` keyframe observations.
+ * poses: [n_obs*12] row-major 3x4 [R|t]; intr: [n_obs*4] fx,fy,cx,cy;
+ * bounds: [n_obs*4] minX,maxX,minY,maxY; kp: [n_obs*2] observed keypoint (double). */
+void orc_map_point_err_observ(int n_obs, const float *Xw, const float *poses,
+                              const float *intr, const float *bounds,
+                              const double *kp, int *observs, float *error,
+                              float *depth);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
