@@ -1,0 +1,169 @@
+/*
+ * lccrf.h -- C-ABI of the MI355X-native dense-CRF mean-field path.
+ *
+ * Drop-in boundary for ONE hot path of LC-CRF-SLAM: the per-frame dense-CRF inference
+ * that labels ORB keypoints static / dynamic inside Tracking::DynamicDetectionWithCRF
+ * (reference src/Tracking.cc:1919-1930).  The entry points are exactly what a binding
+ * of the reference's own operator interface for this path needs -- the two abstract
+ * classes of Thirdparty/DenseCRF/include/densecrf_base.h:
+ *
+ *      class PairwisePotential   (densecrf_base.h:12-19)
+ *      class DenseCRF            (densecrf_base.h:22-92)
+ *
+ * Plain pointers and sizes only; no C++/torch types.  Every function returns
+ * LCCRF_OK (0) or a negative lccrf_status; lccrf_last_error() gives the detail for
+ * the calling thread.  There is NO CPU fallback behind this ABI: without a usable
+ * gfx950 device every call that needs one fails with LCCRF_E_NO_DEVICE.
+ *
+ * Threading: handles are thread-compatible (one handle per thread at a time), like
+ * the reference's stack-local per-frame objects.
+ *
+ * Layouts (all little-endian, densely packed):
+ *   unary / probability : float32 [N][L]   "x0l0 x0l1 .. x1l0 .." (densecrf_base.h:56)
+ *   label / map         : int16   [N]      -1 = unknown (densecrf3d.h:119)
+ *   features            : float32 [N][d]   already divided by the kernel's stdev
+ *                                          (pairwise3d.h:41-44,64-66 do that division)
+ */
+#ifndef LCCRF_H
+#define LCCRF_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LCCRF_ABI_VERSION 1
+#define LCCRF_MAX_KERNELS 8      /* pairwise terms per CRF                        */
+#define LCCRF_MAX_DIMS    8      /* feature dimensions per kernel (reference uses <= 6) */
+#define LCCRF_MAX_LABELS  64
+
+typedef enum lccrf_status {
+    LCCRF_OK            =  0,
+    LCCRF_E_INVALID     = -1,    /* bad argument (NULL, negative size, d/L out of range) */
+    LCCRF_E_NO_DEVICE   = -2,    /* no gfx950 device / HIP runtime unusable              */
+    LCCRF_E_HIP         = -3,    /* a HIP call failed; see lccrf_last_error()            */
+    LCCRF_E_NOMEM       = -4,
+    LCCRF_E_STATE       = -5,    /* call order violated (e.g. inference before unary)    */
+    LCCRF_E_CAPACITY    = -6     /* more kernels / frames / points than created for      */
+} lccrf_status;
+
+int          lccrf_abi_version(void);
+const char  *lccrf_last_error(void);
+int          lccrf_device_count(int *count);
+
+/* ======================================================================================
+ * 1. Object API -- one CRF, host buffers in / host buffers out.
+ *    Mirrors DenseCRF3D<M> + PottsPotential3D<M,F> as used at src/Tracking.cc:1920-1930.
+ * ==================================================================================== */
+typedef struct lccrf_crf *lccrf_handle;
+
+/* DenseCRF3D<M>::DenseCRF3D(int N)              densecrf3d.h:23-28   (M = n_labels)   */
+int  lccrf_create(lccrf_handle *out, int device_id, int n_points, int n_labels);
+/* ~DenseCRF3D / ~DenseCRF (owns its pairwise terms)  densecrf3d.h:30-36, base.h:41-45 */
+void lccrf_destroy(lccrf_handle h);
+
+/* DenseCRF::setUnaryEnergy(const float*)        densecrf3d.h:41-43                    */
+int  lccrf_set_unary(lccrf_handle h, const float *unary);
+/* DenseCRF::setUnaryEnergyFromLabel(const short*, float*)   densecrf3d.h:107-130;
+ * conf has n_labels entries.  The scalar overload (densecrf3d.h:100-105) is the same
+ * call with every entry equal.                                                         */
+int  lccrf_set_unary_from_label(lccrf_handle h, const int16_t *label, const float *conf);
+
+/* new PottsPotential3D<M,F>(features, N, w) + DenseCRF::addPairwiseEnergy(p)
+ * pairwise3d.h:20-28 (lattice init + normalisation), densecrf_base.h:54.
+ * The CRF owns the term.  d = F.  Kernels are applied in the order added.              */
+int  lccrf_add_pairwise(lccrf_handle h, const float *features, int d, float w);
+
+/* PottsPotential3D<M,2>::appearanceKernel(N, w, vobserv, verror, sd1, sd2)
+ * pairwise3d.h:37-48 : features (vobserv/sd1, verror/sd2), then the ctor above.        */
+int  lccrf_add_appearance_kernel(lccrf_handle h, float w, const float *vobserv,
+                                 const float *verror, float sd_observ, float sd_error);
+/* PottsPotential3D<M,2>::smoothKernel(N, w, points3d, points2d, sd3d, sd2d)
+ * pairwise3d.h:51-71 : only the 2-D branch is live -> features (u/sd2d, v/sd2d).
+ * xy is [N][2] (cv::Point2f layout).                                                   */
+int  lccrf_add_smooth_kernel(lccrf_handle h, float w, const float *xy, float sd2d);
+
+/* DenseCRF::startInference()                    densecrf_base.h:78-80                 */
+int  lccrf_start_inference(lccrf_handle h);
+/* DenseCRF::stepInference(float relax)          densecrf_base.h:82-91                 */
+int  lccrf_step_inference(lccrf_handle h, float relax);
+/* DenseCRF3D<M>::buildMap()                     densecrf3d.h:136-151                  */
+int  lccrf_build_map(lccrf_handle h);
+/* DenseCRF::inference(n_iterations, with_map, relax)   densecrf_base.h:65-73          */
+int  lccrf_inference(lccrf_handle h, int n_iterations, int with_map, float relax);
+
+/* DenseCRF::getMap() / getProbability()         densecrf_base.h:74-75
+ * (copies out; the reference returns pointers into object-owned buffers)               */
+int  lccrf_get_map(lccrf_handle h, int16_t *map_out);
+int  lccrf_get_probability(lccrf_handle h, float *prob_out);
+
+/* Parity probes (no reference API; the reference keeps these protected):
+ * lattice size M_ (permutohedral_cpu.h:398) and PottsPotential3D::norm_ (pairwise3d.h:18).
+ * offset/bary are [N][d+1], nbr is [d+1][V][2]; any output pointer may be NULL.         */
+int  lccrf_get_lattice_size(lccrf_handle h, int kernel, int *n_vertices);
+int  lccrf_get_norm(lccrf_handle h, int kernel, float *norm_out);
+int  lccrf_get_lattice(lccrf_handle h, int kernel, int32_t *offset_out, float *bary_out,
+                       int32_t *nbr_out);
+int  lccrf_get_unary(lccrf_handle h, float *unary_out);
+
+/* ======================================================================================
+ * 2. Batch API -- many independent frames in flight on one GPU.
+ *    Every frame is one CRF of the object API; frames never interact.  Inputs may be
+ *    handed over as host buffers (uploaded) or bound as DEVICE pointers (zero copy), so
+ *    a caller that already holds the arrays in HBM pays no PCIe traffic.
+ * ==================================================================================== */
+typedef struct lccrf_batch *lccrf_batch_handle;
+
+typedef struct lccrf_batch_desc {
+    int   max_frames;                       /* frames per batch                          */
+    int   max_points;                       /* per-frame stride of every array           */
+    int   n_labels;
+    int   n_kernels;
+    int   feat_dims[LCCRF_MAX_KERNELS];
+    float weights[LCCRF_MAX_KERNELS];
+} lccrf_batch_desc;
+
+int  lccrf_batch_create(lccrf_batch_handle *out, int device_id, const lccrf_batch_desc *desc);
+void lccrf_batch_destroy(lccrf_batch_handle b);
+
+/* Host inputs (copied to the device).  n_points[f] <= max_points; arrays are strided by
+ * max_points per frame.  Exactly one of unary / label must be non-NULL.                 */
+int  lccrf_batch_set_inputs_host(lccrf_batch_handle b, int n_frames, const int32_t *n_points,
+                                 const float *unary, const int16_t *label, const float *conf,
+                                 const float *const *features /* [n_kernels] */);
+/* Device inputs (bound, not copied; must stay valid until the batch finished).          */
+int  lccrf_batch_bind_inputs_device(lccrf_batch_handle b, int n_frames, const int32_t *d_n_points,
+                                    const float *d_unary, const int16_t *d_label, const float *conf,
+                                    const float *const *d_features /* host array of device ptrs */);
+
+/* Per frame: every PottsPotential3D ctor (lattice + norm), pairwise3d.h:20-28.
+ * Asynchronous on `stream` (a hipStream_t, or NULL for the batch's own stream).         */
+int  lccrf_batch_build(lccrf_batch_handle b, void *stream);
+/* Per frame: DenseCRF::inference(n_iterations, with_map, relax), densecrf_base.h:65-73. */
+int  lccrf_batch_inference(lccrf_batch_handle b, int n_iterations, int with_map, float relax,
+                           void *stream);
+int  lccrf_batch_synchronize(lccrf_batch_handle b);
+
+/* Results: copy to host, or borrow the device buffers ([n_frames][max_points](xL)).     */
+int  lccrf_batch_get_map_host(lccrf_batch_handle b, int16_t *map_out);
+int  lccrf_batch_get_probability_host(lccrf_batch_handle b, float *prob_out);
+int  lccrf_batch_get_lattice_sizes_host(lccrf_batch_handle b, int kernel, int32_t *n_vertices_out);
+int  lccrf_batch_get_norm_host(lccrf_batch_handle b, int kernel, float *norm_out);
+int  lccrf_batch_device_buffers(lccrf_batch_handle b, const int16_t **d_map, const float **d_prob);
+
+/* Engine selection for the inference loop (both give bit-identical results):
+ *   0 = automatic, 1 = streaming kernels over HBM (any size), 2 = fused one-workgroup-
+ *   per-frame kernel with the lattice values in LDS (SLAM sizes only).                  */
+int  lccrf_batch_set_engine(lccrf_batch_handle b, int engine);
+int  lccrf_batch_get_engine(lccrf_batch_handle b, int *engine_in_use);
+
+/* Measurement support for bench.py: HIP-event time of the last lccrf_batch_inference()
+ * on its stream, the number of launches of the dominant kernel and their summed
+ * duration as seen by events around them (0 if not instrumented).                       */
+int  lccrf_batch_last_timing(lccrf_batch_handle b, float *inference_ms, float *build_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LCCRF_H */

@@ -1,0 +1,326 @@
+"""lc-crf-slam_amd -- MI355X-native dense-CRF mean-field path of LC-CRF-SLAM.
+
+Python here is plumbing only: a ctypes binding of the C-ABI in include/lccrf.h
+(liblccrf_hip.so, hand-written gfx950 HIP kernels) plus numpy-facing mirrors of the
+reference's operator interface (densecrf_base.h: DenseCRF / PairwisePotential) so that
+the parity tests read like the reference's call site (src/Tracking.cc:1919-1930).
+
+There is no CPU fallback: if the library is missing, or no GPU is usable, calls raise.
+
+Import with  importlib.import_module("lc-crf-slam_amd")  (the directory name is fixed
+by the project layout and is not a valid identifier).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblccrf_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "lccrf.h")
+
+MAX_KERNELS = 8
+OK = 0
+_STATUS = {0: "OK", -1: "E_INVALID", -2: "E_NO_DEVICE", -3: "E_HIP", -4: "E_NOMEM", -5: "E_STATE",
+           -6: "E_CAPACITY"}
+
+_f32p = C.POINTER(C.c_float)
+_i16p = C.POINTER(C.c_int16)
+_i32p = C.POINTER(C.c_int32)
+
+
+class LccrfError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("lccrf %s (%d): %s" % (_STATUS.get(code, "?"), code, msg))
+        self.code = code
+
+
+class BatchDesc(C.Structure):
+    _fields_ = [("max_frames", C.c_int), ("max_points", C.c_int), ("n_labels", C.c_int),
+                ("n_kernels", C.c_int), ("feat_dims", C.c_int * MAX_KERNELS),
+                ("weights", C.c_float * MAX_KERNELS)]
+
+
+def build_library(quiet=True):
+    """Compile liblccrf_hip.so for gfx950 (hipcc cross-compiles without a GPU)."""
+    subprocess.run(["make", "-C", _HERE, "-j4", "all"], check=True,
+                   stdout=subprocess.DEVNULL if quiet else None)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    """The loaded C-ABI library.  Raises if it has not been built -- never falls back."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FileNotFoundError(
+            LIB_PATH + " is missing: build it with `make -C lc-crf-slam_amd` "
+            "(or __graft_entry__.build()).  There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    L.lccrf_last_error.restype = C.c_char_p
+    L.lccrf_device_count.argtypes = [C.POINTER(C.c_int)]
+    L.lccrf_create.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_int]
+    L.lccrf_destroy.argtypes = [vp]
+    L.lccrf_destroy.restype = None
+    L.lccrf_set_unary.argtypes = [vp, _f32p]
+    L.lccrf_set_unary_from_label.argtypes = [vp, _i16p, _f32p]
+    L.lccrf_add_pairwise.argtypes = [vp, _f32p, C.c_int, C.c_float]
+    L.lccrf_add_appearance_kernel.argtypes = [vp, C.c_float, _f32p, _f32p, C.c_float, C.c_float]
+    L.lccrf_add_smooth_kernel.argtypes = [vp, C.c_float, _f32p, C.c_float]
+    L.lccrf_start_inference.argtypes = [vp]
+    L.lccrf_step_inference.argtypes = [vp, C.c_float]
+    L.lccrf_build_map.argtypes = [vp]
+    L.lccrf_inference.argtypes = [vp, C.c_int, C.c_int, C.c_float]
+    L.lccrf_get_map.argtypes = [vp, _i16p]
+    L.lccrf_get_probability.argtypes = [vp, _f32p]
+    L.lccrf_get_unary.argtypes = [vp, _f32p]
+    L.lccrf_get_lattice_size.argtypes = [vp, C.c_int, C.POINTER(C.c_int)]
+    L.lccrf_get_norm.argtypes = [vp, C.c_int, _f32p]
+    L.lccrf_get_lattice.argtypes = [vp, C.c_int, _i32p, _f32p, _i32p]
+    L.lccrf_batch_create.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(BatchDesc)]
+    L.lccrf_batch_destroy.argtypes = [vp]
+    L.lccrf_batch_destroy.restype = None
+    L.lccrf_batch_set_inputs_host.argtypes = [vp, C.c_int, _i32p, _f32p, _i16p, _f32p, C.POINTER(_f32p)]
+    L.lccrf_batch_bind_inputs_device.argtypes = [vp, C.c_int, vp, vp, vp, _f32p, C.POINTER(vp)]
+    L.lccrf_batch_build.argtypes = [vp, vp]
+    L.lccrf_batch_inference.argtypes = [vp, C.c_int, C.c_int, C.c_float, vp]
+    L.lccrf_batch_synchronize.argtypes = [vp]
+    L.lccrf_batch_get_map_host.argtypes = [vp, _i16p]
+    L.lccrf_batch_get_probability_host.argtypes = [vp, _f32p]
+    L.lccrf_batch_get_lattice_sizes_host.argtypes = [vp, C.c_int, _i32p]
+    L.lccrf_batch_get_norm_host.argtypes = [vp, C.c_int, _f32p]
+    L.lccrf_batch_device_buffers.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
+    L.lccrf_batch_set_engine.argtypes = [vp, C.c_int]
+    L.lccrf_batch_get_engine.argtypes = [vp, C.POINTER(C.c_int)]
+    L.lccrf_batch_last_timing.argtypes = [vp, _f32p, _f32p]
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc != OK:
+        raise LccrfError(rc, lib().lccrf_last_error().decode("utf-8", "replace"))
+
+
+def device_count():
+    n = C.c_int(0)
+    _check(lib().lccrf_device_count(C.byref(n)))
+    return n.value
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _p(a, t):
+    return a.ctypes.data_as(t)
+
+
+class DenseCRFHIP:
+    """Mirror of DenseCRF3D<M> + PottsPotential3D<M,F> (densecrf3d.h, pairwise3d.h) on the
+    HIP path.  Same method meaning and call order as the reference; host arrays in/out."""
+
+    def __init__(self, N, L, device=0):
+        self.N, self.L = int(N), int(L)
+        self._d = []
+        self.h = C.c_void_p()
+        _check(lib().lccrf_create(C.byref(self.h), int(device), self.N, self.L))
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().lccrf_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    # -- unary -------------------------------------------------------------------------
+    def set_unary(self, unary):
+        u = _f32(unary).reshape(-1)
+        if u.size != self.N * self.L:
+            raise ValueError("unary must have N*L entries")
+        _check(lib().lccrf_set_unary(self.h, _p(u, _f32p)))
+
+    def set_unary_from_label(self, label, conf):
+        lab = np.ascontiguousarray(label, np.int16)
+        if lab.size != self.N:
+            raise ValueError("label must have N entries")
+        cf = _f32(np.broadcast_to(np.asarray(conf, np.float32), (self.L,)))
+        _check(lib().lccrf_set_unary_from_label(self.h, _p(lab, _i16p), _p(cf, _f32p)))
+
+    # -- pairwise ----------------------------------------------------------------------
+    def add_pairwise(self, features, w):
+        f = _f32(features)
+        f = f.reshape(self.N, f.shape[-1] if f.ndim == 2 else -1)
+        _check(lib().lccrf_add_pairwise(self.h, _p(f, _f32p), f.shape[1], float(w)))
+        self._d.append(f.shape[1])
+
+    def add_appearance_kernel(self, w, vobserv, verror, sd_observ, sd_error):
+        a, b = _f32(vobserv), _f32(verror)
+        _check(lib().lccrf_add_appearance_kernel(self.h, float(w), _p(a, _f32p), _p(b, _f32p),
+                                                 float(sd_observ), float(sd_error)))
+        self._d.append(2)
+
+    def add_smooth_kernel(self, w, xy, sd2d):
+        a = _f32(xy)
+        _check(lib().lccrf_add_smooth_kernel(self.h, float(w), _p(a, _f32p), float(sd2d)))
+        self._d.append(2)
+
+    # -- inference ---------------------------------------------------------------------
+    def start_inference(self):
+        _check(lib().lccrf_start_inference(self.h))
+
+    def step_inference(self, relax=1.0):
+        _check(lib().lccrf_step_inference(self.h, float(relax)))
+
+    def build_map(self):
+        _check(lib().lccrf_build_map(self.h))
+
+    def inference(self, n_iter, with_map=False, relax=1.0):
+        _check(lib().lccrf_inference(self.h, int(n_iter), int(bool(with_map)), float(relax)))
+
+    inference_native = inference
+
+    def run_trace(self, n_iter, relax=1.0):
+        out = np.empty((n_iter + 1, self.N, self.L), np.float32)
+        self.start_inference()
+        out[0] = self.probability()
+        for t in range(n_iter):
+            self.step_inference(relax)
+            out[t + 1] = self.probability()
+        return out
+
+    # -- results -----------------------------------------------------------------------
+    def map(self):
+        out = np.empty(self.N, np.int16)
+        _check(lib().lccrf_get_map(self.h, _p(out, _i16p)))
+        return out
+
+    def probability(self):
+        out = np.empty((self.N, self.L), np.float32)
+        _check(lib().lccrf_get_probability(self.h, _p(out, _f32p)))
+        return out
+
+    def unary(self):
+        out = np.empty((self.N, self.L), np.float32)
+        _check(lib().lccrf_get_unary(self.h, _p(out, _f32p)))
+        return out
+
+    def kernel(self, k):
+        d = self._d[k]
+        V = C.c_int(0)
+        _check(lib().lccrf_get_lattice_size(self.h, k, C.byref(V)))
+        V = V.value
+        norm = np.empty(self.N, np.float32)
+        off = np.empty((self.N, d + 1), np.int32)
+        bary = np.empty((self.N, d + 1), np.float32)
+        nbr = np.empty((d + 1, V, 2), np.int32)
+        _check(lib().lccrf_get_norm(self.h, k, _p(norm, _f32p)))
+        _check(lib().lccrf_get_lattice(self.h, k, _p(off, _i32p), _p(bary, _f32p), _p(nbr, _i32p)))
+        return dict(d=d, V=V, norm=norm, offset=off, bary=bary, nbr=nbr)
+
+
+class BatchCRF:
+    """Frames-in-flight: F independent CRFs with a common stride (include/lccrf.h section 2)."""
+
+    def __init__(self, max_frames, max_points, n_labels, feat_dims, weights, device=0):
+        self.F, self.maxN, self.L = int(max_frames), int(max_points), int(n_labels)
+        self.dims = [int(d) for d in feat_dims]
+        d = BatchDesc()
+        d.max_frames, d.max_points, d.n_labels, d.n_kernels = self.F, self.maxN, self.L, len(self.dims)
+        for i, (fd, w) in enumerate(zip(self.dims, weights)):
+            d.feat_dims[i] = fd
+            d.weights[i] = float(w)
+        self.h = C.c_void_p()
+        self.n_frames = 0
+        _check(lib().lccrf_batch_create(C.byref(self.h), int(device), C.byref(d)))
+        self._keep = None
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().lccrf_batch_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def set_inputs_host(self, n_points, features, unary=None, label=None, conf=None):
+        npts = np.ascontiguousarray(n_points, np.int32)
+        F = npts.size
+        feats = [_f32(f).reshape(F, self.maxN, d) for f, d in zip(features, self.dims)]
+        arr = (_f32p * len(feats))(*[_p(f, _f32p) for f in feats])
+        u = l = cf = None
+        if unary is not None:
+            u = _f32(unary).reshape(F, self.maxN, self.L)
+        if label is not None:
+            l = np.ascontiguousarray(label, np.int16).reshape(F, self.maxN)
+            cf = _f32(np.broadcast_to(np.asarray(conf, np.float32), (self.L,)))
+        _check(lib().lccrf_batch_set_inputs_host(
+            self.h, F, _p(npts, _i32p), _p(u, _f32p) if u is not None else None,
+            _p(l, _i16p) if l is not None else None, _p(cf, _f32p) if cf is not None else None, arr))
+        self.n_frames = F
+
+    def bind_inputs_device(self, n_frames, d_n_points, d_features, d_unary=None, d_label=None, conf=None):
+        """Pointers are raw device addresses (e.g. torch_tensor.data_ptr())."""
+        arr = (C.c_void_p * len(d_features))(*[C.c_void_p(int(p)) for p in d_features])
+        cf = None
+        if d_label is not None:
+            cf = _f32(np.broadcast_to(np.asarray(conf, np.float32), (self.L,)))
+        _check(lib().lccrf_batch_bind_inputs_device(
+            self.h, int(n_frames), C.c_void_p(int(d_n_points)),
+            C.c_void_p(int(d_unary)) if d_unary is not None else None,
+            C.c_void_p(int(d_label)) if d_label is not None else None,
+            _p(cf, _f32p) if cf is not None else None, arr))
+        self.n_frames = int(n_frames)
+
+    def build(self, stream=None):
+        _check(lib().lccrf_batch_build(self.h, C.c_void_p(stream) if stream else None))
+
+    def inference(self, n_iter, with_map=True, relax=1.0, stream=None):
+        _check(lib().lccrf_batch_inference(self.h, int(n_iter), int(bool(with_map)), float(relax),
+                                           C.c_void_p(stream) if stream else None))
+
+    def synchronize(self):
+        _check(lib().lccrf_batch_synchronize(self.h))
+
+    def set_engine(self, engine):
+        _check(lib().lccrf_batch_set_engine(self.h, int(engine)))
+
+    def engine(self):
+        e = C.c_int(0)
+        _check(lib().lccrf_batch_get_engine(self.h, C.byref(e)))
+        return e.value
+
+    def map(self):
+        out = np.empty((self.n_frames, self.maxN), np.int16)
+        _check(lib().lccrf_batch_get_map_host(self.h, _p(out, _i16p)))
+        return out
+
+    def probability(self):
+        out = np.empty((self.n_frames, self.maxN, self.L), np.float32)
+        _check(lib().lccrf_batch_get_probability_host(self.h, _p(out, _f32p)))
+        return out
+
+    def lattice_sizes(self, k):
+        out = np.empty(self.n_frames, np.int32)
+        _check(lib().lccrf_batch_get_lattice_sizes_host(self.h, k, _p(out, _i32p)))
+        return out
+
+    def norm(self, k):
+        out = np.empty((self.n_frames, self.maxN), np.float32)
+        _check(lib().lccrf_batch_get_norm_host(self.h, k, _p(out, _f32p)))
+        return out
+
+    def device_buffers(self):
+        m, q = C.c_void_p(), C.c_void_p()
+        _check(lib().lccrf_batch_device_buffers(self.h, C.byref(m), C.byref(q)))
+        return m.value, q.value
+
+    def last_timing(self):
+        a, b = C.c_float(0), C.c_float(0)
+        _check(lib().lccrf_batch_last_timing(self.h, C.byref(a), C.byref(b)))
+        return dict(inference_ms=a.value, build_ms=b.value)

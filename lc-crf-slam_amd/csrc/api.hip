@@ -1,0 +1,819 @@
+// api.hip -- the C-ABI of include/lccrf.h on top of the two HIP engines.
+//
+// Host-side glue only: argument checks, device memory, pinned staging, launch order.
+// All arithmetic of the path runs in the kernels (stream_engine.hip / fused_engine.hip);
+// the only numbers computed here are the per-kernel constants of
+// permutohedral_cpu.h:249,282-285,681 and the 2L+1 unary energies of densecrf3d.h:109-115,
+// which the reference also computes once, outside its loops.
+#include "engine.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+using namespace lccrf;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                        \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess)                                                                \
+            return fail(e_ == hipErrorOutOfMemory ? LCCRF_E_NOMEM : LCCRF_E_HIP, "%s: %s",  \
+                        #expr, hipGetErrorString(e_));                                       \
+    } while (0)
+
+int next_pow2(long v)
+{
+    long p = 16;
+    while (p < v) p <<= 1;
+    return (int)p;
+}
+
+int use_device(int device_id)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(LCCRF_E_NO_DEVICE, "no HIP device (hipGetDeviceCount: %s); this library has no CPU fallback",
+                    hipGetErrorString(e));
+    if (device_id < 0 || device_id >= n) return fail(LCCRF_E_INVALID, "device_id %d out of range [0,%d)", device_id, n);
+    HIP_TRY(hipSetDevice(device_id));
+    return LCCRF_OK;
+}
+
+// Owns every device / pinned allocation of one engine.
+struct Arena {
+    std::vector<void *> dev, pinned;
+    template <typename T>
+    int alloc(T **out, size_t count, bool zero = true)
+    {
+        void *p = nullptr;
+        const size_t bytes = (count ? count : 1) * sizeof(T);
+        HIP_TRY(hipMalloc(&p, bytes));
+        dev.push_back(p);
+        if (zero) HIP_TRY(hipMemset(p, 0, bytes));
+        *out = static_cast<T *>(p);
+        return LCCRF_OK;
+    }
+    template <typename T>
+    int alloc_pinned(T **out, size_t count)
+    {
+        void *p = nullptr;
+        HIP_TRY(hipHostMalloc(&p, (count ? count : 1) * sizeof(T), hipHostMallocDefault));
+        pinned.push_back(p);
+        *out = static_cast<T *>(p);
+        return LCCRF_OK;
+    }
+    void release()
+    {
+        for (void *p : dev) (void)hipFree(p);
+        for (void *p : pinned) (void)hipHostFree(p);
+        dev.clear();
+        pinned.clear();
+    }
+};
+
+struct KernelState {
+    KernelDev dev{};
+    float *feat_own = nullptr;    // device copy of host-provided features
+    float *feat_stage = nullptr;  // pinned staging for the object API
+    int maxV = 0;                 // max over frames of V once known, else Epad
+};
+
+// One CRF problem set: F frames x maxN points x L labels, K kernels.
+struct Engine {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    Arena mem;
+    int Fcap = 0, F = 0, maxN = 0, maxNpad = 0, L = 0;
+    CrfDev crf{};
+    int *npoints_own = nullptr;
+    float *unary_own = nullptr;
+    int16_t *label_own = nullptr;
+    float *tbl = nullptr;              // device: {u, n[L], p[L]}
+    float *tbl_host = nullptr;         // pinned
+    int *V_host = nullptr;             // pinned [K][Fcap]
+    std::vector<KernelState> kernels;
+    std::vector<KernelDev> kdevs;      // contiguous copy handed to the launchers
+    std::vector<int> maxV;
+    bool unary_set = false, built = false, sizes_known = false, started = false;
+    int engine_pref = 0, engine_used = 1;
+    size_t fused_lds = 0;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   // build begin/end, inference begin/end
+    bool timed_build = false, timed_inf = false;
+
+    int init(int device_id, int frames, int max_points, int n_labels)
+    {
+        device = device_id;
+        Fcap = F = frames;
+        maxN = max_points;
+        maxNpad = (max_points + 3) & ~3;
+        L = n_labels;
+        HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        for (auto &e : ev) HIP_TRY(hipEventCreate(&e));
+        const size_t nl = (size_t)Fcap * maxN * L;
+        int rc;
+        if ((rc = mem.alloc(&npoints_own, Fcap))) return rc;
+        if ((rc = mem.alloc(&unary_own, nl))) return rc;
+        if ((rc = mem.alloc(&crf.Q, nl))) return rc;
+        if ((rc = mem.alloc(&crf.next, nl))) return rc;
+        if ((rc = mem.alloc(&crf.map, (size_t)Fcap * maxN))) return rc;
+        if ((rc = mem.alloc(&label_own, (size_t)Fcap * maxN))) return rc;
+        if ((rc = mem.alloc(&tbl, 2 * L + 1))) return rc;
+        if ((rc = mem.alloc_pinned(&tbl_host, 2 * L + 1))) return rc;
+        if ((rc = mem.alloc_pinned(&V_host, (size_t)LCCRF_MAX_KERNELS * Fcap))) return rc;
+        crf.F = F;
+        crf.maxN = maxN;
+        crf.L = L;
+        crf.K = 0;
+        crf.n_points = npoints_own;
+        crf.unary = unary_own;
+        return LCCRF_OK;
+    }
+
+    void destroy()
+    {
+        if (stream) (void)hipStreamSynchronize(stream);
+        mem.release();
+        for (auto &e : ev)
+            if (e) (void)hipEventDestroy(e);
+        if (stream) (void)hipStreamDestroy(stream);
+        stream = nullptr;
+    }
+
+    // Allocate the lattice of one more pairwise kernel (all frames).
+    int add_kernel(int d, float w, bool own_features, bool stage)
+    {
+        if ((int)kernels.size() >= LCCRF_MAX_KERNELS)
+            return fail(LCCRF_E_CAPACITY, "at most %d pairwise kernels", LCCRF_MAX_KERNELS);
+        if (d < 1 || d > LCCRF_MAX_DIMS) return fail(LCCRF_E_INVALID, "feature dims %d not in [1,%d]", d, LCCRF_MAX_DIMS);
+        KernelState ks;
+        KernelDev &k = ks.dev;
+        k.d = d;
+        k.D1 = d + 1;
+        k.maxN = maxN;
+        k.maxNpad = maxNpad;
+        k.Epad = maxNpad * k.D1;
+        k.cap = next_pow2(2L * k.Epad);
+        k.vstride = (k.Epad + 1) * L;
+        k.w = w;
+        // permutohedral_cpu.h:681 / :249 / :282-285 (quirk Q4): same expressions, same types
+        k.alpha = 1.0f / (1 + powf(2, -d));
+        k.inv_dp1 = 1.0f / (d + 1);
+        const float inv_std_dev = sqrt(2.0 / 3.0) * (d + 1);
+        for (int i = 0; i < d; ++i) k.scale[i] = (float)(1.0 / sqrt((double)((i + 2) * (i + 1))) * inv_std_dev);
+        const size_t Fz = (size_t)Fcap, E = (size_t)k.Epad;
+        int rc;
+        if ((rc = mem.alloc(&k.rem0, Fz * maxNpad * d))) return rc;
+        if ((rc = mem.alloc(&k.rank, Fz * maxNpad * d))) return rc;
+        if ((rc = mem.alloc(&k.bary, Fz * E))) return rc;
+        if ((rc = mem.alloc(&k.offset, Fz * E))) return rc;
+        if ((rc = mem.alloc(&k.slot, Fz * k.cap))) return rc;
+        if ((rc = mem.alloc(&k.slot_of, Fz * E))) return rc;
+        if ((rc = mem.alloc(&k.flag, Fz * (E + 1)))) return rc;
+        if ((rc = mem.alloc(&k.prefix, Fz * (E + 1)))) return rc;
+        if ((rc = mem.alloc(&k.rep, Fz * E))) return rc;
+        if ((rc = mem.alloc(&k.V, Fz))) return rc;
+        if ((rc = mem.alloc(&k.nbr, Fz * k.D1 * E * 2))) return rc;
+        if ((rc = mem.alloc(&k.rowptr, Fz * (E + 1)))) return rc;
+        if ((rc = mem.alloc(&k.csr_pt, Fz * E))) return rc;
+        if ((rc = mem.alloc(&k.csr_w, Fz * E))) return rc;
+        if ((rc = mem.alloc(&k.norm, Fz * maxN))) return rc;
+        if ((rc = mem.alloc(&k.val0, Fz * k.vstride))) return rc;
+        if ((rc = mem.alloc(&k.val1, Fz * k.vstride))) return rc;
+        if (own_features) {
+            if ((rc = mem.alloc(&ks.feat_own, Fz * maxN * d))) return rc;
+            k.feat = ks.feat_own;
+        }
+        if (stage)
+            if ((rc = mem.alloc_pinned(&ks.feat_stage, Fz * maxN * d))) return rc;
+        ks.maxV = k.Epad;
+        kernels.push_back(ks);
+        sync_views();
+        return LCCRF_OK;
+    }
+
+    void sync_views()
+    {
+        kdevs.resize(kernels.size());
+        maxV.resize(kernels.size());
+        for (size_t i = 0; i < kernels.size(); ++i) {
+            kdevs[i] = kernels[i].dev;
+            maxV[i] = kernels[i].maxV;
+        }
+        crf.K = (int)kernels.size();
+        crf.F = F;
+    }
+
+    // Lattice + normalisation of kernel k for every frame (PottsPotential3D ctor).
+    int build_kernel(int k)
+    {
+        KernelState &ks = kernels[k];
+        ks.maxV = ks.dev.Epad;
+        sync_views();
+        launch_build_kernel(kdevs[k], crf, ks.maxV, stream);
+        launch_norm(kdevs[k], crf, ks.maxV, stream);
+        HIP_TRY(hipMemcpyAsync(V_host + (size_t)k * Fcap, ks.dev.V, sizeof(int) * F, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipGetLastError());
+        sizes_known = false;
+        return LCCRF_OK;
+    }
+
+    // After the builds: learn max V per kernel so inference grids are sized to the lattice.
+    int learn_sizes()
+    {
+        if (sizes_known) return LCCRF_OK;
+        HIP_TRY(hipStreamSynchronize(stream));
+        for (size_t k = 0; k < kernels.size(); ++k) {
+            int m = 0;
+            for (int f = 0; f < F; ++f) m = std::max(m, V_host[k * Fcap + f]);
+            kernels[k].maxV = m;
+        }
+        sync_views();
+        sizes_known = true;
+        engine_used = 1;
+        if (engine_pref != 1 && fused_supported(crf, kdevs.data(), maxV.data(), &fused_lds)) engine_used = 2;
+        if (engine_pref == 2 && engine_used != 2)
+            return fail(LCCRF_E_CAPACITY, "fused engine requested but the problem does not fit one workgroup's LDS");
+        return LCCRF_OK;
+    }
+
+    int set_unary_from_label_tables(const float *conf)
+    {
+        // densecrf3d.h:109-115.  log(float) binds to the float overload at the reference's call
+        // site (src/Tracking.cc:21-43 sees `using namespace std` from include/Tracking.h:55).
+        tbl_host[0] = -logf(1.0f / L);
+        for (int i = 0; i < L; ++i) {
+            tbl_host[1 + i] = -logf((1.0f - conf[i]) / (L - 1));
+            tbl_host[1 + L + i] = -logf(conf[i]);
+        }
+        HIP_TRY(hipMemcpyAsync(tbl, tbl_host, sizeof(float) * (2 * L + 1), hipMemcpyHostToDevice, stream));
+        return LCCRF_OK;
+    }
+
+    int start()
+    {
+        if (!unary_set) return fail(LCCRF_E_STATE, "unary energies not set");
+        launch_start(crf, stream);
+        started = true;
+        return LCCRF_OK;
+    }
+
+    int step(float relax)
+    {
+        if (!started) return fail(LCCRF_E_STATE, "stepInference before startInference");
+        int rc = learn_sizes();
+        if (rc) return rc;
+        launch_step_stream(crf, kdevs.data(), maxV.data(), relax, stream);
+        return LCCRF_OK;
+    }
+
+    int inference(int n_iter, int with_map, float relax)
+    {
+        if (n_iter < 0) return fail(LCCRF_E_INVALID, "n_iterations < 0");
+        if (!unary_set) return fail(LCCRF_E_STATE, "unary energies not set");
+        int rc = learn_sizes();
+        if (rc) return rc;
+        if (engine_used == 2) {
+            launch_inference_fused(crf, kdevs.data(), maxV.data(), n_iter, with_map, relax, fused_lds, stream);
+            started = true;
+        } else {
+            if ((rc = start())) return rc;
+            for (int it = 0; it < n_iter; ++it) launch_step_stream(crf, kdevs.data(), maxV.data(), relax, stream);
+            if (with_map) launch_map(crf, stream);
+        }
+        HIP_TRY(hipGetLastError());
+        return LCCRF_OK;
+    }
+};
+
+}  // namespace
+
+struct lccrf_crf {
+    Engine eng;
+    int N = 0;
+    int16_t *stage_i16 = nullptr;   // pinned [N]
+    float *stage_f32 = nullptr;     // pinned [N*L]
+    int one = 0;
+};
+
+struct lccrf_batch {
+    Engine eng;
+    lccrf_batch_desc desc{};
+    bool inputs_set = false, labels_bound = false;
+    const int16_t *d_label = nullptr;
+};
+
+extern "C" {
+
+int lccrf_abi_version(void) { return LCCRF_ABI_VERSION; }
+const char *lccrf_last_error(void) { return g_err.c_str(); }
+
+int lccrf_device_count(int *count)
+{
+    if (!count) return fail(LCCRF_E_INVALID, "count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *count = 0;
+        return fail(LCCRF_E_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    }
+    *count = n;
+    return LCCRF_OK;
+}
+
+// --------------------------------------------------------------------------------------
+// object API
+// --------------------------------------------------------------------------------------
+int lccrf_create(lccrf_handle *out, int device_id, int n_points, int n_labels)
+{
+    if (!out) return fail(LCCRF_E_INVALID, "out is NULL");
+    *out = nullptr;
+    if (n_points < 0) return fail(LCCRF_E_INVALID, "n_points < 0");
+    if (n_labels < 1 || n_labels > LCCRF_MAX_LABELS) return fail(LCCRF_E_INVALID, "n_labels %d not in [1,%d]", n_labels, LCCRF_MAX_LABELS);
+    int rc = use_device(device_id);
+    if (rc) return rc;
+    lccrf_crf *h = new (std::nothrow) lccrf_crf;
+    if (!h) return fail(LCCRF_E_NOMEM, "host allocation failed");
+    h->N = n_points;
+    rc = h->eng.init(device_id, 1, n_points, n_labels);
+    if (!rc) rc = h->eng.mem.alloc_pinned(&h->stage_i16, n_points);
+    if (!rc) rc = h->eng.mem.alloc_pinned(&h->stage_f32, (size_t)n_points * n_labels);
+    if (!rc) {
+        hipError_t e = hipMemcpy(h->eng.npoints_own, &n_points, sizeof(int), hipMemcpyHostToDevice);
+        if (e != hipSuccess) rc = fail(LCCRF_E_HIP, "hipMemcpy n_points: %s", hipGetErrorString(e));
+    }
+    if (rc) {
+        h->eng.destroy();
+        delete h;
+        return rc;
+    }
+    *out = h;
+    return LCCRF_OK;
+}
+
+void lccrf_destroy(lccrf_handle h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->eng.device);
+    h->eng.destroy();
+    delete h;
+}
+
+#define CHECK_H(h)                                                    \
+    do {                                                              \
+        if (!(h)) return fail(LCCRF_E_INVALID, "handle is NULL");     \
+        HIP_TRY(hipSetDevice((h)->eng.device));                       \
+    } while (0)
+
+int lccrf_set_unary(lccrf_handle h, const float *unary)
+{
+    CHECK_H(h);
+    if (!unary && h->N) return fail(LCCRF_E_INVALID, "unary is NULL");
+    Engine &e = h->eng;
+    const size_t n = (size_t)h->N * e.L;
+    HIP_TRY(hipStreamSynchronize(e.stream));          // staging buffer may still be in flight
+    if (n) {
+        memcpy(h->stage_f32, unary, n * sizeof(float));
+        HIP_TRY(hipMemcpyAsync(e.unary_own, h->stage_f32, n * sizeof(float), hipMemcpyHostToDevice, e.stream));
+    }
+    e.crf.unary = e.unary_own;
+    e.unary_set = true;
+    return LCCRF_OK;
+}
+
+int lccrf_set_unary_from_label(lccrf_handle h, const int16_t *label, const float *conf)
+{
+    CHECK_H(h);
+    if ((!label && h->N) || !conf) return fail(LCCRF_E_INVALID, "label/conf is NULL");
+    Engine &e = h->eng;
+    if (e.L < 2) return fail(LCCRF_E_INVALID, "setUnaryEnergyFromLabel needs >= 2 labels");
+    HIP_TRY(hipStreamSynchronize(e.stream));
+    int rc = e.set_unary_from_label_tables(conf);
+    if (rc) return rc;
+    if (h->N) {
+        memcpy(h->stage_i16, label, (size_t)h->N * sizeof(int16_t));
+        HIP_TRY(hipMemcpyAsync(e.label_own, h->stage_i16, (size_t)h->N * sizeof(int16_t), hipMemcpyHostToDevice, e.stream));
+    }
+    e.crf.unary = e.unary_own;
+    launch_unary_from_label(e.crf, e.label_own, e.tbl, e.stream);
+    HIP_TRY(hipGetLastError());
+    e.unary_set = true;
+    return LCCRF_OK;
+}
+
+int lccrf_add_pairwise(lccrf_handle h, const float *features, int d, float w)
+{
+    CHECK_H(h);
+    if (!features && h->N) return fail(LCCRF_E_INVALID, "features is NULL");
+    Engine &e = h->eng;
+    int rc = e.add_kernel(d, w, true, true);
+    if (rc) return rc;
+    const int k = (int)e.kernels.size() - 1;
+    KernelState &ks = e.kernels[k];
+    const size_t n = (size_t)h->N * d;
+    if (n) {
+        memcpy(ks.feat_stage, features, n * sizeof(float));   // caller may free `features` right away
+        HIP_TRY(hipMemcpyAsync(ks.feat_own, ks.feat_stage, n * sizeof(float), hipMemcpyHostToDevice, e.stream));
+    }
+    return e.build_kernel(k);
+}
+
+int lccrf_add_appearance_kernel(lccrf_handle h, float w, const float *vobserv, const float *verror,
+                                float sd_observ, float sd_error)
+{
+    CHECK_H(h);
+    if ((!vobserv || !verror) && h->N) return fail(LCCRF_E_INVALID, "vobserv/verror is NULL");
+    std::vector<float> f((size_t)h->N * 2 + 1);
+    for (int i = 0; i < h->N; ++i) {                  // pairwise3d.h:41-44
+        f[2 * i + 0] = vobserv[i] / sd_observ;
+        f[2 * i + 1] = verror[i] / sd_error;
+    }
+    return lccrf_add_pairwise(h, f.data(), 2, w);
+}
+
+int lccrf_add_smooth_kernel(lccrf_handle h, float w, const float *xy, float sd2d)
+{
+    CHECK_H(h);
+    if (!xy && h->N) return fail(LCCRF_E_INVALID, "xy is NULL");
+    std::vector<float> f((size_t)h->N * 2 + 1);
+    for (int i = 0; i < h->N; ++i) {                  // pairwise3d.h:64-66
+        f[2 * i + 0] = xy[2 * i + 0] / sd2d;
+        f[2 * i + 1] = xy[2 * i + 1] / sd2d;
+    }
+    return lccrf_add_pairwise(h, f.data(), 2, w);
+}
+
+int lccrf_start_inference(lccrf_handle h)
+{
+    CHECK_H(h);
+    return h->eng.start();
+}
+
+int lccrf_step_inference(lccrf_handle h, float relax)
+{
+    CHECK_H(h);
+    return h->eng.step(relax);
+}
+
+int lccrf_build_map(lccrf_handle h)
+{
+    CHECK_H(h);
+    launch_map(h->eng.crf, h->eng.stream);
+    HIP_TRY(hipGetLastError());
+    return LCCRF_OK;
+}
+
+int lccrf_inference(lccrf_handle h, int n_iterations, int with_map, float relax)
+{
+    CHECK_H(h);
+    return h->eng.inference(n_iterations, with_map, relax);
+}
+
+int lccrf_get_map(lccrf_handle h, int16_t *map_out)
+{
+    CHECK_H(h);
+    if (!map_out && h->N) return fail(LCCRF_E_INVALID, "map_out is NULL");
+    Engine &e = h->eng;
+    if (h->N) HIP_TRY(hipMemcpyAsync(h->stage_i16, e.crf.map, (size_t)h->N * sizeof(int16_t), hipMemcpyDeviceToHost, e.stream));
+    HIP_TRY(hipStreamSynchronize(e.stream));
+    if (h->N) memcpy(map_out, h->stage_i16, (size_t)h->N * sizeof(int16_t));
+    return LCCRF_OK;
+}
+
+static int copy_out_f32(lccrf_handle h, const float *dev, float *out, size_t n)
+{
+    Engine &e = h->eng;
+    if (n) HIP_TRY(hipMemcpyAsync(h->stage_f32, dev, n * sizeof(float), hipMemcpyDeviceToHost, e.stream));
+    HIP_TRY(hipStreamSynchronize(e.stream));
+    if (n) memcpy(out, h->stage_f32, n * sizeof(float));
+    return LCCRF_OK;
+}
+
+int lccrf_get_probability(lccrf_handle h, float *prob_out)
+{
+    CHECK_H(h);
+    if (!prob_out && h->N) return fail(LCCRF_E_INVALID, "prob_out is NULL");
+    return copy_out_f32(h, h->eng.crf.Q, prob_out, (size_t)h->N * h->eng.L);
+}
+
+int lccrf_get_unary(lccrf_handle h, float *unary_out)
+{
+    CHECK_H(h);
+    if (!unary_out && h->N) return fail(LCCRF_E_INVALID, "unary_out is NULL");
+    return copy_out_f32(h, h->eng.crf.unary, unary_out, (size_t)h->N * h->eng.L);
+}
+
+#define CHECK_K(h, k)                                                                      \
+    do {                                                                                   \
+        if ((k) < 0 || (k) >= (int)(h)->eng.kernels.size())                                \
+            return fail(LCCRF_E_INVALID, "kernel index %d out of range", (k));             \
+    } while (0)
+
+int lccrf_get_lattice_size(lccrf_handle h, int kernel, int *n_vertices)
+{
+    CHECK_H(h);
+    CHECK_K(h, kernel);
+    if (!n_vertices) return fail(LCCRF_E_INVALID, "n_vertices is NULL");
+    HIP_TRY(hipStreamSynchronize(h->eng.stream));
+    *n_vertices = h->eng.V_host[(size_t)kernel * h->eng.Fcap];
+    return LCCRF_OK;
+}
+
+int lccrf_get_norm(lccrf_handle h, int kernel, float *norm_out)
+{
+    CHECK_H(h);
+    CHECK_K(h, kernel);
+    if (!norm_out && h->N) return fail(LCCRF_E_INVALID, "norm_out is NULL");
+    HIP_TRY(hipStreamSynchronize(h->eng.stream));
+    if (h->N) HIP_TRY(hipMemcpy(norm_out, h->eng.kernels[kernel].dev.norm, (size_t)h->N * sizeof(float), hipMemcpyDeviceToHost));
+    return LCCRF_OK;
+}
+
+int lccrf_get_lattice(lccrf_handle h, int kernel, int32_t *offset_out, float *bary_out, int32_t *nbr_out)
+{
+    CHECK_H(h);
+    CHECK_K(h, kernel);
+    Engine &e = h->eng;
+    HIP_TRY(hipStreamSynchronize(e.stream));
+    const KernelDev &k = e.kernels[kernel].dev;
+    const size_t ne = (size_t)h->N * k.D1;
+    if (offset_out && ne) HIP_TRY(hipMemcpy(offset_out, k.offset, ne * sizeof(int), hipMemcpyDeviceToHost));
+    if (bary_out && ne) HIP_TRY(hipMemcpy(bary_out, k.bary, ne * sizeof(float), hipMemcpyDeviceToHost));
+    if (nbr_out) {
+        const int V = e.V_host[(size_t)kernel * e.Fcap];
+        for (int j = 0; j < k.D1 && V; ++j)           // device rows are strided by Epad, output by V
+            HIP_TRY(hipMemcpy(nbr_out + (size_t)j * V * 2, k.nbr + (size_t)j * k.Epad * 2, (size_t)V * 2 * sizeof(int),
+                              hipMemcpyDeviceToHost));
+    }
+    return LCCRF_OK;
+}
+
+// --------------------------------------------------------------------------------------
+// batch API
+// --------------------------------------------------------------------------------------
+int lccrf_batch_create(lccrf_batch_handle *out, int device_id, const lccrf_batch_desc *desc)
+{
+    if (!out || !desc) return fail(LCCRF_E_INVALID, "out/desc is NULL");
+    *out = nullptr;
+    if (desc->max_frames < 1 || desc->max_points < 0) return fail(LCCRF_E_INVALID, "max_frames < 1 or max_points < 0");
+    if (desc->n_labels < 1 || desc->n_labels > LCCRF_MAX_LABELS) return fail(LCCRF_E_INVALID, "n_labels out of range");
+    if (desc->n_kernels < 0 || desc->n_kernels > LCCRF_MAX_KERNELS) return fail(LCCRF_E_INVALID, "n_kernels out of range");
+    int rc = use_device(device_id);
+    if (rc) return rc;
+    lccrf_batch *b = new (std::nothrow) lccrf_batch;
+    if (!b) return fail(LCCRF_E_NOMEM, "host allocation failed");
+    b->desc = *desc;
+    rc = b->eng.init(device_id, desc->max_frames, desc->max_points, desc->n_labels);
+    for (int k = 0; k < desc->n_kernels && !rc; ++k) rc = b->eng.add_kernel(desc->feat_dims[k], desc->weights[k], true, false);
+    if (rc) {
+        b->eng.destroy();
+        delete b;
+        return rc;
+    }
+    *out = b;
+    return LCCRF_OK;
+}
+
+void lccrf_batch_destroy(lccrf_batch_handle b)
+{
+    if (!b) return;
+    (void)hipSetDevice(b->eng.device);
+    b->eng.destroy();
+    delete b;
+}
+
+static int batch_common_inputs(lccrf_batch *b, int n_frames, const float *conf, bool have_unary, bool have_label)
+{
+    Engine &e = b->eng;
+    if (n_frames < 1 || n_frames > e.Fcap) return fail(LCCRF_E_CAPACITY, "n_frames %d not in [1,%d]", n_frames, e.Fcap);
+    if (have_unary == have_label) return fail(LCCRF_E_INVALID, "exactly one of unary / label must be given");
+    if (have_label && (!conf || e.L < 2)) return fail(LCCRF_E_INVALID, "label input needs conf[n_labels] and >= 2 labels");
+    e.F = n_frames;
+    e.sync_views();
+    e.unary_set = false;
+    e.built = false;
+    e.started = false;
+    return LCCRF_OK;
+}
+
+int lccrf_batch_set_inputs_host(lccrf_batch_handle b, int n_frames, const int32_t *n_points, const float *unary,
+                                const int16_t *label, const float *conf, const float *const *features)
+{
+    CHECK_H(b);
+    if (!n_points) return fail(LCCRF_E_INVALID, "n_points is NULL");
+    if (b->desc.n_kernels && !features) return fail(LCCRF_E_INVALID, "features is NULL");
+    int rc = batch_common_inputs(b, n_frames, conf, unary != nullptr, label != nullptr);
+    if (rc) return rc;
+    Engine &e = b->eng;
+    for (int f = 0; f < n_frames; ++f)
+        if (n_points[f] < 0 || n_points[f] > e.maxN) return fail(LCCRF_E_CAPACITY, "n_points[%d]=%d not in [0,%d]", f, n_points[f], e.maxN);
+    HIP_TRY(hipStreamSynchronize(e.stream));
+    HIP_TRY(hipMemcpy(e.npoints_own, n_points, sizeof(int) * n_frames, hipMemcpyHostToDevice));
+    e.crf.n_points = e.npoints_own;
+    e.crf.unary = e.unary_own;
+    const size_t per = (size_t)e.maxN;
+    if (unary) {
+        HIP_TRY(hipMemcpy(e.unary_own, unary, sizeof(float) * n_frames * per * e.L, hipMemcpyHostToDevice));
+    } else {
+        HIP_TRY(hipMemcpy(e.label_own, label, sizeof(int16_t) * n_frames * per, hipMemcpyHostToDevice));
+        if ((rc = e.set_unary_from_label_tables(conf))) return rc;
+        launch_unary_from_label(e.crf, e.label_own, e.tbl, e.stream);
+    }
+    for (int k = 0; k < b->desc.n_kernels; ++k) {
+        if (!features[k]) return fail(LCCRF_E_INVALID, "features[%d] is NULL", k);
+        KernelState &ks = e.kernels[k];
+        HIP_TRY(hipMemcpy(ks.feat_own, features[k], sizeof(float) * n_frames * per * ks.dev.d, hipMemcpyHostToDevice));
+        ks.dev.feat = ks.feat_own;
+    }
+    e.sync_views();
+    e.unary_set = true;
+    b->inputs_set = true;
+    return LCCRF_OK;
+}
+
+int lccrf_batch_bind_inputs_device(lccrf_batch_handle b, int n_frames, const int32_t *d_n_points, const float *d_unary,
+                                   const int16_t *d_label, const float *conf, const float *const *d_features)
+{
+    CHECK_H(b);
+    if (!d_n_points) return fail(LCCRF_E_INVALID, "d_n_points is NULL");
+    if (b->desc.n_kernels && !d_features) return fail(LCCRF_E_INVALID, "d_features is NULL");
+    int rc = batch_common_inputs(b, n_frames, conf, d_unary != nullptr, d_label != nullptr);
+    if (rc) return rc;
+    Engine &e = b->eng;
+    e.crf.n_points = d_n_points;
+    if (d_unary) {
+        e.crf.unary = const_cast<float *>(d_unary);   // read-only use
+    } else {
+        e.crf.unary = e.unary_own;
+        if ((rc = e.set_unary_from_label_tables(conf))) return rc;
+        launch_unary_from_label(e.crf, d_label, e.tbl, e.stream);
+    }
+    for (int k = 0; k < b->desc.n_kernels; ++k) {
+        if (!d_features[k]) return fail(LCCRF_E_INVALID, "d_features[%d] is NULL", k);
+        e.kernels[k].dev.feat = d_features[k];
+    }
+    e.sync_views();
+    HIP_TRY(hipGetLastError());
+    e.unary_set = true;
+    b->inputs_set = true;
+    return LCCRF_OK;
+}
+
+static hipStream_t pick_stream(lccrf_batch *b, void *stream) { return stream ? (hipStream_t)stream : b->eng.stream; }
+
+int lccrf_batch_build(lccrf_batch_handle b, void *stream)
+{
+    CHECK_H(b);
+    if (!b->inputs_set) return fail(LCCRF_E_STATE, "inputs not set");
+    Engine &e = b->eng;
+    hipStream_t own = e.stream;
+    e.stream = pick_stream(b, stream);
+    HIP_TRY(hipEventRecord(e.ev[0], e.stream));
+    int rc = LCCRF_OK;
+    for (int k = 0; k < (int)e.kernels.size() && !rc; ++k) rc = e.build_kernel(k);
+    if (!rc) {
+        hipError_t er = hipEventRecord(e.ev[1], e.stream);
+        if (er != hipSuccess) rc = fail(LCCRF_E_HIP, "hipEventRecord: %s", hipGetErrorString(er));
+    }
+    e.timed_build = !rc;
+    e.built = !rc;
+    if (e.stream != own) {                            // V read-back must land before learn_sizes() looks
+        (void)hipStreamSynchronize(e.stream);
+    }
+    e.stream = own;
+    return rc;
+}
+
+int lccrf_batch_inference(lccrf_batch_handle b, int n_iterations, int with_map, float relax, void *stream)
+{
+    CHECK_H(b);
+    Engine &e = b->eng;
+    if (!e.built) return fail(LCCRF_E_STATE, "lccrf_batch_build has not run for these inputs");
+    int rc = e.learn_sizes();
+    if (rc) return rc;
+    hipStream_t own = e.stream;
+    e.stream = pick_stream(b, stream);
+    HIP_TRY(hipEventRecord(e.ev[2], e.stream));
+    rc = e.inference(n_iterations, with_map, relax);
+    if (!rc) {
+        hipError_t er = hipEventRecord(e.ev[3], e.stream);
+        if (er != hipSuccess) rc = fail(LCCRF_E_HIP, "hipEventRecord: %s", hipGetErrorString(er));
+    }
+    e.timed_inf = !rc;
+    e.stream = own;
+    return rc;
+}
+
+int lccrf_batch_synchronize(lccrf_batch_handle b)
+{
+    CHECK_H(b);
+    HIP_TRY(hipStreamSynchronize(b->eng.stream));
+    HIP_TRY(hipDeviceSynchronize());
+    return LCCRF_OK;
+}
+
+int lccrf_batch_get_map_host(lccrf_batch_handle b, int16_t *map_out)
+{
+    CHECK_H(b);
+    if (!map_out) return fail(LCCRF_E_INVALID, "map_out is NULL");
+    Engine &e = b->eng;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(map_out, e.crf.map, sizeof(int16_t) * (size_t)e.F * e.maxN, hipMemcpyDeviceToHost));
+    return LCCRF_OK;
+}
+
+int lccrf_batch_get_probability_host(lccrf_batch_handle b, float *prob_out)
+{
+    CHECK_H(b);
+    if (!prob_out) return fail(LCCRF_E_INVALID, "prob_out is NULL");
+    Engine &e = b->eng;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(prob_out, e.crf.Q, sizeof(float) * (size_t)e.F * e.maxN * e.L, hipMemcpyDeviceToHost));
+    return LCCRF_OK;
+}
+
+int lccrf_batch_get_lattice_sizes_host(lccrf_batch_handle b, int kernel, int32_t *n_vertices_out)
+{
+    CHECK_H(b);
+    CHECK_K(b, kernel);
+    if (!n_vertices_out) return fail(LCCRF_E_INVALID, "n_vertices_out is NULL");
+    Engine &e = b->eng;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(n_vertices_out, e.kernels[kernel].dev.V, sizeof(int) * e.F, hipMemcpyDeviceToHost));
+    return LCCRF_OK;
+}
+
+int lccrf_batch_get_norm_host(lccrf_batch_handle b, int kernel, float *norm_out)
+{
+    CHECK_H(b);
+    CHECK_K(b, kernel);
+    if (!norm_out) return fail(LCCRF_E_INVALID, "norm_out is NULL");
+    Engine &e = b->eng;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(norm_out, e.kernels[kernel].dev.norm, sizeof(float) * (size_t)e.F * e.maxN, hipMemcpyDeviceToHost));
+    return LCCRF_OK;
+}
+
+int lccrf_batch_device_buffers(lccrf_batch_handle b, const int16_t **d_map, const float **d_prob)
+{
+    CHECK_H(b);
+    if (d_map) *d_map = b->eng.crf.map;
+    if (d_prob) *d_prob = b->eng.crf.Q;
+    return LCCRF_OK;
+}
+
+int lccrf_batch_set_engine(lccrf_batch_handle b, int engine)
+{
+    CHECK_H(b);
+    if (engine < 0 || engine > 2) return fail(LCCRF_E_INVALID, "engine must be 0, 1 or 2");
+    b->eng.engine_pref = engine;
+    b->eng.sizes_known = false;
+    return LCCRF_OK;
+}
+
+int lccrf_batch_get_engine(lccrf_batch_handle b, int *engine_in_use)
+{
+    CHECK_H(b);
+    if (!engine_in_use) return fail(LCCRF_E_INVALID, "engine_in_use is NULL");
+    int rc = b->eng.built ? b->eng.learn_sizes() : LCCRF_OK;
+    if (rc) return rc;
+    *engine_in_use = b->eng.engine_used;
+    return LCCRF_OK;
+}
+
+int lccrf_batch_last_timing(lccrf_batch_handle b, float *inference_ms, float *build_ms)
+{
+    CHECK_H(b);
+    Engine &e = b->eng;
+    HIP_TRY(hipDeviceSynchronize());
+    if (build_ms) {
+        *build_ms = 0.0f;
+        if (e.timed_build) HIP_TRY(hipEventElapsedTime(build_ms, e.ev[0], e.ev[1]));
+    }
+    if (inference_ms) {
+        *inference_ms = 0.0f;
+        if (e.timed_inf) HIP_TRY(hipEventElapsedTime(inference_ms, e.ev[2], e.ev[3]));
+    }
+    return LCCRF_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,198 @@
+// device_math.h -- the per-point / per-row arithmetic of the path, shared by both engines.
+//
+// Everything here must round exactly like the reference's SSE2 build: fp32 throughout,
+// no fused multiply-add (the translation units are compiled with -ffp-contract=off),
+// IEEE division, round-half-even where the reference uses _mm_cvtps_epi32.
+// Reference paths are under /root/reference/Thirdparty/DenseCRF/include/.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace lccrf {
+
+// ---------------------------------------------------------------------------------------
+// lattice coordinates of one point.  ref: permutohedral_cpu.h:304-366
+//   out: r0[i]  = i-th coordinate of the enclosing simplex's remainder-0 vertex (i < D)
+//        rk[i]  = rank of coordinate i                                          (i < D)
+//        b[rem] = barycentric weight of the simplex corner with remainder `rem` (rem <= D)
+// ---------------------------------------------------------------------------------------
+template <int D>
+__device__ __forceinline__ void point_record(const float (&feat)[D], const float *scale, float inv_dp1,
+                                             int16_t (&r0)[D], uint8_t (&rk)[D], float (&b)[D + 1])
+{
+    constexpr int D1 = D + 1;
+    const float dp1 = (float)D1;
+
+    // elevate, :304-310
+    float el[D1];
+    float sm = 0.0f;
+#pragma unroll
+    for (int j = D; j > 0; --j) {
+        const float cf = feat[j - 1] * scale[j - 1];
+        el[j] = sm - (float)j * cf;
+        sm += cf;
+    }
+    el[0] = sm;
+
+    // nearest remainder-0 point; _mm_cvtps_epi32 rounds half to even, :313-323 (quirk Q2)
+    float rem0[D1], rank[D1];
+    float sum = 0.0f;
+#pragma unroll
+    for (int i = 0; i < D1; ++i) {
+        const float v = (float)__float2int_rn(inv_dp1 * el[i]);
+        rem0[i] = v * dp1;
+        sum += v;
+        rank[i] = 0.0f;
+    }
+
+    // rank by strict fp32 '<', :326-336 (quirk Q3)
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        const float di = el[i] - rem0[i];
+#pragma unroll
+        for (int j = i + 1; j < D1; ++j) {
+            const float dj = el[j] - rem0[j];
+            const float c = (di < dj) ? 1.0f : 0.0f;
+            rank[i] += c;
+            rank[j] += 1.0f - c;
+        }
+    }
+
+    // off-plane fix-up, :339-345
+#pragma unroll
+    for (int i = 0; i < D1; ++i) {
+        rank[i] += sum;
+        const float add = (rank[i] < 0.0f) ? dp1 : 0.0f;
+        const float sub = (rank[i] >= dp1) ? dp1 : 0.0f;
+        const float adj = add - sub;
+        rank[i] += adj;
+        rem0[i] += adj;
+    }
+
+    // barycentric weights, accumulated over i = 0..D in order, :348-366.
+    // bb has D+2 cells; the indexed updates are written as selects so it stays in registers.
+    float bb[D1 + 1];
+#pragma unroll
+    for (int q = 0; q < D1 + 1; ++q) bb[q] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < D1; ++i) {
+        const float v = (el[i] - rem0[i]) * inv_dp1;
+        const int p = (int)((float)D - rank[i]);
+#pragma unroll
+        for (int q = 0; q < D1 + 1; ++q) {
+            if (q == p) bb[q] = bb[q] + v;
+            if (q == p + 1) bb[q] = bb[q] - v;
+        }
+    }
+    bb[0] += 1.0f + bb[D1];
+
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        r0[i] = (int16_t)(int)rem0[i];
+        rk[i] = (uint8_t)(int)rank[i];
+    }
+#pragma unroll
+    for (int i = 0; i < D1; ++i) b[i] = bb[i];
+}
+
+// i-th key coordinate of the corner with remainder `rem`: rem0 + canonical[rem][rank],
+// canonical[rem][r] = rem if r <= D-rem else rem-(D+1).  ref: :274-279,373.
+template <int D>
+__device__ __forceinline__ int16_t vertex_coord(int16_t r0, uint8_t rk, int rem)
+{
+    const int c = ((int)rk <= D - rem) ? rem : rem - (D + 1);
+    return (int16_t)(r0 + c);
+}
+
+// Any hash works: vertex numbering comes from first-occurrence order, not from the table.
+template <int D>
+__device__ __forceinline__ unsigned hash_key(const int16_t (&key)[D])
+{
+    unsigned h = 0;
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        h += (unsigned)(int)key[i];
+        h *= 1664525u;
+    }
+    h ^= h >> 15;
+    h *= 2246822519u;
+    h ^= h >> 13;
+    return h;
+}
+
+// ---------------------------------------------------------------------------------------
+// softmax with the reference's polynomial exp.  ref: densecrf3d.h:51-98
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ float very_fast_exp(float x)     // densecrf3d.h:51-54
+{
+    return 1 - x * (0.9999999995f - x * (0.4999999206f - x * (0.1666653019f - x * (0.0416573475f
+             - x * (0.0083013598f - x * (0.0013298820f - x * (0.0001413161f)))))));
+}
+
+__device__ __forceinline__ float fast_exp(float x)          // densecrf3d.h:55-67
+{
+    bool less_zero = true;
+    if (x < 0) { less_zero = false; x = -x; }
+    if (x > 20) return 0;
+    int mult = 0;
+    // the thresholds are double products compared against the promoted float (quirk Q5)
+    while ((double)x > 0.69 * 2 * 2 * 2) { mult += 3; x /= 8.0f; }
+    while ((double)x > 0.69 * 2 * 2)     { mult += 2; x /= 4.0f; }
+    while ((double)x > 0.69)             { mult += 1; x /= 2.0f; }
+    x = very_fast_exp(x);
+    while (mult) { mult--; x = x * x; }
+    return less_zero ? 1 / x : x;
+}
+
+// One row of expAndNormalize (densecrf3d.h:70-98); `out` may alias `in`.
+__device__ __forceinline__ void exp_and_normalize_row(const float *in, float *out, int L, float scale,
+                                                      float relax)
+{
+    float mx = scale * in[0];
+    for (int j = 1; j < L; ++j) {
+        const float s = scale * in[j];
+        if (mx < s) mx = s;
+    }
+    float tt = 0;
+    for (int j = 0; j < L; ++j) tt += fast_exp(scale * in[j] - mx);
+    for (int j = 0; j < L; ++j) {
+        const float v = fast_exp(scale * in[j] - mx) / tt;
+        if (relax == 1) out[j] = v;
+        else out[j] = (1 - relax) * out[j] + relax * v;
+    }
+}
+
+// Compile-time-width variant for values already in registers.
+template <int L>
+__device__ __forceinline__ void exp_and_normalize_reg(const float (&in)[L], float (&out)[L], float scale,
+                                                      float relax)
+{
+    float mx = scale * in[0];
+#pragma unroll
+    for (int j = 1; j < L; ++j) {
+        const float s = scale * in[j];
+        if (mx < s) mx = s;
+    }
+    float v[L];
+    float tt = 0;
+#pragma unroll
+    for (int j = 0; j < L; ++j) { v[j] = fast_exp(scale * in[j] - mx); tt += v[j]; }
+#pragma unroll
+    for (int j = 0; j < L; ++j) {
+        const float p = v[j] / tt;
+        if (relax == 1) out[j] = p;
+        else out[j] = (1 - relax) * out[j] + relax * p;
+    }
+}
+
+__device__ __forceinline__ int argmax_row(const float *p, int L)   // densecrf3d.h:140-149
+{
+    float mx = p[0];
+    int imx = 0;
+    for (int m = 1; m < L; ++m)
+        if (mx < p[m]) { mx = p[m]; imx = m; }
+    return imx;
+}
+
+}  // namespace lccrf

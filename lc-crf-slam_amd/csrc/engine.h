@@ -1,0 +1,77 @@
+// engine.h -- internal structures shared by the HIP kernels and the C-ABI layer.
+//
+// Vocabulary follows the reference (Thirdparty/DenseCRF): a CRF over N *points*
+// (keypoints) with L *labels* and K pairwise *kernels*; every kernel owns a
+// permutohedral *lattice* with V *vertices*; a point touches d+1 vertices, one per
+// *remainder*; the pair (point, remainder) is an *entry* e = point*(d+1)+remainder.
+// A *frame* is one independent CRF; a batch holds F frames with a common stride.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/lccrf.h"
+
+namespace lccrf {
+
+constexpr int kMaxD = LCCRF_MAX_DIMS;
+constexpr int kEmpty = -1;
+
+// Device view of one pairwise kernel across all frames of a batch.
+// All per-frame arrays are strided by the capacities below (not by the actual N / V).
+struct KernelDev {
+    int d, D1;            // feature dims, d+1
+    int maxN;             // per-frame stride of point arrays (features, norm)
+    int maxNpad;          // maxN rounded up to a multiple of 4 (phantom points, quirk Q1)
+    int Epad;             // entries per frame = maxNpad * D1 (also the vertex capacity)
+    int cap;              // hash capacity per frame (power of two >= 2*Epad)
+    int vstride;          // per-frame stride of val0/val1 = (Epad+1)*L of the owning CRF
+    float w;              // kernel weight (PottsPotential3D::w_)
+    float alpha;          // 1/(1+2^-d)                     permutohedral_cpu.h:681
+    float inv_dp1;        // 1.0f/(d+1)                     permutohedral_cpu.h:249
+    float scale[kMaxD];   // elevation scale factors        permutohedral_cpu.h:282-285
+
+    const float *feat;    // [F][maxN][d]      input features (already / stdev)
+    int16_t *rem0;        // [F][maxNpad][d]   nearest remainder-0 lattice point (first d coords)
+    uint8_t *rank;        // [F][maxNpad][d]   rank of each coordinate
+    float *bary;          // [F][Epad]         barycentric weight of every entry
+    int *offset;          // [F][Epad]         vertex id of every entry (reference offset_)
+    int *slot;            // [F][cap]          hash slots: lowest entry id with that key, or -1
+    int *slot_of;         // [F][Epad]         slot index each entry landed in
+    int *flag;            // [F][Epad+1]       scratch: first-occurrence flags / row counts / unsorted rows
+    int *prefix;          // [F][Epad+1]       exclusive scan of flag == dense vertex id of a first entry
+    int *rep;             // [F][Epad]         vertex id -> representative (first) entry
+    int *V;               // [F]               number of vertices (reference M_)
+    int *nbr;             // [F][D1][Epad][2]  blur neighbours {n1,n2} per (axis, vertex), -1 absent
+    int *rowptr;          // [F][Epad+1]       CSR: vertex -> range of splat contributions
+    int *csr_pt;          // [F][Epad]         contributing point, ascending within a row
+    float *csr_w;         // [F][Epad]         its barycentric weight
+    float *norm;          // [F][maxN]         1/(K*1 + 1e-20)  (PottsPotential3D::norm_)
+    float *val0, *val1;   // [F][(Epad+1)*L]   lattice values, slot 0 = "absent neighbour" = 0
+};
+
+// Device view of the CRF state of a batch.
+struct CrfDev {
+    int F, maxN, L, K;
+    const int *n_points;  // [F]
+    float *unary;         // [F][maxN][L]
+    float *Q;             // [F][maxN][L]   current_
+    float *next;          // [F][maxN][L]   next_
+    int16_t *map;         // [F][maxN]
+};
+
+// ---- streaming engine (any size; every array in HBM) ---------------------------------
+void launch_build_kernel(const KernelDev &kd, const CrfDev &c, int maxV_hint, hipStream_t s);
+void launch_norm(const KernelDev &kd, const CrfDev &c, int maxV, hipStream_t s);
+void launch_unary_from_label(const CrfDev &c, const int16_t *label, const float *tbl, hipStream_t s);
+void launch_start(const CrfDev &c, hipStream_t s);
+void launch_step_stream(const CrfDev &c, const KernelDev *kds, const int *maxV, float relax,
+                        hipStream_t s);
+void launch_map(const CrfDev &c, hipStream_t s);
+
+// ---- fused engine (SLAM sizes; one workgroup per frame, lattice values in LDS) --------
+bool fused_supported(const CrfDev &c, const KernelDev *kds, const int *maxV, size_t *lds_bytes);
+void launch_inference_fused(const CrfDev &c, const KernelDev *kds, const int *maxV, int n_iter,
+                            int with_map, float relax, size_t lds_bytes, hipStream_t s);
+
+}  // namespace lccrf

@@ -1,0 +1,456 @@
+// stream_engine.hip -- the general ("streaming") engine: every array lives in HBM, one
+// kernel launch per phase, frames of a batch in grid.y.  Handles any N / d / L.
+//
+// Compiled with -ffp-contract=off: the reference is an SSE2 build without FMA, so every
+// a*b+c must stay two roundings.  No -ffast-math: fp32 division must
+// be IEEE (V/=tt, 1/(norm+1e-20)), denormals are kept (gfx950 default).
+//
+// Reference being restated (paths under /root/reference/Thirdparty/DenseCRF/include/):
+//   lattice construction   permutohedral_cpu.h:241-424   -> k_points / k_insert / k_offsets / k_neighbors
+//   splat / blur / slice   permutohedral_cpu.h:634-699   -> k_splat / k_blur / k_slice
+//   normalisation          pairwise3d.h:20-28            -> launch_norm
+//   apply                  pairwise3d.h:73-78            -> k_slice (mode APPLY)
+//   stepInit               densecrf3d.h:154-158          -> k_slice (first kernel)
+//   expAndNormalize        densecrf3d.h:51-98            -> k_softmax
+//   buildMap               densecrf3d.h:136-151          -> k_map
+#include "engine.h"
+#include "device_math.h"
+
+namespace lccrf {
+
+namespace {
+
+constexpr int kBlock = 256;
+
+inline dim3 grid_for(long work, int F) { return dim3((unsigned)((work + kBlock - 1) / kBlock), (unsigned)F); }
+
+// ---------------------------------------------------------------------------------------
+// lattice construction
+// ---------------------------------------------------------------------------------------
+
+// One thread per point (phantom lanes included): elevate, round, rank, barycentric.
+// ref: permutohedral_cpu.h:294-366.
+template <int D>
+__global__ void __launch_bounds__(kBlock) k_points(KernelDev kd, const int *__restrict__ n_points)
+{
+    constexpr int D1 = D + 1;
+    const int f = blockIdx.y;
+    const int N = n_points[f];
+    const int Npad = (N + 3) & ~3;                       // blocks of four, :294
+    const int n = blockIdx.x * kBlock + threadIdx.x;
+    if (n >= Npad) return;
+
+    float feat[D];
+    const float *fp = kd.feat + ((size_t)f * kd.maxN + n) * D;
+#pragma unroll
+    for (int j = 0; j < D; ++j) feat[j] = (n < N) ? fp[j] : 0.0f;   // phantom lanes, :299
+
+    int16_t r0[D];
+    uint8_t rk[D];
+    float b[D1];
+    point_record<D>(feat, kd.scale, kd.inv_dp1, r0, rk, b);
+
+    int16_t *r0p = kd.rem0 + ((size_t)f * kd.maxNpad + n) * D;
+    uint8_t *rkp = kd.rank + ((size_t)f * kd.maxNpad + n) * D;
+    float *bp = kd.bary + (size_t)f * kd.Epad + (size_t)n * D1;
+#pragma unroll
+    for (int i = 0; i < D; ++i) { r0p[i] = r0[i]; rkp[i] = rk[i]; }
+#pragma unroll
+    for (int i = 0; i < D1; ++i) bp[i] = b[i];
+}
+
+template <int D>
+__device__ __forceinline__ void load_entry_key(const KernelDev &kd, int f, int e, int16_t (&key)[D])
+{
+    constexpr int D1 = D + 1;
+    const int pt = e / D1, rem = e - pt * D1;
+    const int16_t *r0 = kd.rem0 + ((size_t)f * kd.maxNpad + pt) * D;
+    const uint8_t *rk = kd.rank + ((size_t)f * kd.maxNpad + pt) * D;
+#pragma unroll
+    for (int i = 0; i < D; ++i) key[i] = vertex_coord<D>(r0[i], rk[i], rem);
+}
+
+// One thread per entry: insert its vertex key into the frame's hash table.  A slot ends up
+// holding the LOWEST entry id carrying that key, i.e. the entry at which the reference's
+// sequential HashTableCPU::find(create=true) would have created the vertex (:134-161,371-377).
+template <int D>
+__global__ void __launch_bounds__(kBlock) k_insert(KernelDev kd, const int *__restrict__ n_points)
+{
+    constexpr int D1 = D + 1;
+    const int f = blockIdx.y;
+    const int Npad = (n_points[f] + 3) & ~3;
+    const int e = blockIdx.x * kBlock + threadIdx.x;
+    if (e >= Npad * D1) return;
+
+    int16_t key[D];
+    load_entry_key<D>(kd, f, e, key);
+    const unsigned mask = (unsigned)kd.cap - 1u;
+    unsigned h = hash_key<D>(key) & mask;
+    int *slot = kd.slot + (size_t)f * kd.cap;
+    for (;;) {
+        const int prev = atomicCAS(&slot[h], kEmpty, e);
+        if (prev == kEmpty || prev == e) break;
+        int16_t other[D];
+        load_entry_key<D>(kd, f, prev, other);
+        bool same = true;
+#pragma unroll
+        for (int i = 0; i < D; ++i) same &= (other[i] == key[i]);
+        if (same) { atomicMin(&slot[h], e); break; }
+        h = (h + 1u) & mask;
+    }
+    kd.slot_of[(size_t)f * kd.Epad + e] = (int)h;
+}
+
+// flag[e] = 1 iff entry e is the first occurrence of its vertex.
+__global__ void __launch_bounds__(kBlock) k_first_flag(KernelDev kd, const int *__restrict__ n_points)
+{
+    const int f = blockIdx.y;
+    const int live = ((n_points[f] + 3) & ~3) * kd.D1;
+    const int e = blockIdx.x * kBlock + threadIdx.x;
+    if (e > kd.Epad) return;
+    int v = 0;
+    if (e < live) {
+        const int s = kd.slot_of[(size_t)f * kd.Epad + e];
+        v = (kd.slot[(size_t)f * kd.cap + s] == e);
+    }
+    kd.flag[(size_t)f * (kd.Epad + 1) + e] = v;
+}
+
+// Exclusive scan of n ints per frame by one 1024-thread workgroup (wave scans + carry).
+// in/out strided by `stride` per frame; the grand total goes to total[f] if non-null.
+__global__ void __launch_bounds__(1024) k_scan_frame(const int *__restrict__ in, int *__restrict__ out,
+                                                     int n, int stride, int *__restrict__ total)
+{
+    __shared__ int wave_sum[16];
+    __shared__ int carry_s;
+    const int f = blockIdx.x;
+    in += (size_t)f * stride;
+    out += (size_t)f * stride;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += 1024) {
+        const int i = base + threadIdx.x;
+        const int x = (i < n) ? in[i] : 0;
+        int incl = x;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int y = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += y;
+        }
+        if (lane == 63) wave_sum[wave] = incl;
+        __syncthreads();
+        int wbase = 0;
+        for (int w = 0; w < wave; ++w) wbase += wave_sum[w];
+        const int carry = carry_s;
+        if (i < n) out[i] = carry + wbase + incl - x;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = carry + wbase + incl;
+        __syncthreads();
+    }
+    if (total && threadIdx.x == 0) total[f] = carry_s;
+}
+
+// offset[e] = dense id of e's vertex; the first entry of each vertex registers as its
+// representative.  Ids come out in first-insertion order, exactly the reference's ids.
+__global__ void __launch_bounds__(kBlock) k_offsets(KernelDev kd, const int *__restrict__ n_points)
+{
+    const int f = blockIdx.y;
+    const int live = ((n_points[f] + 3) & ~3) * kd.D1;
+    const int e = blockIdx.x * kBlock + threadIdx.x;
+    if (e >= live) return;
+    const size_t fe = (size_t)f * kd.Epad;
+    const int *prefix = kd.prefix + (size_t)f * (kd.Epad + 1);
+    const int r = kd.slot[(size_t)f * kd.cap + kd.slot_of[fe + e]];
+    const int id = prefix[r];
+    kd.offset[fe + e] = id;
+    if (r == e) kd.rep[fe + id] = e;
+}
+
+template <int D>
+__device__ __forceinline__ int find_vertex(const KernelDev &kd, int f, const int16_t (&key)[D])
+{
+    const unsigned mask = (unsigned)kd.cap - 1u;
+    unsigned h = hash_key<D>(key) & mask;
+    const int *slot = kd.slot + (size_t)f * kd.cap;
+    for (;;) {
+        const int r = slot[h];
+        if (r == kEmpty) return -1;
+        int16_t other[D];
+        load_entry_key<D>(kd, f, r, other);
+        bool same = true;
+#pragma unroll
+        for (int i = 0; i < D; ++i) same &= (other[i] == key[i]);
+        if (same) return kd.prefix[(size_t)f * (kd.Epad + 1) + r];
+        h = (h + 1u) & mask;
+    }
+}
+
+// One thread per (axis j, vertex v): the two blur neighbours.  ref: :408-421.
+template <int D>
+__global__ void __launch_bounds__(kBlock) k_neighbors(KernelDev kd)
+{
+    constexpr int D1 = D + 1;
+    const int f = blockIdx.y;
+    const int V = kd.V[f];
+    const int idx = blockIdx.x * kBlock + threadIdx.x;
+    if (idx >= V * D1) return;
+    const int j = idx / V, v = idx - j * V;
+    int16_t key[D], n1[D], n2[D];
+    load_entry_key<D>(kd, f, kd.rep[(size_t)f * kd.Epad + v], key);
+#pragma unroll
+    for (int t = 0; t < D; ++t) {
+        n1[t] = (int16_t)(key[t] - 1);
+        n2[t] = (int16_t)(key[t] + 1);
+    }
+#pragma unroll
+    for (int t = 0; t < D; ++t)          // axis d touches only the implied last coordinate
+        if (t == j) { n1[t] = (int16_t)(key[t] + D); n2[t] = (int16_t)(key[t] - D); }
+    int2 r;
+    r.x = find_vertex<D>(kd, f, n1);
+    r.y = find_vertex<D>(kd, f, n2);
+    reinterpret_cast<int2 *>(kd.nbr)[((size_t)f * D1 + j) * kd.Epad + v] = r;
+}
+
+// ---- CSR of splat contributions: vertex -> (point, weight), points ascending ------------
+// The reference splats sequentially over points (:653-661), so each vertex's sum is taken
+// in ascending point order; an ordered CSR walk reproduces that sum bit for bit.
+
+__global__ void __launch_bounds__(kBlock) k_csr_count(KernelDev kd, const int *__restrict__ n_points)
+{
+    const int f = blockIdx.y;
+    const int e = blockIdx.x * kBlock + threadIdx.x;
+    if (e >= n_points[f] * kd.D1) return;               // real points only
+    atomicAdd(&kd.flag[(size_t)f * (kd.Epad + 1) + kd.offset[(size_t)f * kd.Epad + e]], 1);
+}
+
+__global__ void __launch_bounds__(kBlock) k_csr_fill(KernelDev kd, const int *__restrict__ n_points)
+{
+    const int f = blockIdx.y;
+    const int e = blockIdx.x * kBlock + threadIdx.x;
+    if (e >= n_points[f] * kd.D1) return;
+    const size_t f1 = (size_t)f * (kd.Epad + 1);
+    const int v = kd.offset[(size_t)f * kd.Epad + e];
+    const int k = atomicSub(&kd.flag[f1 + v], 1) - 1;   // counts run down to zero
+    kd.slot_of[(size_t)f * kd.Epad + kd.rowptr[f1 + v] + k] = e;   // slot_of reused: unsorted rows
+}
+
+__global__ void __launch_bounds__(kBlock) k_csr_order(KernelDev kd, const int *__restrict__ n_points)
+{
+    const int f = blockIdx.y;
+    const int p = blockIdx.x * kBlock + threadIdx.x;
+    if (p >= n_points[f] * kd.D1) return;
+    const size_t fe = (size_t)f * kd.Epad, f1 = (size_t)f * (kd.Epad + 1);
+    const int *rows = kd.slot_of + fe;
+    const int e = rows[p];
+    const int v = kd.offset[fe + e];
+    const int s = kd.rowptr[f1 + v], t = kd.rowptr[f1 + v + 1];
+    int rank = 0;
+    for (int q = s; q < t; ++q) rank += (rows[q] < e);
+    kd.csr_pt[fe + s + rank] = e / kd.D1;
+    kd.csr_w[fe + s + rank] = kd.bary[fe + e];
+}
+
+// ---------------------------------------------------------------------------------------
+// splat / blur / slice  (value width L at run time; one thread per (vertex|point, label))
+// ---------------------------------------------------------------------------------------
+
+// val0[v+1][l] = sum over the vertex's contributions, ascending point order.  in == nullptr
+// means the all-ones input of the normalisation pass (pairwise3d.h:23-24).
+__global__ void __launch_bounds__(kBlock) k_splat(KernelDev kd, const float *__restrict__ in,
+                                                  int in_stride, int L)
+{
+    const int f = blockIdx.y;
+    const int V = kd.V[f];
+    const int idx = blockIdx.x * kBlock + threadIdx.x;
+    if (idx >= V * L) return;
+    const int v = idx / L, l = idx - v * L;
+    const size_t fe = (size_t)f * kd.Epad, f1 = (size_t)f * (kd.Epad + 1);
+    const int s = kd.rowptr[f1 + v], t = kd.rowptr[f1 + v + 1];
+    const float *x = in ? in + (size_t)f * in_stride : nullptr;
+    float acc = 0.0f;
+    for (int p = s; p < t; ++p) {
+        const float xv = x ? x[(size_t)kd.csr_pt[fe + p] * L + l] : 1.0f;
+        acc += kd.csr_w[fe + p] * xv;
+    }
+    kd.val0[(size_t)f * kd.vstride + (size_t)(v + 1) * L + l] = acc;
+}
+
+// One Jacobi blur pass along axis j.  ref: :663-679.
+__global__ void __launch_bounds__(kBlock) k_blur(KernelDev kd, const float *__restrict__ src,
+                                                 float *__restrict__ dst, int j, int L)
+{
+    const int f = blockIdx.y;
+    const int V = kd.V[f];
+    const int idx = blockIdx.x * kBlock + threadIdx.x;
+    if (idx >= V * L) return;
+    const int v = idx / L, l = idx - v * L;
+    const size_t fv = (size_t)f * kd.vstride;
+    const int2 nb = reinterpret_cast<const int2 *>(kd.nbr)[((size_t)f * kd.D1 + j) * kd.Epad + v];
+    const float *o = src + fv;
+    const float a = o[(size_t)(nb.x + 1) * L + l];
+    const float c = o[(size_t)(nb.y + 1) * L + l];
+    dst[fv + (size_t)(v + 1) * L + l] = o[(size_t)(v + 1) * L + l] + 0.5f * (a + c);
+}
+
+enum SliceMode { SLICE_NORM = 0, SLICE_APPLY_FIRST = 1, SLICE_APPLY = 2 };
+
+// slice (+ what the caller does with it).  ref: :684-694, pairwise3d.h:25-27,73-78,
+// densecrf3d.h:154-158.
+__global__ void __launch_bounds__(kBlock) k_slice(KernelDev kd, CrfDev c, const float *__restrict__ val,
+                                                  int L, int mode)
+{
+    const int f = blockIdx.y;
+    const int N = c.n_points[f];
+    const int idx = blockIdx.x * kBlock + threadIdx.x;
+    if (idx >= N * L) return;
+    const int i = idx / L, l = idx - i * L;
+    const size_t fe = (size_t)f * kd.Epad;
+    const float *vf = val + (size_t)f * kd.vstride;
+    float t = 0.0f;
+    for (int j = 0; j < kd.D1; ++j) {
+        const int o = kd.offset[fe + (size_t)i * kd.D1 + j];
+        const float wgt = kd.bary[fe + (size_t)i * kd.D1 + j] * kd.alpha;
+        t += wgt * vf[(size_t)(o + 1) * L + l];
+    }
+    if (mode == SLICE_NORM) {
+        kd.norm[(size_t)f * kd.maxN + i] = 1.0f / (t + 1e-20f);
+    } else {
+        const size_t q = ((size_t)f * c.maxN + i) * L + l;
+        const float base = (mode == SLICE_APPLY_FIRST) ? -c.unary[q] : c.next[q];
+        c.next[q] = base + kd.w * kd.norm[(size_t)f * kd.maxN + i] * t;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// CRF-level kernels
+// ---------------------------------------------------------------------------------------
+
+// unary[i][:] from a label and the three energy tables {u, n[L], p[L]}.  densecrf3d.h:116-129.
+__global__ void __launch_bounds__(kBlock) k_unary_from_label(CrfDev c, const int16_t *__restrict__ label,
+                                                             const float *__restrict__ tbl)
+{
+    const int f = blockIdx.y;
+    const int idx = blockIdx.x * kBlock + threadIdx.x;
+    if (idx >= c.n_points[f] * c.L) return;
+    const int i = idx / c.L, m = idx - i * c.L;
+    const int t = label[(size_t)f * c.maxN + i];
+    float u;
+    if (t < 0 || t >= c.L) u = tbl[0];      // -1 = unknown; out-of-range labels (UB in the reference) likewise
+    else u = (m == t) ? tbl[1 + c.L + t] : tbl[1 + t];
+    c.unary[((size_t)f * c.maxN + i) * c.L + m] = u;
+}
+
+// out = softmax_fe(scale * in) (blended with the old out when relax != 1).
+__global__ void __launch_bounds__(kBlock) k_softmax(CrfDev c, const float *__restrict__ in,
+                                                    float *__restrict__ out, float scale, float relax)
+{
+    const int f = blockIdx.y;
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= c.n_points[f]) return;
+    const size_t q = ((size_t)f * c.maxN + i) * c.L;
+    exp_and_normalize_row(in + q, out + q, c.L, scale, relax);
+}
+
+__global__ void __launch_bounds__(kBlock) k_map(CrfDev c)
+{
+    const int f = blockIdx.y;
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= c.n_points[f]) return;
+    const float *p = c.Q + ((size_t)f * c.maxN + i) * c.L;
+    c.map[(size_t)f * c.maxN + i] = (int16_t)argmax_row(p, c.L);
+}
+
+template <int D>
+void build_kernel_d(const KernelDev &kd, const CrfDev &c, hipStream_t s)
+{
+    const int F = c.F, D1 = D + 1;
+    (void)hipMemsetAsync(kd.slot, 0xff, (size_t)F * kd.cap * sizeof(int), s);
+    k_points<D><<<grid_for(kd.maxNpad, F), kBlock, 0, s>>>(kd, c.n_points);
+    k_insert<D><<<grid_for(kd.Epad, F), kBlock, 0, s>>>(kd, c.n_points);
+    k_first_flag<<<grid_for(kd.Epad + 1, F), kBlock, 0, s>>>(kd, c.n_points);
+    k_scan_frame<<<F, 1024, 0, s>>>(kd.flag, kd.prefix, kd.Epad + 1, kd.Epad + 1, kd.V);
+    k_offsets<<<grid_for(kd.Epad, F), kBlock, 0, s>>>(kd, c.n_points);
+    k_neighbors<D><<<grid_for((long)kd.Epad * D1, F), kBlock, 0, s>>>(kd);
+    // CSR
+    (void)hipMemsetAsync(kd.flag, 0, (size_t)F * (kd.Epad + 1) * sizeof(int), s);
+    k_csr_count<<<grid_for(kd.Epad, F), kBlock, 0, s>>>(kd, c.n_points);
+    k_scan_frame<<<F, 1024, 0, s>>>(kd.flag, kd.rowptr, kd.Epad + 1, kd.Epad + 1, nullptr);
+    k_csr_fill<<<grid_for(kd.Epad, F), kBlock, 0, s>>>(kd, c.n_points);
+    k_csr_order<<<grid_for(kd.Epad, F), kBlock, 0, s>>>(kd, c.n_points);
+}
+
+}  // namespace
+
+void launch_build_kernel(const KernelDev &kd, const CrfDev &c, int, hipStream_t s)
+{
+    switch (kd.d) {
+    case 1: build_kernel_d<1>(kd, c, s); break;
+    case 2: build_kernel_d<2>(kd, c, s); break;
+    case 3: build_kernel_d<3>(kd, c, s); break;
+    case 4: build_kernel_d<4>(kd, c, s); break;
+    case 5: build_kernel_d<5>(kd, c, s); break;
+    case 6: build_kernel_d<6>(kd, c, s); break;
+    case 7: build_kernel_d<7>(kd, c, s); break;
+    case 8: build_kernel_d<8>(kd, c, s); break;
+    default: break;
+    }
+}
+
+static void filter_passes(const KernelDev &kd, int F, int maxV, int L, hipStream_t s, const float **result)
+{
+    const float *src = kd.val0;
+    float *dst = kd.val1;
+    for (int j = 0; j < kd.D1; ++j) {
+        k_blur<<<grid_for((long)maxV * L, F), kBlock, 0, s>>>(kd, src, dst, j, L);
+        const float *t = src;
+        src = dst;
+        dst = const_cast<float *>(t);
+    }
+    *result = src;
+}
+
+// norm = 1 / (compute(ones) + 1e-20), value width 1.  pairwise3d.h:22-27.
+void launch_norm(const KernelDev &kd, const CrfDev &c, int maxV, hipStream_t s)
+{
+    k_splat<<<grid_for(maxV, c.F), kBlock, 0, s>>>(kd, nullptr, 0, 1);
+    const float *res;
+    filter_passes(kd, c.F, maxV, 1, s, &res);
+    k_slice<<<grid_for(c.maxN, c.F), kBlock, 0, s>>>(kd, c, res, 1, SLICE_NORM);
+}
+
+void launch_unary_from_label(const CrfDev &c, const int16_t *label, const float *tbl, hipStream_t s)
+{
+    k_unary_from_label<<<grid_for((long)c.maxN * c.L, c.F), kBlock, 0, s>>>(c, label, tbl);
+}
+
+void launch_start(const CrfDev &c, hipStream_t s)   // densecrf_base.h:78-80
+{
+    k_softmax<<<grid_for(c.maxN, c.F), kBlock, 0, s>>>(c, c.unary, c.Q, -1.0f, 1.0f);
+}
+
+void launch_step_stream(const CrfDev &c, const KernelDev *kds, const int *maxV, float relax, hipStream_t s)
+{                                                    // densecrf_base.h:82-91
+    const int L = c.L;
+    if (c.K == 0) {
+        // stepInit only: next = -unary, then softmax.  Done by the softmax with scale -1.
+        k_softmax<<<grid_for(c.maxN, c.F), kBlock, 0, s>>>(c, c.unary, c.Q, -1.0f, relax);
+        return;
+    }
+    for (int k = 0; k < c.K; ++k) {
+        const KernelDev &kd = kds[k];
+        k_splat<<<grid_for((long)maxV[k] * L, c.F), kBlock, 0, s>>>(kd, c.Q, c.maxN * L, L);
+        const float *res;
+        filter_passes(kd, c.F, maxV[k], L, s, &res);
+        k_slice<<<grid_for((long)c.maxN * L, c.F), kBlock, 0, s>>>(kd, c, res, L,
+                                                                 k == 0 ? SLICE_APPLY_FIRST : SLICE_APPLY);
+    }
+    k_softmax<<<grid_for(c.maxN, c.F), kBlock, 0, s>>>(c, c.next, c.Q, 1.0f, relax);
+}
+
+void launch_map(const CrfDev &c, hipStream_t s)
+{
+    k_map<<<grid_for(c.maxN, c.F), kBlock, 0, s>>>(c);
+}
+
+}  // namespace lccrf
