@@ -174,6 +174,7 @@ struct Engine {
         k.Epad = maxNpad * k.D1;
         k.cap = next_pow2(2L * k.Epad);
         k.vstride = (k.Epad + 1) * L;
+        k.vbase = L;
         k.w = w;
         // permutohedral_cpu.h:681 / :249 / :282-285 (quirk Q4): same expressions, same types
         k.alpha = 1.0f / (1 + powf(2, -d));

@@ -26,6 +26,8 @@ struct KernelDev {
     int Epad;             // entries per frame = maxNpad * D1 (also the vertex capacity)
     int cap;              // hash capacity per frame (power of two >= 2*Epad)
     int vstride;          // per-frame stride of val0/val1 = (Epad+1)*L of the owning CRF
+    int vbase;            // = L of the owning CRF: vertex v, label l of a width-W pass sits at
+                          //   vbase + v*W + l; [0,vbase) stays zero and serves as vertex -1
     float w;              // kernel weight (PottsPotential3D::w_)
     float alpha;          // 1/(1+2^-d)                     permutohedral_cpu.h:681
     float inv_dp1;        // 1.0f/(d+1)                     permutohedral_cpu.h:249
@@ -47,7 +49,7 @@ struct KernelDev {
     int *csr_pt;          // [F][Epad]         contributing point, ascending within a row
     float *csr_w;         // [F][Epad]         its barycentric weight
     float *norm;          // [F][maxN]         1/(K*1 + 1e-20)  (PottsPotential3D::norm_)
-    float *val0, *val1;   // [F][(Epad+1)*L]   lattice values, slot 0 = "absent neighbour" = 0
+    float *val0, *val1;   // [F][vstride]      lattice values (see vbase)
 };
 
 // Device view of the CRF state of a batch.

@@ -22,7 +22,11 @@ namespace {
 
 constexpr int kBlock = 256;
 
-inline dim3 grid_for(long work, int F) { return dim3((unsigned)((work + kBlock - 1) / kBlock), (unsigned)F); }
+inline dim3 grid_for(long work, int F)
+{
+    const long nb = (work + kBlock - 1) / kBlock;
+    return dim3((unsigned)(nb > 0 ? nb : 1), (unsigned)F);   // empty frames still get a (no-op) block
+}
 
 // ---------------------------------------------------------------------------------------
 // lattice construction
@@ -273,7 +277,7 @@ __global__ void __launch_bounds__(kBlock) k_splat(KernelDev kd, const float *__r
         const float xv = x ? x[(size_t)kd.csr_pt[fe + p] * L + l] : 1.0f;
         acc += kd.csr_w[fe + p] * xv;
     }
-    kd.val0[(size_t)f * kd.vstride + (size_t)(v + 1) * L + l] = acc;
+    kd.val0[(size_t)f * kd.vstride + kd.vbase + (long)v * L + l] = acc;
 }
 
 // One Jacobi blur pass along axis j.  ref: :663-679.
@@ -287,10 +291,10 @@ __global__ void __launch_bounds__(kBlock) k_blur(KernelDev kd, const float *__re
     const int v = idx / L, l = idx - v * L;
     const size_t fv = (size_t)f * kd.vstride;
     const int2 nb = reinterpret_cast<const int2 *>(kd.nbr)[((size_t)f * kd.D1 + j) * kd.Epad + v];
-    const float *o = src + fv;
-    const float a = o[(size_t)(nb.x + 1) * L + l];
-    const float c = o[(size_t)(nb.y + 1) * L + l];
-    dst[fv + (size_t)(v + 1) * L + l] = o[(size_t)(v + 1) * L + l] + 0.5f * (a + c);
+    const float *o = src + fv + kd.vbase;      // o[v*L+l], v = -1 is the all-zero "absent" vertex
+    const float a = o[(long)nb.x * L + l];
+    const float c = o[(long)nb.y * L + l];
+    dst[fv + kd.vbase + (long)v * L + l] = o[(long)v * L + l] + 0.5f * (a + c);
 }
 
 enum SliceMode { SLICE_NORM = 0, SLICE_APPLY_FIRST = 1, SLICE_APPLY = 2 };
@@ -306,12 +310,12 @@ __global__ void __launch_bounds__(kBlock) k_slice(KernelDev kd, CrfDev c, const 
     if (idx >= N * L) return;
     const int i = idx / L, l = idx - i * L;
     const size_t fe = (size_t)f * kd.Epad;
-    const float *vf = val + (size_t)f * kd.vstride;
+    const float *vf = val + (size_t)f * kd.vstride + kd.vbase;
     float t = 0.0f;
     for (int j = 0; j < kd.D1; ++j) {
         const int o = kd.offset[fe + (size_t)i * kd.D1 + j];
         const float wgt = kd.bary[fe + (size_t)i * kd.D1 + j] * kd.alpha;
-        t += wgt * vf[(size_t)(o + 1) * L + l];
+        t += wgt * vf[(long)o * L + l];
     }
     if (mode == SLICE_NORM) {
         kd.norm[(size_t)f * kd.maxN + i] = 1.0f / (t + 1e-20f);
