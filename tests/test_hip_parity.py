@@ -181,3 +181,42 @@ def test_hip_full_size_properties(wl):
     c = cc.setup(pkg.DenseCRFHIP, pbs[1])
     c.inference(5, True)
     assert cc.same_bits(c.probability(), Q[1]) and np.array_equal(c.map(), M[1])
+
+
+@pytest.mark.parametrize("N,n_iter,relax", [(2000, 5, 1.0), (3000, 5, 1.0), (1000, 10, 1.0), (257, 3, 0.5),
+                                             (1, 2, 1.0), (4096, 2, 1.0)])
+def test_fused_and_streaming_engines_agree_bitwise(wl, N, n_iter, relax):
+    """Engine 2 (one workgroup per frame, LDS) vs engine 1 (streaming kernels)."""
+    F = 6
+    sizes = [N, max(N - 1, 0), N // 2, N, 0, min(N, 7)]
+    pbs = [wl.slam_problem(n, seed=60 + i) for i, n in enumerate(sizes)]
+    feats = [np.zeros((F, N, 2), np.float32) for _ in range(2)]
+    label = np.full((F, N), -1, np.int16)
+    for f, pb in enumerate(pbs):
+        n = pb["N"]
+        label[f, :n] = pb["label"]
+        for k in range(2):
+            feats[k][f, :n] = pb["kernels"][k][0]
+    res = {}
+    for eng in (1, 2):
+        b = pkg.BatchCRF(F, N, 2, [2, 2], [10.0, 30.0])
+        b.set_engine(eng)
+        b.set_inputs_host(sizes, feats, label=label, conf=0.7)
+        b.build()
+        b.inference(n_iter, True, relax=relax)
+        assert b.engine() == eng
+        res[eng] = (b.probability(), b.map())
+        b.close()
+    for f, n in enumerate(sizes):
+        assert cc.same_bits(res[1][0][f, :n], res[2][0][f, :n]), f
+        assert np.array_equal(res[1][1][f, :n], res[2][1][f, :n]), f
+
+
+def test_fused_engine_single_kernel(po, wl):
+    pb = wl.slam_problem(1500, seed=77)
+    pb["kernels"] = pb["kernels"][1:]                      # smoothness kernel only (K = 1)
+    o = cc.setup(po.OracleCRF, pb)
+    o.inference_native(4, True)
+    h = cc.setup(pkg.DenseCRFHIP, pb)
+    h.inference(4, True)
+    assert cc.same_bits(o.probability(), h.probability()) and np.array_equal(o.map(), h.map())
