@@ -20,6 +20,9 @@
 #include "engine.h"
 #include "device_math.h"
 
+#include <cstdio>
+#include <cstdlib>
+
 namespace lccrf {
 
 namespace {
@@ -45,12 +48,20 @@ struct FusedArgs {
     FusedLayout lay;
     int n_iter, with_map;
     float relax;
+    long long *timing;                    // debug: shader-clock stamps of workgroup 0 (LCCRF_FUSED_TIMING=1)
 };
 
-template <int PPT, int K, int D>
+#define STAMP()                                                        \
+    do {                                                               \
+        if (a.timing && blockIdx.x == 0 && tid == 0) a.timing[n_stamp++] = clock64(); \
+    } while (0)
+
+template <int PPT, int K, int D, bool CSR_REG>
 __global__ void __launch_bounds__(kNT) k_fused(CrfDev c, FusedArgs a)
 {
     constexpr int D1 = D + 1;
+    constexpr int EPT = PPT * D1;         // splat entries per lane and kernel: ceil(N*D1 / kNT)
+    int n_stamp = 0;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int f = blockIdx.x;
     const int tid = threadIdx.x;
@@ -111,7 +122,25 @@ __global__ void __launch_bounds__(kNT) k_fused(CrfDev c, FusedArgs a)
             reinterpret_cast<float2 *>(smem + a.lay.val[k][1])[0] = make_float2(0.f, 0.f);
         }
     }
+    // The splat contributions (CSR order) never change between iterations: when they fit,
+    // each lane keeps its EPT entries per kernel in registers and the loop touches no HBM/L2.
+    float cw_r[CSR_REG ? K : 1][CSR_REG ? EPT : 1];
+    int cp_r[CSR_REG ? K : 1][CSR_REG ? EPT : 1];
+    if constexpr (CSR_REG) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const float *cw = a.kd[k].csr_w + (size_t)f * a.kd[k].Epad;
+            const int *cp = a.kd[k].csr_pt + (size_t)f * a.kd[k].Epad;
+#pragma unroll
+            for (int u = 0; u < EPT; ++u) {
+                const int p = tid + u * kNT;
+                cw_r[k][u] = (p < E[k]) ? cw[p] : 0.0f;
+                cp_r[k][u] = (p < E[k]) ? cp[p] : 0;
+            }
+        }
+    }
     __syncthreads();
+    STAMP();
 
     for (int it = 0; it < a.n_iter; ++it) {
         // ---- splat = products (P) + ordered row sums (S) ------------------------------
@@ -119,13 +148,41 @@ __global__ void __launch_bounds__(kNT) k_fused(CrfDev c, FusedArgs a)
             const KernelDev &kd = a.kd[k];
             float *p0 = reinterpret_cast<float *>(smem + a.lay.prod[k]);
             float *p1 = p0 + a.lay.Ecap[k];
-            const float *cw = kd.csr_w + (size_t)f * kd.Epad;
-            const int *cp = kd.csr_pt + (size_t)f * kd.Epad;
-            for (int p = tid; p < E[k]; p += kNT) {
-                const float w = cw[p];
-                const float2 x = Q[cp[p]];
-                p0[p] = w * x.x;
-                p1[p] = w * x.y;
+            if constexpr (CSR_REG) {
+                float2 x[EPT];
+#pragma unroll
+                for (int u = 0; u < EPT; ++u) x[u] = Q[cp_r[k][u]];
+#pragma unroll
+                for (int u = 0; u < EPT; ++u) {
+                    const int p = tid + u * kNT;
+                    if (p < E[k]) {
+                        p0[p] = cw_r[k][u] * x[u].x;
+                        p1[p] = cw_r[k][u] * x[u].y;
+                    }
+                }
+            } else {
+                const float *cw = kd.csr_w + (size_t)f * kd.Epad;
+                const int *cp = kd.csr_pt + (size_t)f * kd.Epad;
+#pragma unroll 1
+                for (int u0 = 0; u0 < EPT; u0 += D1) {                  // D1 entries at a time: bounded registers
+                    float w[D1];
+                    int pt[D1];
+#pragma unroll
+                    for (int u = 0; u < D1; ++u) {
+                        const int p = tid + (u0 + u) * kNT;
+                        w[u] = (p < E[k]) ? cw[p] : 0.0f;
+                        pt[u] = (p < E[k]) ? cp[p] : 0;
+                    }
+#pragma unroll
+                    for (int u = 0; u < D1; ++u) {
+                        const int p = tid + (u0 + u) * kNT;
+                        const float2 x = Q[pt[u]];
+                        if (p < E[k]) {
+                            p0[p] = w[u] * x.x;
+                            p1[p] = w[u] * x.y;
+                        }
+                    }
+                }
             }
         };
         auto phase_S = [&](int k) {
@@ -137,7 +194,14 @@ __global__ void __launch_bounds__(kNT) k_fused(CrfDev c, FusedArgs a)
                 const float *pl = p0 + l * a.lay.Ecap[k];
                 const int s = row[v], t = row[v + 1];
                 float acc = 0.0f;
-                for (int p = s; p < t; ++p) acc += pl[p];               // strictly left to right
+                int p = s;
+                for (; p + 8 <= t; p += 8) {                            // 8 loads in flight, then
+                    const float x0 = pl[p], x1 = pl[p + 1], x2 = pl[p + 2], x3 = pl[p + 3];
+                    const float x4 = pl[p + 4], x5 = pl[p + 5], x6 = pl[p + 6], x7 = pl[p + 7];
+                    acc += x0; acc += x1; acc += x2; acc += x3;         // strictly left to right
+                    acc += x4; acc += x5; acc += x6; acc += x7;
+                }
+                for (; p < t; ++p) acc += pl[p];
                 val[(v + 1) * 2 + l] = acc;
             }
         };
@@ -145,9 +209,11 @@ __global__ void __launch_bounds__(kNT) k_fused(CrfDev c, FusedArgs a)
 #pragma unroll
             for (int k = 0; k < K; ++k) phase_P(k);
             __syncthreads();
+            STAMP();
 #pragma unroll
             for (int k = 0; k < K; ++k) phase_S(k);
             __syncthreads();
+            STAMP();
         } else {
 #pragma unroll
             for (int k = 0; k < K; ++k) {
@@ -177,6 +243,7 @@ __global__ void __launch_bounds__(kNT) k_fused(CrfDev c, FusedArgs a)
             }
             __syncthreads();
         }
+        STAMP();
 
         // ---- slice + apply + softmax per point ----------------------------------------
 #pragma unroll
@@ -204,6 +271,7 @@ __global__ void __launch_bounds__(kNT) k_fused(CrfDev c, FusedArgs a)
             }
         }
         __syncthreads();
+        STAMP();
     }
 
     // ---- results ------------------------------------------------------------------------
@@ -215,6 +283,8 @@ __global__ void __launch_bounds__(kNT) k_fused(CrfDev c, FusedArgs a)
             if (a.with_map) c.map[(size_t)f * c.maxN + i] = (q[s].x < q[s].y) ? 1 : 0;   // densecrf3d.h:145
         }
     }
+    STAMP();
+    if (a.timing && blockIdx.x == 0 && tid == 0) a.timing[63] = n_stamp;
 }
 
 bool make_layout(const CrfDev &c, const KernelDev *kds, const int *maxV, FusedLayout *lay)
@@ -259,7 +329,7 @@ bool make_layout(const CrfDev &c, const KernelDev *kds, const int *maxV, FusedLa
 template <int PPT, int K>
 void launch_fused(const CrfDev &c, const FusedArgs &a, hipStream_t s)
 {
-    auto fn = k_fused<PPT, K, 2>;
+    auto fn = k_fused<PPT, K, 2, (PPT <= 2)>;
     // per (function, device); cheap enough to repeat and safe with several devices in one process
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)kLdsLimit);
@@ -285,6 +355,10 @@ void launch_inference_fused(const CrfDev &c, const KernelDev *kds, const int *ma
     a.n_iter = n_iter;
     a.with_map = with_map;
     a.relax = relax;
+    static long long *timing_buf = nullptr;
+    static const bool want_timing = getenv("LCCRF_FUSED_TIMING") != nullptr;
+    if (want_timing && !timing_buf) (void)hipMalloc(&timing_buf, 64 * sizeof(long long));
+    a.timing = want_timing ? timing_buf : nullptr;
     const int ppt = (c.maxN + kNT - 1) / kNT;
 #define FUSED_CASE(P)                                            \
     case P:                                                      \
@@ -299,6 +373,14 @@ void launch_inference_fused(const CrfDev &c, const KernelDev *kds, const int *ma
     default: break;
     }
 #undef FUSED_CASE
+    if (a.timing) {                       // debug only: synchronous read-back of workgroup 0's phase stamps
+        long long h[64];
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpy(h, a.timing, sizeof(h), hipMemcpyDeviceToHost);
+        fprintf(stderr, "[lccrf fused timing] %lld stamps, deltas (shader clocks):", h[63]);
+        for (int i = 1; i < h[63] && i < 63; ++i) fprintf(stderr, " %lld", h[i] - h[i - 1]);
+        fprintf(stderr, "\n");
+    }
 }
 
 }  // namespace lccrf

@@ -184,7 +184,7 @@ def test_hip_full_size_properties(wl):
 
 
 @pytest.mark.parametrize("N,n_iter,relax", [(2000, 5, 1.0), (3000, 5, 1.0), (1000, 10, 1.0), (257, 3, 0.5),
-                                             (1, 2, 1.0), (4096, 2, 1.0)])
+                                             (1, 2, 1.0), (3400, 2, 1.0)])
 def test_fused_and_streaming_engines_agree_bitwise(wl, N, n_iter, relax):
     """Engine 2 (one workgroup per frame, LDS) vs engine 1 (streaming kernels)."""
     F = 6
@@ -220,3 +220,19 @@ def test_fused_engine_single_kernel(po, wl):
     h = cc.setup(pkg.DenseCRFHIP, pb)
     h.inference(4, True)
     assert cc.same_bits(o.probability(), h.probability()) and np.array_equal(o.map(), h.map())
+
+
+def test_oversize_frames_fall_back_to_streaming_engine(wl):
+    """4096 keypoints do not fit one workgroup's 160 KiB of LDS: automatic engine choice
+    must pick the streaming engine, and forcing the fused one must fail loudly."""
+    N = 4096
+    pb = wl.slam_problem(N, seed=3)
+    feats = [pb["kernels"][k][0][None] for k in range(2)]
+    b = pkg.BatchCRF(1, N, 2, [2, 2], [10.0, 30.0])
+    b.set_inputs_host([N], feats, label=pb["label"][None], conf=0.7)
+    b.build()
+    b.inference(2, True)
+    assert b.engine() == 1
+    b.set_engine(2)
+    with pytest.raises(pkg.LccrfError):
+        b.inference(2, True)
