@@ -130,19 +130,52 @@ __device__ __forceinline__ float very_fast_exp(float x)     // densecrf3d.h:51-5
              - x * (0.0083013598f - x * (0.0013298820f - x * (0.0001413161f)))))));
 }
 
+// The reference compares the float against DOUBLE products (0.69*2*2*2 etc., quirk Q5).
+// None of the three is representable in fp32 and each rounds DOWN when narrowed, so no fp32
+// value lies between (float)T and T:  (double)x > T  <=>  x > (float)T.  Checked at compile time.
+constexpr double kFe8d = 0.69 * 2 * 2 * 2, kFe4d = 0.69 * 2 * 2, kFe1d = 0.69;
+constexpr float kFe8 = (float)kFe8d, kFe4 = (float)kFe4d, kFe1 = (float)kFe1d;
+static_assert((double)kFe8 < kFe8d && (double)kFe4 < kFe4d && (double)kFe1 < kFe1d,
+              "fast_exp thresholds must narrow downwards for the fp32 compare to be equivalent");
+
 __device__ __forceinline__ float fast_exp(float x)          // densecrf3d.h:55-67
 {
+    // x == 0 (the row maximum in a softmax): the reference takes its 1/x branch with
+    // very_fast_exp(0) = 1 and returns 1/1.  Same value, without the division.
+    if (x == 0) return 1.0f;
     bool less_zero = true;
     if (x < 0) { less_zero = false; x = -x; }
     if (x > 20) return 0;
     int mult = 0;
-    // the thresholds are double products compared against the promoted float (quirk Q5)
-    while ((double)x > 0.69 * 2 * 2 * 2) { mult += 3; x /= 8.0f; }
-    while ((double)x > 0.69 * 2 * 2)     { mult += 2; x /= 4.0f; }
-    while ((double)x > 0.69)             { mult += 1; x /= 2.0f; }
+    while (x > kFe8) { mult += 3; x /= 8.0f; }
+    while (x > kFe4) { mult += 2; x /= 4.0f; }
+    while (x > kFe1) { mult += 1; x /= 2.0f; }
     x = very_fast_exp(x);
     while (mult) { mult--; x = x * x; }
     return less_zero ? 1 / x : x;
+}
+
+// fast_exp for arguments <= 0 (all a softmax ever passes: value - row maximum), with the
+// data-dependent loops of densecrf3d.h:60-64 turned into selects so a wavefront does not
+// serialise over its lanes' different trip counts.  Same operations, same order, same
+// results -- including x == 0 (-> 1) and x < -20 (-> 0):
+//   * a = -x <= 20 enters the "/8" loop at most once (20/8 < 5.52), the "/4" loop at most
+//     once, the "/2" loop at most twice; dividing by 8, 4, 2 is exact, as is multiplying
+//     by 0.125, 0.25, 0.5;
+//   * the reference then squares `mult` (<= 5) times.
+__device__ __forceinline__ float fast_exp_nonpos(float x)
+{
+    float a = -x;
+    const bool cut = a > 20;
+    int mult = 0;
+    { const bool c = a > kFe8; a = c ? a * 0.125f : a; mult += c ? 3 : 0; }
+    { const bool c = a > kFe4; a = c ? a * 0.25f : a;  mult += c ? 2 : 0; }
+    { const bool c = a > kFe1; a = c ? a * 0.5f : a;   mult += c ? 1 : 0; }
+    { const bool c = a > kFe1; a = c ? a * 0.5f : a;   mult += c ? 1 : 0; }
+    float r = very_fast_exp(a);
+#pragma unroll
+    for (int i = 0; i < 5; ++i) r = (i < mult) ? r * r : r;
+    return cut ? 0.0f : r;
 }
 
 // One row of expAndNormalize (densecrf3d.h:70-98); `out` may alias `in`.
@@ -177,7 +210,7 @@ __device__ __forceinline__ void exp_and_normalize_reg(const float (&in)[L], floa
     float v[L];
     float tt = 0;
 #pragma unroll
-    for (int j = 0; j < L; ++j) { v[j] = fast_exp(scale * in[j] - mx); tt += v[j]; }
+    for (int j = 0; j < L; ++j) { v[j] = fast_exp_nonpos(scale * in[j] - mx); tt += v[j]; }
 #pragma unroll
     for (int j = 0; j < L; ++j) {
         const float p = v[j] / tt;
