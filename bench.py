@@ -27,6 +27,23 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
+
+def pmc_traffic(name, engine, F):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
+    (profiles/<tag>/pmc_summary.csv: FETCH_SIZE doubled per the gfx950 correction, + WRITE_SIZE).
+    Counters cannot be collected inside this process, so this is the figure of the committed
+    profile of the SAME command line; None when no matching profile exists."""
+    import csv
+    tag = {("c2", 2, 1024): "r1_fused_c2"}.get((name, engine, F))
+    fn = os.path.join(ROOT, "profiles", tag or "", "pmc_summary.csv")
+    if not tag or not os.path.exists(fn):
+        return None
+    tot = 0.0
+    for r in csv.DictReader(open(fn)):
+        if "k_fused" in r["kernel"]:
+            tot += float(r["bytes_corrected"])
+    return tot or None
+
 WORKLOADS = {
     # name: (N, n_iter, obs_cap, description)
     "c1": (1000, 5, None, "C1: 1000 keypoints, 5 iters, two 2-D kernels (TUM3.yaml), L=2"),
@@ -151,9 +168,9 @@ def main():
     engine = b.engine()
     Vs = [b.lattice_sizes(k).astype(np.float64).mean() for k in range(len(dims))]
 
+    sh = importlib.import_module("lc-crf-slam_amd.sharding")
     d_map_ptr, _ = b.device_buffers()
     map_view = torch.as_tensor(CudaView(d_map_ptr, (F, N), "<i2"), device=dev)
-    gathered = torch.empty((world, F, N), dtype=torch.int16, device=dev) if world > 1 else None
 
     def barrier():
         if world > 1:
@@ -170,8 +187,8 @@ def main():
     for _ in range(args.steps):
         b.inference(n_iter, True)
     b.synchronize()
-    if world > 1:                                   # the one collective: final label gather
-        dist.all_gather_into_tensor(gathered, map_view)
+    if world > 1:                                   # the one collective: final label gather (RCCL)
+        gathered, _ = sh.gather_labels(map_view, d_np)
     barrier()
     t1 = time.perf_counter()
     dt = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
@@ -233,7 +250,7 @@ def main():
                        "engine": {1: "streaming", 2: "fused"}.get(engine, str(engine)),
                        "sharding": "frames over ranks, no data-path collective; final RCCL label all_gather"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(name, engine, F),
                          "kernel": "inference (start + %d mean-field iterations + map), HIP events" % n_iter,
                          "algorithmic_bytes_per_launch": bytes_launch, "launch_ms": inf_ms,
                          "note": "SLAM-size working sets are LDS/L2-resident: latency-bound, not HBM-bound"

@@ -1,0 +1,60 @@
+"""Frames-in-flight across the GPUs of a node.
+
+One frame's CRF is globally coupled through its lattices and fits one GPU (one workgroup
+at SLAM sizes), so a frame is never split.  The unit of distribution is the FRAME:
+
+    frame f  ->  rank  f mod world_size                       (round robin)
+
+No inter-GPU traffic happens during lattice build or inference.  The only collective is the
+final label gather: every rank contributes its [frames_per_rank, max_points] int16 label
+block (padded; per-frame point counts travel alongside) in ONE all_gather.  RCCL has no
+16-bit integer type, so the block is viewed as bytes.  The payload is KB-scale per frame --
+latency-bound, so no ring/tree tuning and no bucketing: one call.
+
+torch.distributed is plumbing here (backend "nccl" is RCCL on ROCm; "gloo" in CPU tests).
+"""
+import torch
+import torch.distributed as dist
+
+
+def frames_of_rank(n_frames, rank, world):
+    """Global frame ids owned by `rank`."""
+    return list(range(rank, n_frames, world))
+
+
+def frames_per_rank(n_frames, world):
+    """Slots every rank reserves (the last ranks may leave one unused)."""
+    return (n_frames + world - 1) // world
+
+
+def gather_labels(local_labels, local_counts, group=None):
+    """All-gather the per-rank label blocks.
+
+    local_labels : int16 [S, max_points]  (S = frames_per_rank slots, unused slots arbitrary)
+    local_counts : int32 [S]              points per local frame, -1 for an unused slot
+    returns (labels [world, S, max_points] int16, counts [world, S] int32), on every rank.
+    """
+    world = dist.get_world_size(group)
+    S, P = local_labels.shape
+    lab_bytes = local_labels.contiguous().view(torch.uint8)              # RCCL: no int16
+    # outputs are the rank blocks concatenated along dim 0 (the layout both RCCL and gloo accept)
+    out_bytes = torch.empty((world * S, lab_bytes.shape[1]), dtype=torch.uint8, device=local_labels.device)
+    counts = torch.empty((world * S,), dtype=torch.int32, device=local_counts.device)
+    if world == 1:
+        out_bytes.copy_(lab_bytes)
+        counts.copy_(local_counts)
+    else:
+        dist.all_gather_into_tensor(out_bytes, lab_bytes, group=group)
+        dist.all_gather_into_tensor(counts, local_counts.contiguous(), group=group)
+    return out_bytes.view(torch.int16).view(world, S, P), counts.view(world, S)
+
+
+def unshard(labels, counts, n_frames):
+    """Back to global frame order: list of 1-D int16 tensors (trimmed to each frame's size)."""
+    world = labels.shape[0]
+    out = []
+    for f in range(n_frames):
+        r, s = f % world, f // world
+        n = int(counts[r, s])
+        out.append(labels[r, s, :n].clone())
+    return out
