@@ -96,6 +96,7 @@ struct KernelState {
     float *feat_own = nullptr;    // device copy of host-provided features
     float *feat_stage = nullptr;  // pinned staging for the object API
     int maxV = 0;                 // max over frames of V once known, else Epad
+    int maxRow = 0;               // max over frames of the longest CSR row
 };
 
 // One CRF problem set: F frames x maxN points x L labels, K kernels.
@@ -111,9 +112,10 @@ struct Engine {
     float *tbl = nullptr;              // device: {u, n[L], p[L]}
     float *tbl_host = nullptr;         // pinned
     int *V_host = nullptr;             // pinned [K][Fcap]
+    int *row_host = nullptr;           // pinned [K][Fcap]
     std::vector<KernelState> kernels;
     std::vector<KernelDev> kdevs;      // contiguous copy handed to the launchers
-    std::vector<int> maxV;
+    std::vector<int> maxV, maxRow;
     bool unary_set = false, built = false, sizes_known = false, started = false;
     int engine_pref = 0, engine_used = 1;
     size_t fused_lds = 0;
@@ -140,6 +142,7 @@ struct Engine {
         if ((rc = mem.alloc(&tbl, 2 * L + 1))) return rc;
         if ((rc = mem.alloc_pinned(&tbl_host, 2 * L + 1))) return rc;
         if ((rc = mem.alloc_pinned(&V_host, (size_t)LCCRF_MAX_KERNELS * Fcap))) return rc;
+        if ((rc = mem.alloc_pinned(&row_host, (size_t)LCCRF_MAX_KERNELS * Fcap))) return rc;
         crf.F = F;
         crf.maxN = maxN;
         crf.L = L;
@@ -193,6 +196,7 @@ struct Engine {
         if ((rc = mem.alloc(&k.prefix, Fz * (E + 1)))) return rc;
         if ((rc = mem.alloc(&k.rep, Fz * E))) return rc;
         if ((rc = mem.alloc(&k.V, Fz))) return rc;
+        if ((rc = mem.alloc(&k.rowmax, Fz))) return rc;
         if ((rc = mem.alloc(&k.nbr, Fz * k.D1 * E * 2))) return rc;
         if ((rc = mem.alloc(&k.rowptr, Fz * (E + 1)))) return rc;
         if ((rc = mem.alloc(&k.csr_pt, Fz * E))) return rc;
@@ -216,9 +220,11 @@ struct Engine {
     {
         kdevs.resize(kernels.size());
         maxV.resize(kernels.size());
+        maxRow.resize(kernels.size());
         for (size_t i = 0; i < kernels.size(); ++i) {
             kdevs[i] = kernels[i].dev;
             maxV[i] = kernels[i].maxV;
+            maxRow[i] = kernels[i].maxRow;
         }
         crf.K = (int)kernels.size();
         crf.F = F;
@@ -233,6 +239,7 @@ struct Engine {
         launch_build_kernel(kdevs[k], crf, ks.maxV, stream);
         launch_norm(kdevs[k], crf, ks.maxV, stream);
         HIP_TRY(hipMemcpyAsync(V_host + (size_t)k * Fcap, ks.dev.V, sizeof(int) * F, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipMemcpyAsync(row_host + (size_t)k * Fcap, ks.dev.rowmax, sizeof(int) * F, hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipGetLastError());
         sizes_known = false;
         return LCCRF_OK;
@@ -244,14 +251,18 @@ struct Engine {
         if (sizes_known) return LCCRF_OK;
         HIP_TRY(hipStreamSynchronize(stream));
         for (size_t k = 0; k < kernels.size(); ++k) {
-            int m = 0;
-            for (int f = 0; f < F; ++f) m = std::max(m, V_host[k * Fcap + f]);
+            int m = 0, r = 0;
+            for (int f = 0; f < F; ++f) {
+                m = std::max(m, V_host[k * Fcap + f]);
+                r = std::max(r, row_host[k * Fcap + f]);
+            }
             kernels[k].maxV = m;
+            kernels[k].maxRow = r;
         }
         sync_views();
         sizes_known = true;
         engine_used = 1;
-        if (engine_pref != 1 && fused_supported(crf, kdevs.data(), maxV.data(), &fused_lds)) engine_used = 2;
+        if (engine_pref != 1 && fused_supported(crf, kdevs.data(), maxV.data(), maxRow.data(), &fused_lds)) engine_used = 2;
         if (engine_pref == 2 && engine_used != 2)
             return fail(LCCRF_E_CAPACITY, "fused engine requested but the problem does not fit one workgroup's LDS");
         return LCCRF_OK;
@@ -294,7 +305,7 @@ struct Engine {
         int rc = learn_sizes();
         if (rc) return rc;
         if (engine_used == 2) {
-            launch_inference_fused(crf, kdevs.data(), maxV.data(), n_iter, with_map, relax, fused_lds, stream);
+            launch_inference_fused(crf, kdevs.data(), maxV.data(), maxRow.data(), n_iter, with_map, relax, stream);
             started = true;
         } else {
             if ((rc = start())) return rc;

@@ -44,6 +44,7 @@ struct KernelDev {
     int *prefix;          // [F][Epad+1]       exclusive scan of flag == dense vertex id of a first entry
     int *rep;             // [F][Epad]         vertex id -> representative (first) entry
     int *V;               // [F]               number of vertices (reference M_)
+    int *rowmax;          // [F]               longest CSR row (splat contributions of one vertex)
     int *nbr;             // [F][D1][Epad][2]  blur neighbours {n1,n2} per (axis, vertex), -1 absent
     int *rowptr;          // [F][Epad+1]       CSR: vertex -> range of splat contributions
     int *csr_pt;          // [F][Epad]         contributing point, ascending within a row
@@ -72,8 +73,9 @@ void launch_step_stream(const CrfDev &c, const KernelDev *kds, const int *maxV, 
 void launch_map(const CrfDev &c, hipStream_t s);
 
 // ---- fused engine (SLAM sizes; one workgroup per frame, lattice values in LDS) --------
-bool fused_supported(const CrfDev &c, const KernelDev *kds, const int *maxV, size_t *lds_bytes);
-void launch_inference_fused(const CrfDev &c, const KernelDev *kds, const int *maxV, int n_iter,
-                            int with_map, float relax, size_t lds_bytes, hipStream_t s);
+bool fused_supported(const CrfDev &c, const KernelDev *kds, const int *maxV, const int *maxRow,
+                     size_t *lds_bytes);
+void launch_inference_fused(const CrfDev &c, const KernelDev *kds, const int *maxV, const int *maxRow,
+                            int n_iter, int with_map, float relax, hipStream_t s);
 
 }  // namespace lccrf

@@ -228,6 +228,16 @@ __global__ void __launch_bounds__(kBlock) k_csr_count(KernelDev kd, const int *_
     atomicAdd(&kd.flag[(size_t)f * (kd.Epad + 1) + kd.offset[(size_t)f * kd.Epad + e]], 1);
 }
 
+// rowmax[f] = longest CSR row of the frame (lets the fused engine pick its splat strategy).
+__global__ void __launch_bounds__(kBlock) k_row_max(KernelDev kd)
+{
+    const int f = blockIdx.y;
+    const int v = blockIdx.x * kBlock + threadIdx.x;
+    if (v >= kd.V[f]) return;
+    const int *rp = kd.rowptr + (size_t)f * (kd.Epad + 1);
+    atomicMax(&kd.rowmax[f], rp[v + 1] - rp[v]);
+}
+
 __global__ void __launch_bounds__(kBlock) k_csr_fill(KernelDev kd, const int *__restrict__ n_points)
 {
     const int f = blockIdx.y;
@@ -382,6 +392,8 @@ void build_kernel_d(const KernelDev &kd, const CrfDev &c, hipStream_t s)
     k_scan_frame<<<F, 1024, 0, s>>>(kd.flag, kd.rowptr, kd.Epad + 1, kd.Epad + 1, nullptr);
     k_csr_fill<<<grid_for(kd.Epad, F), kBlock, 0, s>>>(kd, c.n_points);
     k_csr_order<<<grid_for(kd.Epad, F), kBlock, 0, s>>>(kd, c.n_points);
+    (void)hipMemsetAsync(kd.rowmax, 0, (size_t)F * sizeof(int), s);
+    k_row_max<<<grid_for(kd.Epad, F), kBlock, 0, s>>>(kd);
 }
 
 }  // namespace
