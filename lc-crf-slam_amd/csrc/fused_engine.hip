@@ -1,31 +1,22 @@
-// fused_engine.hip -- SLAM-size inference as ONE kernel launch: one 512-lane workgroup per
+// fused_engine.hip -- SLAM-size inference as ONE kernel launch: one 1024-lane workgroup per
 // frame runs startInference, every mean-field iteration and buildMap without leaving the CU.
 //
 // Why: at SLAM sizes (N ~ 2000 keypoints, V ~ 1.2k lattice vertices) one iteration moves
 // < 0.5 MB; a launch-per-phase design is bound by launch gaps, not by memory (SURVEY.md
-// section 7).  Here the mean-field state lives on chip and the loop touches no HBM:
-//     LDS        Q[N][2], both ping-pong lattice value arrays of every kernel, and the
-//                per-entry splat products w*Q
-//     registers  for every point a lane owns: the LDS addresses of its d+1 vertices, the
-//                weights bary*alpha, w*norm, its unary; for every splat entry it owns: the
-//                weight and the LDS address of the contributing point's Q; for every lattice
-//                vertex it owns: the LDS addresses of its blur neighbours and its CSR row.
-//                All of it is loaded once per launch (8 wavefronts -> 256 VGPRs per lane).
-//
-// What bounds it: measured with shader-clock stamps, the loop is bound by VALU issue inside
-// the CU (not HBM, not LDS bandwidth) plus one serial tail -- see below.  Hence: addresses are
-// precomputed, two labels ride in one float2, softmax needs one exp (L = 2).
+// section 7).  Here the mean-field state lives on chip:
+//     LDS        Q[N][2], both ping-pong lattice value arrays of every kernel, the blur
+//                neighbour table, the CSR row pointers, and the per-entry splat products
+//     registers  everything a point needs for slice/apply/softmax (its d+1 vertex ids,
+//                weights bary*alpha, w*norm, its unary) -- loaded once per launch
+//     L2         the CSR (csr_w, csr_pt) streamed once per iteration, fully coalesced
 //
 // Bit-exactness: the reference splats sequentially over points (permutohedral_cpu.h:653-661),
-// so a vertex's value is a left-to-right fp32 sum in ascending point order.  Phase P forms all
-// products w*Q in parallel (exact, order-free); phase S adds each vertex's products strictly
-// left to right.  The appearance kernel funnels hundreds of keypoints into one vertex (rows of
-// ~450 products), so its rows get a dedicated lane per (vertex, label) that streams the row
-// through a 2 x 32-deep register prefetch ring: the chain then runs at the fp32 add latency
-// instead of the LDS latency.  Nothing is re-associated, nothing is fused (-ffp-contract=off).
+// so a vertex's value is a left-to-right fp32 sum in ascending point order.  Phase P forms
+// all products w*Q in parallel (exact, order-free); phase S then adds each vertex's products
+// strictly left to right.  Nothing is re-associated, nothing is fused (-ffp-contract=off).
 //
-// Specialised for L = 2 labels (the SLAM configuration, src/Tracking.cc:1919) and 2-D kernels
-// (pairwise3d.h:37-71); anything else runs on the streaming engine with identical results.
+// Specialised for L = 2 labels (the SLAM configuration, src/Tracking.cc:1919) and kernels of
+// equal dimension D; anything else runs on the streaming engine with identical results.
 #include "engine.h"
 #include "device_math.h"
 
@@ -36,21 +27,18 @@ namespace lccrf {
 
 namespace {
 
-constexpr int kNT = 512;                  // lanes per workgroup: 8 wavefronts, 2 per SIMD, 256 VGPRs each
-constexpr int kD1 = 3;                    // d + 1 for the 2-D kernels this engine handles
-constexpr int kVPT = 4;                   // lattice vertices (all kernels together) per lane
-constexpr int kMaxPPT = 7;                // points per lane -> N <= 3584
+constexpr int kNT = 1024;                 // lanes per workgroup (16 wavefronts)
 constexpr int kMaxFusedK = 2;
-constexpr int kLongRow = 24;              // a kernel whose longest splat row exceeds this uses chain lanes
 constexpr size_t kLdsLimit = 160 * 1024;  // MI355X: 160 KiB LDS per CU, one workgroup may own it all
 
 struct FusedLayout {                      // byte offsets into dynamic LDS
-    int q;                                // float2 [maxN]
-    int prod[kMaxFusedK];                 // splat products: float2 [Ecap] (short rows) or float [2][Ecap] (long)
-    int val[kMaxFusedK][2];               // float2 [V_k+1], slot 0 = absent neighbour = 0
-    int Ecap;                             // entries per product array (multiple of 4, padded for over-reads)
-    int long_mode[kMaxFusedK];            // 1: label-major products + chain lanes
-    int chain_base[kMaxFusedK];           // first chain lane of a long kernel
+    int q;                                // float2 [Nq]
+    int prod[kMaxFusedK];                 // float  [2][E_k]   (label-major), may alias when !prod_all
+    int val[kMaxFusedK][2];               // float2 [V_k+1]    slot 0 = absent neighbour = 0
+    int nbr[kMaxFusedK];                  // u32    [D1][V_k]  (n1+1) | (n2+1)<<16
+    int row[kMaxFusedK];                  // u16    [V_k+1]
+    int Ecap[kMaxFusedK];                 // capacity of prod in entries
+    int Vcap[kMaxFusedK];
     int prod_all;                         // 1: every kernel has its own product buffer
     int total;
 };
@@ -63,328 +51,167 @@ struct FusedArgs {
     long long *timing;                    // debug: shader-clock stamps of workgroup 0 (LCCRF_FUSED_TIMING=1)
 };
 
-#define STAMP()                                                                                        \
-    do {                                                                                               \
-        if (a.timing && blockIdx.x == 0 && tid == 0 && n_stamp < 62) a.timing[n_stamp++] = clock64();  \
+#define STAMP()                                                        \
+    do {                                                               \
+        if (a.timing && blockIdx.x == 0 && tid == 0) a.timing[n_stamp++] = clock64(); \
     } while (0)
 
-// expAndNormalize for two labels (densecrf3d.h:70-98).  One of the two fast_exp arguments is
-// exactly 0 (value minus row maximum) and fast_exp(0) == 1, so a single exp is evaluated; the
-// sum and the two IEEE divisions are the reference's.
-__device__ __forceinline__ float2 softmax2(float a, float b, float2 old, float relax)
-{
-    const bool lt = a < b;                            // mx = b iff a < b (densecrf3d.h:76-79)
-    const float e = fast_exp_nonpos(lt ? a - b : b - a);
-    const float v0 = lt ? e : 1.0f, v1 = lt ? 1.0f : e;
-    const float tt = v0 + v1;
-    const float p0 = v0 / tt, p1 = v1 / tt;
-    if (relax == 1) return make_float2(p0, p1);
-    return make_float2((1 - relax) * old.x + relax * p0, (1 - relax) * old.y + relax * p1);
-}
-
-template <int PPT, int K, bool CSR_REG>
+template <int PPT, int K, int D, bool CSR_REG>
 __global__ void __launch_bounds__(kNT) k_fused(CrfDev c, FusedArgs a)
 {
-    constexpr int EPT = PPT * kD1;        // splat entries per lane and kernel = ceil(N*D1 / kNT)
+    constexpr int D1 = D + 1;
+    constexpr int EPT = PPT * D1;         // splat entries per lane and kernel: ceil(N*D1 / kNT)
+    int n_stamp = 0;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int f = blockIdx.x;
     const int tid = threadIdx.x;
     const int N = c.n_points[f];
-    const int E = N * kD1;
-    int n_stamp = 0;
-    STAMP();
 
-    // Q and the lattice value arrays sit in the first 64 KiB of LDS (make_layout), so their byte
-    // addresses fit 16 bits and are kept two per register.
-    auto lo16 = [](unsigned x) { return (int)(x & 0xffffu); };
-    auto hi16 = [](unsigned x) { return (int)(x >> 16); };
-    auto ld1 = [&](int addr) { return *reinterpret_cast<const float *>(smem + addr); };
-    auto ld2 = [&](int addr) { return *reinterpret_cast<const float2 *>(smem + addr); };
-    auto ld4 = [&](int addr) { return *reinterpret_cast<const float4 *>(smem + addr); };
-    auto st1 = [&](int addr, float v) { *reinterpret_cast<float *>(smem + addr) = v; };
-    auto st2 = [&](int addr, float2 v) { *reinterpret_cast<float2 *>(smem + addr) = v; };
+    float2 *Q = reinterpret_cast<float2 *>(smem + a.lay.q);
 
-    // ---- points a lane owns: i = tid + s*kNT ----------------------------------------------
+    // ---- per-thread point state (registers) ------------------------------------------
     float2 un[PPT], q[PPT];
-    unsigned gaddr[PPT][K][2];            // LDS addresses of val_final[k][offset+1]: {j0 | j1<<16, j2}
-    float wgt[PPT][K][kD1];               // bary * alpha               permutohedral_cpu.h:689
-    float wn[PPT][K];                     // w_ * norm_[i]              pairwise3d.h:77
+    int off[PPT][K][D1];
+    float wgt[PPT][K][D1];
+    float wn[PPT][K];
 #pragma unroll
     for (int s = 0; s < PPT; ++s) {
         const int i = tid + s * kNT;
-        un[s] = q[s] = make_float2(0.f, 0.f);
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-            wn[s][k] = 0.f;
-#pragma unroll
-            for (int j = 0; j < kD1; ++j) wgt[s][k][j] = 0.f;
-            gaddr[s][k][0] = gaddr[s][k][1] = 0;
-        }
+        un[s] = make_float2(0.f, 0.f);
+        q[s] = make_float2(0.f, 0.f);
         if (i < N) {
             un[s] = reinterpret_cast<const float2 *>(c.unary)[(size_t)f * c.maxN + i];
 #pragma unroll
             for (int k = 0; k < K; ++k) {
                 const KernelDev &kd = a.kd[k];
-                const size_t e0 = (size_t)f * kd.Epad + (size_t)i * kD1;
+                const size_t e0 = (size_t)f * kd.Epad + (size_t)i * D1;
 #pragma unroll
-                for (int j = 0; j < kD1; ++j) {
-                    const unsigned ga = (unsigned)(a.lay.val[k][kD1 & 1] + (kd.offset[e0 + j] + 1) * 8);
-                    if (j == 0) gaddr[s][k][0] = ga;
-                    if (j == 1) gaddr[s][k][0] |= ga << 16;
-                    if (j == 2) gaddr[s][k][1] = ga;
-                    wgt[s][k][j] = kd.bary[e0 + j] * kd.alpha;
+                for (int j = 0; j < D1; ++j) {
+                    off[s][k][j] = kd.offset[e0 + j] + 1;
+                    wgt[s][k][j] = kd.bary[e0 + j] * kd.alpha;            // permutohedral_cpu.h:689
                 }
-                wn[s][k] = kd.w * kd.norm[(size_t)f * kd.maxN + i];
+                wn[s][k] = kd.w * kd.norm[(size_t)f * kd.maxN + i];      // pairwise3d.h:77 (w_*norm_[i])
             }
-            q[s] = softmax2(-1.0f * un[s].x, -1.0f * un[s].y, q[s], 1.0f);   // startInference, base.h:78-80
-            st2(a.lay.q + i * 8, q[s]);
+            // startInference: Q = softmax(-unary), densecrf_base.h:78-80
+            float in[2] = {un[s].x, un[s].y}, out[2] = {0.f, 0.f};
+            exp_and_normalize_reg<2>(in, out, -1.0f, 1.0f);
+            q[s] = make_float2(out[0], out[1]);
+            Q[i] = q[s];
         }
     }
 
-    // ---- splat entries a lane owns: p = tid + u*kNT (CSR order) ----------------------------
-    float cw[CSR_REG ? K : 1][CSR_REG ? EPT : 1];
-    unsigned pa[CSR_REG ? K : 1][CSR_REG ? (EPT + 1) / 2 : 1];   // LDS addresses of Q[contributing point], two per register
+    // ---- per-frame lattice tables into LDS --------------------------------------------
+    int V[K], E[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const KernelDev &kd = a.kd[k];
+        V[k] = kd.V[f];
+        E[k] = N * D1;
+        unsigned *nbr = reinterpret_cast<unsigned *>(smem + a.lay.nbr[k]);
+        const int2 *gn = reinterpret_cast<const int2 *>(kd.nbr) + (size_t)f * D1 * kd.Epad;
+        for (int idx = tid; idx < D1 * V[k]; idx += kNT) {
+            const int j = idx / V[k], v = idx - j * V[k];
+            const int2 n = gn[(size_t)j * kd.Epad + v];
+            nbr[idx] = (unsigned)(n.x + 1) | ((unsigned)(n.y + 1) << 16);
+        }
+        unsigned short *row = reinterpret_cast<unsigned short *>(smem + a.lay.row[k]);
+        const int *gr = kd.rowptr + (size_t)f * (kd.Epad + 1);
+        for (int v = tid; v <= V[k]; v += kNT) row[v] = (unsigned short)gr[v];
+        if (tid == 0) {
+            reinterpret_cast<float2 *>(smem + a.lay.val[k][0])[0] = make_float2(0.f, 0.f);
+            reinterpret_cast<float2 *>(smem + a.lay.val[k][1])[0] = make_float2(0.f, 0.f);
+        }
+    }
+    // The splat contributions (CSR order) never change between iterations: when they fit,
+    // each lane keeps its EPT entries per kernel in registers and the loop touches no HBM/L2.
+    float cw_r[CSR_REG ? K : 1][CSR_REG ? EPT : 1];
+    int cp_r[CSR_REG ? K : 1][CSR_REG ? EPT : 1];
     if constexpr (CSR_REG) {
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-            const float *gw = a.kd[k].csr_w + (size_t)f * a.kd[k].Epad;
-            const int *gp = a.kd[k].csr_pt + (size_t)f * a.kd[k].Epad;
-#pragma unroll
-            for (int u = 0; u < (EPT + 1) / 2; ++u) pa[k][u] = 0;
+            const float *cw = a.kd[k].csr_w + (size_t)f * a.kd[k].Epad;
+            const int *cp = a.kd[k].csr_pt + (size_t)f * a.kd[k].Epad;
 #pragma unroll
             for (int u = 0; u < EPT; ++u) {
                 const int p = tid + u * kNT;
-                cw[k][u] = (p < E) ? gw[p] : 0.0f;
-                pa[k][u >> 1] |= (unsigned)(a.lay.q + ((p < E) ? gp[p] : 0) * 8) << ((u & 1) * 16);
+                cw_r[k][u] = (p < E[k]) ? cw[p] : 0.0f;
+                cp_r[k][u] = (p < E[k]) ? cp[p] : 0;
             }
         }
-    }
-
-    // ---- lattice vertices a lane owns: all kernels concatenated, g = tid + t*kNT -------------
-    int V[K];
-#pragma unroll
-    for (int k = 0; k < K; ++k) V[k] = a.kd[k].V[f];
-    int own0[kVPT], own1[kVPT];           // LDS address of the vertex in ping / pong (0: no vertex)
-    unsigned nb[kVPT][kD1];               // LDS addresses of its two neighbours per blur pass: n1 | n2<<16
-    int rowaddr[kVPT], rowlen[kVPT];      // its splat row (short-row kernels); len < 0: none
-    int rowk[kVPT];
-#pragma unroll
-    for (int t = 0; t < kVPT; ++t) {
-        int g = tid + t * kNT, k = 0;
-        if (K > 1 && g >= V[0]) { g -= V[0]; k = 1; }
-        const bool valid = g < V[K > 1 ? k : 0];
-        own0[t] = own1[t] = 0;
-        rowaddr[t] = 0;
-        rowlen[t] = -1;
-        rowk[t] = k;
-#pragma unroll
-        for (int j = 0; j < kD1; ++j) nb[t][j] = 0;
-        if (valid) {
-            const KernelDev &kd = a.kd[k];
-            own0[t] = a.lay.val[k][0] + (g + 1) * 8;
-            own1[t] = a.lay.val[k][1] + (g + 1) * 8;
-            const int2 *gn = reinterpret_cast<const int2 *>(kd.nbr) + (size_t)f * kD1 * kd.Epad;
-#pragma unroll
-            for (int j = 0; j < kD1; ++j) {
-                const int2 n = gn[(size_t)j * kd.Epad + g];
-                nb[t][j] = (unsigned)(a.lay.val[k][j & 1] + (n.x + 1) * 8) |
-                           ((unsigned)(a.lay.val[k][j & 1] + (n.y + 1) * 8) << 16);
-            }
-            const int *gr = kd.rowptr + (size_t)f * (kd.Epad + 1);
-            const int r0 = gr[g], r1 = gr[g + 1];
-            rowaddr[t] = a.lay.prod[k] + r0 * 8;
-            rowlen[t] = a.lay.long_mode[k] ? -1 : r1 - r0;
-        }
-    }
-
-    // ---- chain lanes: one lane per (vertex, label) of a long-row kernel ---------------------
-    int chain_addr = 0, chain_len = -1, chain_out = 0, chain_k = -1;
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-        if (a.lay.long_mode[k]) {
-            const int idx = tid - a.lay.chain_base[k];
-            if (idx >= 0 && idx < 2 * V[k]) {
-                const int v = idx >> 1, l = idx & 1;
-                const int *gr = a.kd[k].rowptr + (size_t)f * (a.kd[k].Epad + 1);
-                const int r0 = gr[v], r1 = gr[v + 1];
-                chain_addr = a.lay.prod[k] + (l * a.lay.Ecap + r0) * 4;
-                chain_len = r1 - r0;
-                chain_out = a.lay.val[k][0] + (v + 1) * 8 + l * 4;
-                chain_k = k;
-            }
-        }
-    }
-
-    if (tid < K) {                        // the "absent neighbour" slot of both buffers
-        st2(a.lay.val[tid][0], make_float2(0.f, 0.f));
-        st2(a.lay.val[tid][1], make_float2(0.f, 0.f));
     }
     __syncthreads();
     STAMP();
 
     for (int it = 0; it < a.n_iter; ++it) {
-        // The packed address registers are loop-invariant; without this the compiler hoists their
-        // unpacked halves out of the loop and spills.  The empty asm makes each one opaque per trip.
-#pragma unroll
-        for (int s = 0; s < PPT; ++s)
-#pragma unroll
-            for (int k = 0; k < K; ++k) asm volatile("" : "+v"(gaddr[s][k][0]), "+v"(gaddr[s][k][1]));
-        if constexpr (CSR_REG) {
-#pragma unroll
-            for (int k = 0; k < K; ++k)
-#pragma unroll
-                for (int u = 0; u < (EPT + 1) / 2; ++u) asm volatile("" : "+v"(pa[k][u]));
-        }
-#pragma unroll
-        for (int t = 0; t < kVPT; ++t)
-#pragma unroll
-            for (int j = 0; j < kD1; ++j) asm volatile("" : "+v"(nb[t][j]));
-
-        // ---- P: products w * Q[point] for every splat entry --------------------------------
+        // ---- splat = products (P) + ordered row sums (S) ------------------------------
         auto phase_P = [&](int k) {
-            const bool lm = a.lay.long_mode[k] != 0;
-            const int wbase = a.lay.prod[k] + tid * (lm ? 4 : 8);
-            const int lstride = a.lay.Ecap * 4;
+            const KernelDev &kd = a.kd[k];
+            float *p0 = reinterpret_cast<float *>(smem + a.lay.prod[k]);
+            float *p1 = p0 + a.lay.Ecap[k];
             if constexpr (CSR_REG) {
-                constexpr int CH = (EPT % 6 == 0) ? 6 : kD1;            // gathers in flight per group
+                float2 x[EPT];
 #pragma unroll
-                for (int u0 = 0; u0 < EPT; u0 += CH) {
-                    float2 x[CH];
+                for (int u = 0; u < EPT; ++u) x[u] = Q[cp_r[k][u]];
 #pragma unroll
-                    for (int u = 0; u < CH; ++u)
-                        x[u] = ld2(((u0 + u) & 1) ? hi16(pa[k][(u0 + u) >> 1]) : lo16(pa[k][(u0 + u) >> 1]));
-#pragma unroll
-                    for (int u = 0; u < CH; ++u) {
-                        if (tid + (u0 + u) * kNT < E) {
-                            const float2 r = make_float2(cw[k][u0 + u] * x[u].x, cw[k][u0 + u] * x[u].y);
-                            if (lm) {
-                                st1(wbase + (u0 + u) * kNT * 4, r.x);
-                                st1(wbase + (u0 + u) * kNT * 4 + lstride, r.y);
-                            } else {
-                                st2(wbase + (u0 + u) * kNT * 8, r);
-                            }
-                        }
+                for (int u = 0; u < EPT; ++u) {
+                    const int p = tid + u * kNT;
+                    if (p < E[k]) {
+                        p0[p] = cw_r[k][u] * x[u].x;
+                        p1[p] = cw_r[k][u] * x[u].y;
                     }
-                    __builtin_amdgcn_sched_barrier(0);                   // keep the groups apart: bounded registers
                 }
             } else {
-                const float *gw = a.kd[k].csr_w + (size_t)f * a.kd[k].Epad;
-                const int *gp = a.kd[k].csr_pt + (size_t)f * a.kd[k].Epad;
+                const float *cw = kd.csr_w + (size_t)f * kd.Epad;
+                const int *cp = kd.csr_pt + (size_t)f * kd.Epad;
 #pragma unroll 1
-                for (int u0 = 0; u0 < EPT; u0 += kD1) {                 // D1 entries at a time: bounded registers
-                    float w[kD1];
-                    int pt[kD1];
+                for (int u0 = 0; u0 < EPT; u0 += D1) {                  // D1 entries at a time: bounded registers
+                    float w[D1];
+                    int pt[D1];
 #pragma unroll
-                    for (int u = 0; u < kD1; ++u) {
+                    for (int u = 0; u < D1; ++u) {
                         const int p = tid + (u0 + u) * kNT;
-                        w[u] = (p < E) ? gw[p] : 0.0f;
-                        pt[u] = (p < E) ? gp[p] : 0;
+                        w[u] = (p < E[k]) ? cw[p] : 0.0f;
+                        pt[u] = (p < E[k]) ? cp[p] : 0;
                     }
 #pragma unroll
-                    for (int u = 0; u < kD1; ++u) {
+                    for (int u = 0; u < D1; ++u) {
                         const int p = tid + (u0 + u) * kNT;
-                        const float2 x = ld2(a.lay.q + pt[u] * 8);
-                        if (p < E) {
-                            const float2 r = make_float2(w[u] * x.x, w[u] * x.y);
-                            if (lm) {
-                                st1(wbase + (u0 + u) * kNT * 4, r.x);
-                                st1(wbase + (u0 + u) * kNT * 4 + lstride, r.y);
-                            } else {
-                                st2(wbase + (u0 + u) * kNT * 8, r);
-                            }
+                        const float2 x = Q[pt[u]];
+                        if (p < E[k]) {
+                            p0[p] = w[u] * x.x;
+                            p1[p] = w[u] * x.y;
                         }
                     }
                 }
             }
         };
-
-        // ---- S: ordered row sums -----------------------------------------------------------
-        auto phase_S_short = [&](int k) {
-            // a vertex's (short) row is fetched eight products at a time, then added in order
-#pragma unroll
-            for (int t = 0; t < kVPT; ++t) {
-                const int n = rowlen[t];
-                if (n < 0 || rowk[t] != k) continue;
-                float a0 = 0.0f, a1 = 0.0f;
-                for (int cidx = 0; cidx < n; cidx += 8) {
-                    float2 x[8];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) x[u] = ld2(rowaddr[t] + (cidx + u) * 8);   // buffer is padded
-#pragma unroll
-                    for (int u = 0; u < 8; ++u)
-                        if (cidx + u < n) { a0 += x[u].x; a1 += x[u].y; }
+        auto phase_S = [&](int k) {
+            const float *p0 = reinterpret_cast<const float *>(smem + a.lay.prod[k]);
+            const unsigned short *row = reinterpret_cast<const unsigned short *>(smem + a.lay.row[k]);
+            float *val = reinterpret_cast<float *>(smem + a.lay.val[k][0]);
+            for (int idx = tid; idx < 2 * V[k]; idx += kNT) {
+                const int v = idx >> 1, l = idx & 1;
+                const float *pl = p0 + l * a.lay.Ecap[k];
+                const int s = row[v], t = row[v + 1];
+                float acc = 0.0f;
+                int p = s;
+                for (; p + 8 <= t; p += 8) {                            // 8 loads in flight, then
+                    const float x0 = pl[p], x1 = pl[p + 1], x2 = pl[p + 2], x3 = pl[p + 3];
+                    const float x4 = pl[p + 4], x5 = pl[p + 5], x6 = pl[p + 6], x7 = pl[p + 7];
+                    acc += x0; acc += x1; acc += x2; acc += x3;         // strictly left to right
+                    acc += x4; acc += x5; acc += x6; acc += x7;
                 }
-                st2(own0[t], make_float2(a0, a1));
+                for (; p < t; ++p) acc += pl[p];
+                val[(v + 1) * 2 + l] = acc;
             }
         };
-        auto phase_S_chain = [&](int k) {
-            // one lane per (vertex, label): the row streams through a 2 x 32-deep register ring so
-            // the strictly ordered additions never wait for LDS.
-            if (chain_len < 0 || chain_k != k) return;
-            const int n = chain_len;
-            int addr = chain_addr;
-            float acc = 0.0f;
-            int p = 0;
-            while (p < n && (addr & 15)) { acc += ld1(addr); addr += 4; ++p; }     // reach 16-byte alignment
-            // Blocks of 16 products, two register buffers A/B used alternately: the loads of the
-            // next block are issued BEFORE the (strictly ordered) additions of the current one;
-            // sched_barrier keeps the compiler from folding the pipeline back into load->use.
-            const int nblk = (n - p) >> 4;
-            if (nblk > 0) {
-                float4 A[4], B[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) A[u] = ld4(addr + u * 16);
-                int b = 0;
-#pragma unroll 1
-                for (; b + 2 <= nblk; b += 2) {
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) B[u] = ld4(addr + (b + 1) * 64 + u * 16);
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) { acc += A[u].x; acc += A[u].y; acc += A[u].z; acc += A[u].w; }
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) A[u] = ld4(addr + (b + 2) * 64 + u * 16);   // may over-read into the pad
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) { acc += B[u].x; acc += B[u].y; acc += B[u].z; acc += B[u].w; }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                if (b < nblk) {
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) { acc += A[u].x; acc += A[u].y; acc += A[u].z; acc += A[u].w; }
-                }
-                addr += nblk * 64;
-                p += nblk * 16;
-            }
-            if (p < n) {                                             // < 16 left: up to 3 aligned quads, then singles
-                const int nq = (n - p) >> 2;
-                float4 t4[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) t4[u] = ld4(addr + u * 16);           // over-read stays inside the buffer pad
-#pragma unroll
-                for (int u = 0; u < 3; ++u)
-                    if (u < nq) { acc += t4[u].x; acc += t4[u].y; acc += t4[u].z; acc += t4[u].w; }
-                const float4 last = nq == 0 ? t4[0] : nq == 1 ? t4[1] : nq == 2 ? t4[2] : t4[3];
-                p += nq * 4;
-                if (p < n) acc += last.x;
-                if (p + 1 < n) acc += last.y;
-                if (p + 2 < n) acc += last.z;
-            }
-            st1(chain_out, acc);
-        };
-
         if (a.lay.prod_all) {
 #pragma unroll
             for (int k = 0; k < K; ++k) phase_P(k);
             __syncthreads();
             STAMP();
 #pragma unroll
-            for (int k = 0; k < K; ++k) {
-                if (a.lay.long_mode[k]) phase_S_chain(k);
-                else phase_S_short(k);
-                STAMP();
-            }
+            for (int k = 0; k < K; ++k) phase_S(k);
             __syncthreads();
             STAMP();
         } else {
@@ -392,62 +219,62 @@ __global__ void __launch_bounds__(kNT) k_fused(CrfDev c, FusedArgs a)
             for (int k = 0; k < K; ++k) {
                 phase_P(k);
                 __syncthreads();
-                if (a.lay.long_mode[k]) phase_S_chain(k);
-                else phase_S_short(k);
+                phase_S(k);
                 __syncthreads();
             }
-            STAMP();
-            STAMP();
         }
 
-        // ---- d+1 Jacobi blur passes, permutohedral_cpu.h:663-679 ------------------------------
+        // ---- d+1 Jacobi blur passes, permutohedral_cpu.h:663-679 -----------------------
 #pragma unroll
-        for (int j = 0; j < kD1; ++j) {
+        for (int j = 0; j < D1; ++j) {
 #pragma unroll
-            for (int t = 0; t < kVPT; ++t) {
-                if (own0[t]) {
-                    const float2 o = ld2((j & 1) ? own1[t] : own0[t]);
-                    const float2 x = ld2(lo16(nb[t][j])), y = ld2(hi16(nb[t][j]));
-                    st2((j & 1) ? own0[t] : own1[t],
-                        make_float2(o.x + 0.5f * (x.x + y.x), o.y + 0.5f * (x.y + y.y)));
+            for (int k = 0; k < K; ++k) {
+                const float2 *src = reinterpret_cast<const float2 *>(smem + a.lay.val[k][j & 1]);
+                float2 *dst = reinterpret_cast<float2 *>(smem + a.lay.val[k][(j & 1) ^ 1]);
+                const unsigned *nbr = reinterpret_cast<const unsigned *>(smem + a.lay.nbr[k]) + j * V[k];
+                for (int v = tid; v < V[k]; v += kNT) {
+                    const unsigned n = nbr[v];
+                    const float2 o = src[v + 1], x = src[n & 0xffffu], y = src[n >> 16];
+                    float2 r;
+                    r.x = o.x + 0.5f * (x.x + y.x);
+                    r.y = o.y + 0.5f * (x.y + y.y);
+                    dst[v + 1] = r;
                 }
             }
             __syncthreads();
         }
         STAMP();
 
-        // ---- X: slice + apply + softmax per point -------------------------------------------------
+        // ---- slice + apply + softmax per point ----------------------------------------
 #pragma unroll
         for (int s = 0; s < PPT; ++s) {
             const int i = tid + s * kNT;
             if (i < N) {
-                float2 x[K][kD1];
-#pragma unroll
-                for (int k = 0; k < K; ++k)
-#pragma unroll
-                    for (int j = 0; j < kD1; ++j)
-                        x[k][j] = ld2(j == 0 ? lo16(gaddr[s][k][0]) : j == 1 ? hi16(gaddr[s][k][0]) : (int)gaddr[s][k][1]);
-                float n0 = -un[s].x, n1 = -un[s].y;                       // stepInit, densecrf3d.h:154-158
+                float nx[2] = {-un[s].x, -un[s].y};                       // stepInit, densecrf3d.h:154-158
 #pragma unroll
                 for (int k = 0; k < K; ++k) {
-                    float t0 = 0.0f, t1 = 0.0f;                           // slice, permutohedral_cpu.h:684-694
+                    const float2 *val = reinterpret_cast<const float2 *>(smem + a.lay.val[k][D1 & 1]);
+                    float t0 = 0.0f, t1 = 0.0f;
 #pragma unroll
-                    for (int j = 0; j < kD1; ++j) {
-                        t0 += wgt[s][k][j] * x[k][j].x;
-                        t1 += wgt[s][k][j] * x[k][j].y;
+                    for (int j = 0; j < D1; ++j) {
+                        const float2 x = val[off[s][k][j]];
+                        t0 += wgt[s][k][j] * x.x;
+                        t1 += wgt[s][k][j] * x.y;
                     }
-                    n0 += wn[s][k] * t0;                                  // apply, pairwise3d.h:77
-                    n1 += wn[s][k] * t1;
+                    nx[0] += wn[s][k] * t0;                               // pairwise3d.h:77
+                    nx[1] += wn[s][k] * t1;
                 }
-                q[s] = softmax2(1.0f * n0, 1.0f * n1, q[s], a.relax);     // densecrf_base.h:90
-                st2(a.lay.q + i * 8, q[s]);
+                float out[2] = {q[s].x, q[s].y};
+                exp_and_normalize_reg<2>(nx, out, 1.0f, a.relax);
+                q[s] = make_float2(out[0], out[1]);
+                Q[i] = q[s];
             }
         }
         __syncthreads();
         STAMP();
     }
 
-    // ---- results ------------------------------------------------------------------------------
+    // ---- results ------------------------------------------------------------------------
 #pragma unroll
     for (int s = 0; s < PPT; ++s) {
         const int i = tid + s * kNT;
@@ -460,24 +287,13 @@ __global__ void __launch_bounds__(kNT) k_fused(CrfDev c, FusedArgs a)
     if (a.timing && blockIdx.x == 0 && tid == 0) a.timing[63] = n_stamp;
 }
 
-bool make_layout(const CrfDev &c, const KernelDev *kds, const int *maxV, const int *maxRow, FusedLayout *lay)
+bool make_layout(const CrfDev &c, const KernelDev *kds, const int *maxV, FusedLayout *lay)
 {
     if (c.L != 2 || c.K < 1 || c.K > kMaxFusedK) return false;
-    if (c.maxN < 1 || c.maxN > kMaxPPT * kNT) return false;
-    int vtot = 0;
+    if (c.maxN < 1 || c.maxN > 4 * kNT) return false;
     for (int k = 0; k < c.K; ++k) {
-        if (kds[k].d != 2) return false;
-        vtot += maxV[k];
-    }
-    if (vtot > kVPT * kNT) return false;
-    // chain lanes for long-row kernels, as long as lanes remain
-    int long_mode[kMaxFusedK] = {0, 0}, chain_base[kMaxFusedK] = {0, 0}, next_lane = 0;
-    for (int k = 0; k < c.K; ++k) {
-        if (maxRow[k] > kLongRow && next_lane + 2 * maxV[k] <= kNT) {
-            long_mode[k] = 1;
-            chain_base[k] = next_lane;
-            next_lane += (2 * maxV[k] + 63) & ~63;                  // whole wavefronts
-        }
+        if (kds[k].d != kds[0].d || kds[k].d != 2) return false;
+        if (maxV[k] >= 65535 || kds[k].Epad >= 65535) return false;     // u16 row pointers / neighbour ids
     }
     for (int all = 1; all >= 0; --all) {
         FusedLayout L{};
@@ -485,19 +301,20 @@ bool make_layout(const CrfDev &c, const KernelDev *kds, const int *maxV, const i
         auto take = [&](size_t bytes) { size_t r = o; o += (bytes + 15) & ~(size_t)15; return (int)r; };
         L.prod_all = all;
         L.q = take((size_t)c.maxN * sizeof(float2));
-        L.Ecap = ((c.maxN * kD1 + 3) & ~3) + 64;                     // pad: rows are over-read by < 64 floats
+        size_t shared_prod = 0;
         for (int k = 0; k < c.K; ++k) {
-            L.long_mode[k] = long_mode[k];
-            L.chain_base[k] = chain_base[k];
+            L.Ecap[k] = c.maxN * kds[k].D1;
+            L.Vcap[k] = maxV[k];
             L.val[k][0] = take((size_t)(maxV[k] + 1) * sizeof(float2));
             L.val[k][1] = take((size_t)(maxV[k] + 1) * sizeof(float2));
+            L.nbr[k] = take((size_t)kds[k].D1 * maxV[k] * sizeof(unsigned));
+            L.row[k] = take((size_t)(maxV[k] + 2) * sizeof(unsigned short));
+            const size_t pb = (size_t)L.Ecap[k] * 2 * sizeof(float);
+            if (all) L.prod[k] = take(pb);
+            else shared_prod = pb > shared_prod ? pb : shared_prod;
         }
-        if (o > 65536) return false;                                 // 16-bit LDS addresses for Q and val
-        const size_t pb = (size_t)L.Ecap * sizeof(float2);
-        if (all) {
-            for (int k = 0; k < c.K; ++k) L.prod[k] = take(pb);
-        } else {
-            const int p = take(pb);
+        if (!all) {
+            const int p = take(shared_prod);
             for (int k = 0; k < c.K; ++k) L.prod[k] = p;
         }
         L.total = (int)o;
@@ -512,7 +329,7 @@ bool make_layout(const CrfDev &c, const KernelDev *kds, const int *maxV, const i
 template <int PPT, int K>
 void launch_fused(const CrfDev &c, const FusedArgs &a, hipStream_t s)
 {
-    auto fn = k_fused<PPT, K, (PPT <= 4)>;
+    auto fn = k_fused<PPT, K, 2, (PPT <= 2)>;
     // per (function, device); cheap enough to repeat and safe with several devices in one process
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)kLdsLimit);
@@ -521,19 +338,20 @@ void launch_fused(const CrfDev &c, const FusedArgs &a, hipStream_t s)
 
 }  // namespace
 
-bool fused_supported(const CrfDev &c, const KernelDev *kds, const int *maxV, const int *maxRow, size_t *lds_bytes)
+bool fused_supported(const CrfDev &c, const KernelDev *kds, const int *maxV, const int * /*maxRow*/,
+                     size_t *lds_bytes)
 {
     FusedLayout lay;
-    const bool ok = make_layout(c, kds, maxV, maxRow, &lay);
+    const bool ok = make_layout(c, kds, maxV, &lay);
     if (lds_bytes) *lds_bytes = ok ? (size_t)lay.total : 0;
     return ok;
 }
 
-void launch_inference_fused(const CrfDev &c, const KernelDev *kds, const int *maxV, const int *maxRow, int n_iter,
-                            int with_map, float relax, hipStream_t s)
+void launch_inference_fused(const CrfDev &c, const KernelDev *kds, const int *maxV, const int * /*maxRow*/,
+                            int n_iter, int with_map, float relax, hipStream_t s)
 {
     FusedArgs a{};
-    if (!make_layout(c, kds, maxV, maxRow, &a.lay)) return;
+    if (!make_layout(c, kds, maxV, &a.lay)) return;
     for (int k = 0; k < c.K; ++k) a.kd[k] = kds[k];
     a.n_iter = n_iter;
     a.with_map = with_map;
@@ -553,9 +371,6 @@ void launch_inference_fused(const CrfDev &c, const KernelDev *kds, const int *ma
         FUSED_CASE(2)
         FUSED_CASE(3)
         FUSED_CASE(4)
-        FUSED_CASE(5)
-        FUSED_CASE(6)
-        FUSED_CASE(7)
     default: break;
     }
 #undef FUSED_CASE
