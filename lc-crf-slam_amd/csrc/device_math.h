@@ -219,6 +219,20 @@ __device__ __forceinline__ void exp_and_normalize_reg(const float (&in)[L], floa
     }
 }
 
+// expAndNormalize for two labels (densecrf3d.h:70-98), a = scale*in[0], b = scale*in[1].  One of
+// the two fast_exp arguments is exactly 0 (value minus row maximum) and fast_exp(0) == 1, so a
+// single exp is evaluated; the sum and the two IEEE divisions are the reference's.
+__device__ __forceinline__ float2 softmax2(float a, float b, float2 old, float relax)
+{
+    const bool lt = a < b;                            // mx = b iff a < b (densecrf3d.h:76-79)
+    const float e = fast_exp_nonpos(lt ? a - b : b - a);
+    const float v0 = lt ? e : 1.0f, v1 = lt ? 1.0f : e;
+    const float tt = v0 + v1;
+    const float p0 = v0 / tt, p1 = v1 / tt;
+    if (relax == 1) return make_float2(p0, p1);
+    return make_float2((1 - relax) * old.x + relax * p0, (1 - relax) * old.y + relax * p1);
+}
+
 __device__ __forceinline__ int argmax_row(const float *p, int L)   // densecrf3d.h:140-149
 {
     float mx = p[0];

@@ -336,6 +336,75 @@ __global__ void __launch_bounds__(kBlock) k_slice(KernelDev kd, CrfDev c, const 
     }
 }
 
+// ---- two-label specialisations (the SLAM configuration, L = 2): one thread per vertex / point,
+// both labels in a float2.  Same operations per label as the generic kernels above.
+__global__ void __launch_bounds__(kBlock) k_splat2(KernelDev kd, const float2 *__restrict__ in, int in_stride)
+{
+    const int f = blockIdx.y;
+    const int v = blockIdx.x * kBlock + threadIdx.x;
+    if (v >= kd.V[f]) return;
+    const size_t fe = (size_t)f * kd.Epad, f1 = (size_t)f * (kd.Epad + 1);
+    const int s = kd.rowptr[f1 + v], t = kd.rowptr[f1 + v + 1];
+    const float2 *x = in + (size_t)f * in_stride;
+    float a0 = 0.0f, a1 = 0.0f;
+    for (int p = s; p < t; ++p) {
+        const float w = kd.csr_w[fe + p];
+        const float2 q = x[kd.csr_pt[fe + p]];
+        a0 += w * q.x;
+        a1 += w * q.y;
+    }
+    reinterpret_cast<float2 *>(kd.val0 + (size_t)f * kd.vstride + kd.vbase)[v] = make_float2(a0, a1);
+}
+
+__global__ void __launch_bounds__(kBlock) k_blur2(KernelDev kd, const float *__restrict__ src,
+                                                  float *__restrict__ dst, int j)
+{
+    const int f = blockIdx.y;
+    const int v = blockIdx.x * kBlock + threadIdx.x;
+    if (v >= kd.V[f]) return;
+    const int2 nb = reinterpret_cast<const int2 *>(kd.nbr)[((size_t)f * kd.D1 + j) * kd.Epad + v];
+    const float2 *o = reinterpret_cast<const float2 *>(src + (size_t)f * kd.vstride + kd.vbase);   // o[-1] = absent
+    const float2 c = o[v], x = o[nb.x], y = o[nb.y];
+    reinterpret_cast<float2 *>(dst + (size_t)f * kd.vstride + kd.vbase)[v] =
+        make_float2(c.x + 0.5f * (x.x + y.x), c.y + 0.5f * (x.y + y.y));
+}
+
+// slice + apply for L = 2; the LAST kernel of the step also does the softmax (saves a pass over next).
+template <int D1>
+__global__ void __launch_bounds__(kBlock) k_slice2(KernelDev kd, CrfDev c, const float *__restrict__ val,
+                                                   int first, int last, float relax)
+{
+    const int f = blockIdx.y;
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= c.n_points[f]) return;
+    const size_t fe = (size_t)f * kd.Epad;
+    const float2 *vf = reinterpret_cast<const float2 *>(val + (size_t)f * kd.vstride + kd.vbase);
+    float t0 = 0.0f, t1 = 0.0f;
+#pragma unroll
+    for (int j = 0; j < D1; ++j) {
+        const float wgt = kd.bary[fe + (size_t)i * D1 + j] * kd.alpha;
+        const float2 x = vf[kd.offset[fe + (size_t)i * D1 + j]];
+        t0 += wgt * x.x;
+        t1 += wgt * x.y;
+    }
+    const size_t q = (size_t)f * c.maxN + i;
+    float2 base;
+    if (first) {
+        const float2 u = reinterpret_cast<const float2 *>(c.unary)[q];
+        base = make_float2(-u.x, -u.y);
+    } else {
+        base = reinterpret_cast<const float2 *>(c.next)[q];
+    }
+    const float wn = kd.w * kd.norm[q];
+    const float2 nx = make_float2(base.x + wn * t0, base.y + wn * t1);
+    if (last) {
+        float2 *Q = reinterpret_cast<float2 *>(c.Q);
+        Q[q] = softmax2(1.0f * nx.x, 1.0f * nx.y, Q[q], relax);
+    } else {
+        reinterpret_cast<float2 *>(c.next)[q] = nx;
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // CRF-level kernels
 // ---------------------------------------------------------------------------------------
@@ -451,6 +520,33 @@ void launch_step_stream(const CrfDev &c, const KernelDev *kds, const int *maxV, 
     if (c.K == 0) {
         // stepInit only: next = -unary, then softmax.  Done by the softmax with scale -1.
         k_softmax<<<grid_for(c.maxN, c.F), kBlock, 0, s>>>(c, c.unary, c.Q, -1.0f, relax);
+        return;
+    }
+    if (L == 2) {
+        for (int k = 0; k < c.K; ++k) {
+            const KernelDev &kd = kds[k];
+            k_splat2<<<grid_for(maxV[k], c.F), kBlock, 0, s>>>(kd, reinterpret_cast<const float2 *>(c.Q), c.maxN);
+            const float *src = kd.val0;
+            float *dst = kd.val1;
+            for (int j = 0; j < kd.D1; ++j) {
+                k_blur2<<<grid_for(maxV[k], c.F), kBlock, 0, s>>>(kd, src, dst, j);
+                const float *t = src;
+                src = dst;
+                dst = const_cast<float *>(t);
+            }
+            const int first = k == 0, last = k == c.K - 1;
+            const dim3 g = grid_for(c.maxN, c.F);
+            switch (kd.D1) {
+            case 2: k_slice2<2><<<g, kBlock, 0, s>>>(kd, c, src, first, last, relax); break;
+            case 3: k_slice2<3><<<g, kBlock, 0, s>>>(kd, c, src, first, last, relax); break;
+            case 4: k_slice2<4><<<g, kBlock, 0, s>>>(kd, c, src, first, last, relax); break;
+            case 5: k_slice2<5><<<g, kBlock, 0, s>>>(kd, c, src, first, last, relax); break;
+            case 6: k_slice2<6><<<g, kBlock, 0, s>>>(kd, c, src, first, last, relax); break;
+            case 7: k_slice2<7><<<g, kBlock, 0, s>>>(kd, c, src, first, last, relax); break;
+            case 8: k_slice2<8><<<g, kBlock, 0, s>>>(kd, c, src, first, last, relax); break;
+            default: k_slice2<9><<<g, kBlock, 0, s>>>(kd, c, src, first, last, relax); break;
+            }
+        }
         return;
     }
     for (int k = 0; k < c.K; ++k) {
