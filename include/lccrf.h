@@ -60,8 +60,13 @@ typedef struct lccrf_crf *lccrf_handle;
 
 /* DenseCRF3D<M>::DenseCRF3D(int N)              densecrf3d.h:23-28   (M = n_labels)   */
 int  lccrf_create(lccrf_handle *out, int device_id, int n_points, int n_labels);
-/* ~DenseCRF3D / ~DenseCRF (owns its pairwise terms)  densecrf3d.h:30-36, base.h:41-45 */
+/* ~DenseCRF3D / ~DenseCRF (owns its pairwise terms)  densecrf3d.h:30-36, base.h:41-45.
+ * The reference constructs and destroys one CRF per frame (src/Tracking.cc:1920); to keep that
+ * pattern cheap a destroyed handle's device memory, stream and pinned staging are parked and
+ * reused by the next lccrf_create of a compatible size.  lccrf_trim_cache() frees the parked
+ * handles (returns how many).                                                             */
 void lccrf_destroy(lccrf_handle h);
+int  lccrf_trim_cache(void);
 
 /* DenseCRF::setUnaryEnergy(const float*)        densecrf3d.h:41-43                    */
 int  lccrf_set_unary(lccrf_handle h, const float *unary);

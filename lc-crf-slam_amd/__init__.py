@@ -68,6 +68,7 @@ def lib():
     L.lccrf_create.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_int]
     L.lccrf_destroy.argtypes = [vp]
     L.lccrf_destroy.restype = None
+    L.lccrf_trim_cache.argtypes = []
     L.lccrf_set_unary.argtypes = [vp, _f32p]
     L.lccrf_set_unary_from_label.argtypes = [vp, _i16p, _f32p]
     L.lccrf_add_pairwise.argtypes = [vp, _f32p, C.c_int, C.c_float]

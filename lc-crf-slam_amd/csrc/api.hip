@@ -10,7 +10,9 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <algorithm>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -105,6 +107,7 @@ struct Engine {
     hipStream_t stream = nullptr;
     Arena mem;
     int Fcap = 0, F = 0, maxN = 0, maxNpad = 0, L = 0;
+    int activeN = 0;                   // largest frame of the current inputs if known on the host, else 0
     CrfDev crf{};
     int *npoints_own = nullptr;
     float *unary_own = nullptr;
@@ -114,6 +117,7 @@ struct Engine {
     int *V_host = nullptr;             // pinned [K][Fcap]
     int *row_host = nullptr;           // pinned [K][Fcap]
     std::vector<KernelState> kernels;
+    std::vector<KernelState> spare;    // allocated lattices of earlier uses of this (recycled) engine
     std::vector<KernelDev> kdevs;      // contiguous copy handed to the launchers
     std::vector<int> maxV, maxRow;
     bool unary_set = false, built = false, sizes_known = false, started = false;
@@ -168,6 +172,19 @@ struct Engine {
         if ((int)kernels.size() >= LCCRF_MAX_KERNELS)
             return fail(LCCRF_E_CAPACITY, "at most %d pairwise kernels", LCCRF_MAX_KERNELS);
         if (d < 1 || d > LCCRF_MAX_DIMS) return fail(LCCRF_E_INVALID, "feature dims %d not in [1,%d]", d, LCCRF_MAX_DIMS);
+        for (size_t i = 0; i < spare.size(); ++i) {     // a recycled engine already owns a lattice of this shape
+            if (spare[i].dev.d == d && (!stage || spare[i].feat_stage) && (!own_features || spare[i].feat_own)) {
+                KernelState ks = spare[i];
+                spare.erase(spare.begin() + i);
+                ks.dev.w = w;
+                ks.dev.feat = ks.feat_own;
+                ks.maxV = ks.dev.Epad;
+                ks.maxRow = 0;
+                kernels.push_back(ks);
+                sync_views();
+                return LCCRF_OK;
+            }
+        }
         KernelState ks;
         KernelDev &k = ks.dev;
         k.d = d;
@@ -216,6 +233,21 @@ struct Engine {
         return LCCRF_OK;
     }
 
+    // Park everything for the next user of this engine (object API handle cache).
+    void recycle()
+    {
+        if (stream) (void)hipStreamSynchronize(stream);
+        for (auto &ks : kernels) spare.push_back(ks);
+        kernels.clear();
+        F = Fcap;
+        crf.unary = unary_own;
+        crf.n_points = npoints_own;
+        unary_set = built = sizes_known = started = false;
+        engine_pref = 0;
+        engine_used = 1;
+        sync_views();
+    }
+
     void sync_views()
     {
         kdevs.resize(kernels.size());
@@ -228,6 +260,7 @@ struct Engine {
         }
         crf.K = (int)kernels.size();
         crf.F = F;
+        crf.activeN = activeN;
     }
 
     // Lattice + normalisation of kernel k for every frame (PottsPotential3D ctor).
@@ -321,11 +354,25 @@ struct Engine {
 
 struct lccrf_crf {
     Engine eng;
-    int N = 0;
-    int16_t *stage_i16 = nullptr;   // pinned [N]
-    float *stage_f32 = nullptr;     // pinned [N*L]
-    int one = 0;
+    int N = 0;                      // points of the CRF this handle currently represents
+    int cap = 0;                    // capacity it was allocated for (eng.maxN)
+    int16_t *stage_i16 = nullptr;   // pinned [cap]
+    float *stage_f32 = nullptr;     // pinned [cap*L]
+    int *stage_n = nullptr;         // pinned [1]
 };
+
+namespace {
+// The reference builds and destroys a DenseCRF3D per frame (src/Tracking.cc:1920); doing that with
+// device memory, a stream and pinned staging costs milliseconds.  Destroyed handles are therefore
+// parked here and handed out again by lccrf_create when device, label count and capacity fit.
+struct HandleCache {
+    std::mutex m;
+    std::vector<lccrf_crf *> parked;
+    static constexpr size_t kMaxParked = 8;
+} g_cache;
+
+int capacity_for(int n) { return std::max(1024, ((n + n / 4 + 511) / 512) * 512); }
+}  // namespace
 
 struct lccrf_batch {
     Engine eng;
@@ -363,20 +410,42 @@ int lccrf_create(lccrf_handle *out, int device_id, int n_points, int n_labels)
     if (n_labels < 1 || n_labels > LCCRF_MAX_LABELS) return fail(LCCRF_E_INVALID, "n_labels %d not in [1,%d]", n_labels, LCCRF_MAX_LABELS);
     int rc = use_device(device_id);
     if (rc) return rc;
-    lccrf_crf *h = new (std::nothrow) lccrf_crf;
-    if (!h) return fail(LCCRF_E_NOMEM, "host allocation failed");
-    h->N = n_points;
-    rc = h->eng.init(device_id, 1, n_points, n_labels);
-    if (!rc) rc = h->eng.mem.alloc_pinned(&h->stage_i16, n_points);
-    if (!rc) rc = h->eng.mem.alloc_pinned(&h->stage_f32, (size_t)n_points * n_labels);
-    if (!rc) {
-        hipError_t e = hipMemcpy(h->eng.npoints_own, &n_points, sizeof(int), hipMemcpyHostToDevice);
-        if (e != hipSuccess) rc = fail(LCCRF_E_HIP, "hipMemcpy n_points: %s", hipGetErrorString(e));
+    lccrf_crf *h = nullptr;
+    {
+        std::lock_guard<std::mutex> g(g_cache.m);
+        for (size_t i = 0; i < g_cache.parked.size(); ++i) {
+            lccrf_crf *c = g_cache.parked[i];
+            if (c->eng.device == device_id && c->eng.L == n_labels && c->cap >= n_points &&
+                c->cap <= std::max(4 * n_points, 4096)) {
+                h = c;
+                g_cache.parked.erase(g_cache.parked.begin() + i);
+                break;
+            }
+        }
     }
-    if (rc) {
+    if (!h) {
+        h = new (std::nothrow) lccrf_crf;
+        if (!h) return fail(LCCRF_E_NOMEM, "host allocation failed");
+        h->cap = capacity_for(n_points);
+        rc = h->eng.init(device_id, 1, h->cap, n_labels);
+        if (!rc) rc = h->eng.mem.alloc_pinned(&h->stage_i16, h->cap);
+        if (!rc) rc = h->eng.mem.alloc_pinned(&h->stage_f32, (size_t)h->cap * n_labels);
+        if (!rc) rc = h->eng.mem.alloc_pinned(&h->stage_n, 1);
+        if (rc) {
+            h->eng.destroy();
+            delete h;
+            return rc;
+        }
+    }
+    h->N = n_points;
+    h->eng.activeN = n_points;
+    h->eng.sync_views();
+    *h->stage_n = n_points;
+    hipError_t e = hipMemcpyAsync(h->eng.npoints_own, h->stage_n, sizeof(int), hipMemcpyHostToDevice, h->eng.stream);
+    if (e != hipSuccess) {
         h->eng.destroy();
         delete h;
-        return rc;
+        return fail(LCCRF_E_HIP, "hipMemcpyAsync n_points: %s", hipGetErrorString(e));
     }
     *out = h;
     return LCCRF_OK;
@@ -386,8 +455,31 @@ void lccrf_destroy(lccrf_handle h)
 {
     if (!h) return;
     (void)hipSetDevice(h->eng.device);
+    h->eng.recycle();
+    {
+        std::lock_guard<std::mutex> g(g_cache.m);
+        if (g_cache.parked.size() < HandleCache::kMaxParked) {
+            g_cache.parked.push_back(h);
+            return;
+        }
+    }
     h->eng.destroy();
     delete h;
+}
+
+int lccrf_trim_cache(void)
+{
+    std::vector<lccrf_crf *> v;
+    {
+        std::lock_guard<std::mutex> g(g_cache.m);
+        v.swap(g_cache.parked);
+    }
+    for (lccrf_crf *h : v) {
+        (void)hipSetDevice(h->eng.device);
+        h->eng.destroy();
+        delete h;
+    }
+    return (int)v.size();
 }
 
 #define CHECK_H(h)                                                    \
@@ -638,6 +730,8 @@ int lccrf_batch_set_inputs_host(lccrf_batch_handle b, int n_frames, const int32_
     Engine &e = b->eng;
     for (int f = 0; f < n_frames; ++f)
         if (n_points[f] < 0 || n_points[f] > e.maxN) return fail(LCCRF_E_CAPACITY, "n_points[%d]=%d not in [0,%d]", f, n_points[f], e.maxN);
+    e.activeN = 0;
+    for (int f = 0; f < n_frames; ++f) e.activeN = std::max(e.activeN, n_points[f]);
     HIP_TRY(hipStreamSynchronize(e.stream));
     HIP_TRY(hipMemcpy(e.npoints_own, n_points, sizeof(int) * n_frames, hipMemcpyHostToDevice));
     e.crf.n_points = e.npoints_own;
@@ -671,6 +765,7 @@ int lccrf_batch_bind_inputs_device(lccrf_batch_handle b, int n_frames, const int
     int rc = batch_common_inputs(b, n_frames, conf, d_unary != nullptr, d_label != nullptr);
     if (rc) return rc;
     Engine &e = b->eng;
+    e.activeN = 0;                                    // per-frame sizes live on the device: unknown here
     e.crf.n_points = d_n_points;
     if (d_unary) {
         e.crf.unary = const_cast<float *>(d_unary);   // read-only use

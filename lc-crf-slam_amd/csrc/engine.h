@@ -55,7 +55,8 @@ struct KernelDev {
 
 // Device view of the CRF state of a batch.
 struct CrfDev {
-    int F, maxN, L, K;
+    int F, maxN, L, K;    // maxN = per-frame STRIDE (capacity) of every point array
+    int activeN;          // largest n_points of the batch when the host knows it, else maxN
     const int *n_points;  // [F]
     float *unary;         // [F][maxN][L]
     float *Q;             // [F][maxN][L]   current_

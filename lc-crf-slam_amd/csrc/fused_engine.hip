@@ -290,7 +290,8 @@ __global__ void __launch_bounds__(kNT) k_fused(CrfDev c, FusedArgs a)
 bool make_layout(const CrfDev &c, const KernelDev *kds, const int *maxV, FusedLayout *lay)
 {
     if (c.L != 2 || c.K < 1 || c.K > kMaxFusedK) return false;
-    if (c.maxN < 1 || c.maxN > 4 * kNT) return false;
+    const int NA = c.activeN > 0 ? c.activeN : c.maxN;   // size LDS and the points-per-lane variant by the frames' real size
+    if (NA < 1 || NA > 4 * kNT) return false;
     for (int k = 0; k < c.K; ++k) {
         if (kds[k].d != kds[0].d || kds[k].d != 2) return false;
         if (maxV[k] >= 65535 || kds[k].Epad >= 65535) return false;     // u16 row pointers / neighbour ids
@@ -300,10 +301,10 @@ bool make_layout(const CrfDev &c, const KernelDev *kds, const int *maxV, FusedLa
         size_t o = 0;
         auto take = [&](size_t bytes) { size_t r = o; o += (bytes + 15) & ~(size_t)15; return (int)r; };
         L.prod_all = all;
-        L.q = take((size_t)c.maxN * sizeof(float2));
+        L.q = take((size_t)NA * sizeof(float2));
         size_t shared_prod = 0;
         for (int k = 0; k < c.K; ++k) {
-            L.Ecap[k] = c.maxN * kds[k].D1;
+            L.Ecap[k] = NA * kds[k].D1;
             L.Vcap[k] = maxV[k];
             L.val[k][0] = take((size_t)(maxV[k] + 1) * sizeof(float2));
             L.val[k][1] = take((size_t)(maxV[k] + 1) * sizeof(float2));
@@ -360,7 +361,7 @@ void launch_inference_fused(const CrfDev &c, const KernelDev *kds, const int *ma
     static const bool want_timing = getenv("LCCRF_FUSED_TIMING") != nullptr;
     if (want_timing && !timing_buf) (void)hipMalloc(&timing_buf, 64 * sizeof(long long));
     a.timing = want_timing ? timing_buf : nullptr;
-    const int ppt = (c.maxN + kNT - 1) / kNT;
+    const int ppt = ((c.activeN > 0 ? c.activeN : c.maxN) + kNT - 1) / kNT;
 #define FUSED_CASE(P)                                            \
     case P:                                                      \
         if (c.K == 1) launch_fused<P, 1>(c, a, s);               \
