@@ -263,20 +263,36 @@ struct Engine {
         crf.activeN = activeN;
     }
 
-    // Lattice + normalisation of kernel k for every frame (PottsPotential3D ctor).
-    int build_kernel(int k)
+    // Lattice + normalisation of kernels [k0, k0+n) for every frame (PottsPotential3D ctor).
+    // SLAM-size frames take the fused build (one launch for all of them when they share d);
+    // anything else the streaming build (19 launches per kernel).
+    int build_kernels(int k0, int n)
     {
-        KernelState &ks = kernels[k];
-        ks.maxV = ks.dev.Epad;
+        for (int k = k0; k < k0 + n; ++k) kernels[k].maxV = kernels[k].dev.Epad;
         sync_views();
-        launch_build_kernel(kdevs[k], crf, ks.maxV, stream);
-        launch_norm(kdevs[k], crf, ks.maxV, stream);
-        HIP_TRY(hipMemcpyAsync(V_host + (size_t)k * Fcap, ks.dev.V, sizeof(int) * F, hipMemcpyDeviceToHost, stream));
-        HIP_TRY(hipMemcpyAsync(row_host + (size_t)k * Fcap, ks.dev.rowmax, sizeof(int) * F, hipMemcpyDeviceToHost, stream));
+        static const bool no_small = getenv("LCCRF_NO_FUSED_BUILD") != nullptr;
+        int k = k0;
+        while (k < k0 + n) {
+            int m = 1;
+            if (!no_small && k + 1 < k0 + n && build_small_supported(&kdevs[k], 2)) m = 2;
+            if (!no_small && build_small_supported(&kdevs[k], m)) {
+                launch_build_small(&kdevs[k], m, crf, stream);
+            } else {
+                m = 1;
+                launch_build_kernel(kdevs[k], crf, kernels[k].maxV, stream);
+                launch_norm(kdevs[k], crf, kernels[k].maxV, stream);
+            }
+            k += m;
+        }
+        for (k = k0; k < k0 + n; ++k) {
+            HIP_TRY(hipMemcpyAsync(V_host + (size_t)k * Fcap, kernels[k].dev.V, sizeof(int) * F, hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipMemcpyAsync(row_host + (size_t)k * Fcap, kernels[k].dev.rowmax, sizeof(int) * F, hipMemcpyDeviceToHost, stream));
+        }
         HIP_TRY(hipGetLastError());
         sizes_known = false;
         return LCCRF_OK;
     }
+    int build_kernel(int k) { return build_kernels(k, 1); }
 
     // After the builds: learn max V per kernel so inference grids are sized to the lattice.
     int learn_sizes()
@@ -796,7 +812,7 @@ int lccrf_batch_build(lccrf_batch_handle b, void *stream)
     e.stream = pick_stream(b, stream);
     HIP_TRY(hipEventRecord(e.ev[0], e.stream));
     int rc = LCCRF_OK;
-    for (int k = 0; k < (int)e.kernels.size() && !rc; ++k) rc = e.build_kernel(k);
+    if (!e.kernels.empty()) rc = e.build_kernels(0, (int)e.kernels.size());
     if (!rc) {
         hipError_t er = hipEventRecord(e.ev[1], e.stream);
         if (er != hipSuccess) rc = fail(LCCRF_E_HIP, "hipEventRecord: %s", hipGetErrorString(er));

@@ -15,6 +15,7 @@
 //   buildMap               densecrf3d.h:136-151          -> k_map
 #include "engine.h"
 #include "device_math.h"
+#include "lattice_device.h"
 
 namespace lccrf {
 
@@ -61,17 +62,6 @@ __global__ void __launch_bounds__(kBlock) k_points(KernelDev kd, const int *__re
     for (int i = 0; i < D; ++i) { r0p[i] = r0[i]; rkp[i] = rk[i]; }
 #pragma unroll
     for (int i = 0; i < D1; ++i) bp[i] = b[i];
-}
-
-template <int D>
-__device__ __forceinline__ void load_entry_key(const KernelDev &kd, int f, int e, int16_t (&key)[D])
-{
-    constexpr int D1 = D + 1;
-    const int pt = e / D1, rem = e - pt * D1;
-    const int16_t *r0 = kd.rem0 + ((size_t)f * kd.maxNpad + pt) * D;
-    const uint8_t *rk = kd.rank + ((size_t)f * kd.maxNpad + pt) * D;
-#pragma unroll
-    for (int i = 0; i < D; ++i) key[i] = vertex_coord<D>(r0[i], rk[i], rem);
 }
 
 // One thread per entry: insert its vertex key into the frame's hash table.  A slot ends up
