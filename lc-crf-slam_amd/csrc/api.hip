@@ -274,9 +274,10 @@ struct Engine {
         int k = k0;
         while (k < k0 + n) {
             int m = 1;
-            if (!no_small && k + 1 < k0 + n && build_small_supported(&kdevs[k], 2)) m = 2;
-            if (!no_small && build_small_supported(&kdevs[k], m)) {
-                launch_build_small(&kdevs[k], m, crf, stream);
+            const int NA = activeN > 0 ? activeN : maxN;
+            if (!no_small && k + 1 < k0 + n && build_small_supported(&kdevs[k], 2, NA)) m = 2;
+            if (!no_small && build_small_supported(&kdevs[k], m, NA)) {
+                launch_build_small(&kdevs[k], m, NA, crf, stream);
             } else {
                 m = 1;
                 launch_build_kernel(kdevs[k], crf, kernels[k].maxV, stream);

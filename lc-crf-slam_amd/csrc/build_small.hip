@@ -16,10 +16,18 @@
 #include "lattice_device.h"
 
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 
 namespace lccrf {
 
 namespace {
+
+__device__ long long g_build_stamps[32];    // debug: shader-clock stamps of workgroup (0,0) (LCCRF_BUILD_TIMING=1)
+#define BSTAMP(i)                                                                              \
+    do {                                                                                       \
+        if (stamps && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_build_stamps[i] = clock64(); \
+    } while (0)
 
 constexpr int kBT = 1024;
 constexpr size_t kBuildLdsLimit = 158 * 1024;   // dynamic part; the kernel also has a few static LDS words
@@ -29,35 +37,44 @@ constexpr size_t kBuildLdsLimit = 158 * 1024;   // dynamic part; the kernel also
 template <typename Get, typename Put>
 __device__ __forceinline__ int block_scan(int n, Get get, Put put)
 {
+    // every lane owns `per` consecutive elements: local sum, one workgroup scan of the 1024
+    // partial sums (wave shuffles + 16 wave totals), then a local running prefix.
     __shared__ int wave_sum[kBT / 64];
-    __shared__ int carry_s;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) carry_s = 0;
-    __syncthreads();
-    for (int base = 0; base < n; base += kBT) {
-        const int i = base + tid;
-        const int x = (i < n) ? get(i) : 0;
-        int incl = x;
+    const int per = (n + kBT - 1) / kBT, base = tid * per;
+    int sum = 0;
+    for (int i = 0; i < per; ++i)
+        if (base + i < n) sum += get(base + i);
+    int incl = sum;
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int y = __shfl_up(incl, o, 64);
-            if (lane >= o) incl += y;
-        }
-        if (lane == 63) wave_sum[wave] = incl;
-        __syncthreads();
-        int wbase = 0;
-        for (int w = 0; w < wave; ++w) wbase += wave_sum[w];
-        const int carry = carry_s;
-        if (i < n) put(i, carry + wbase + incl - x);
-        __syncthreads();
-        if (tid == kBT - 1) carry_s = carry + wbase + incl;
-        __syncthreads();
+    for (int o = 1; o < 64; o <<= 1) {
+        const int y = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += y;
     }
-    return carry_s;
+    __syncthreads();                                      // wave_sum may still be read by a previous scan
+    if (lane == 63) wave_sum[wave] = incl;
+    __syncthreads();
+    int wbase = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < kBT / 64; ++w) {
+        const int x = wave_sum[w];
+        if (w < wave) wbase += x;
+        total += x;
+    }
+    int run = wbase + incl - sum;
+    for (int i = 0; i < per; ++i) {
+        if (base + i < n) {
+            const int x = get(base + i);
+            put(base + i, run);
+            run += x;
+        }
+    }
+    return total;
 }
 
 template <int D>
-__global__ void __launch_bounds__(kBT) k_build_small(KernelDev kd0, KernelDev kd1, CrfDev c, int lds_ints)
+__global__ void __launch_bounds__(kBT) k_build_small(KernelDev kd0, KernelDev kd1, CrfDev c, int lds_ints, int hcap,
+                                                    int stamps)
 {
     constexpr int D1 = D + 1;
     extern __shared__ __attribute__((aligned(16))) int lds[];
@@ -67,11 +84,21 @@ __global__ void __launch_bounds__(kBT) k_build_small(KernelDev kd0, KernelDev kd
     const int Npad = (N + 3) & ~3;                       // blocks of four, permutohedral_cpu.h:294 (quirk Q1)
     const int live = Npad * D1, E = N * D1;
     const size_t fe = (size_t)f * kd.Epad, f1 = (size_t)f * (kd.Epad + 1);
-    const unsigned mask = (unsigned)kd.cap - 1u;
+    const unsigned mask = (unsigned)hcap - 1u;          // LDS hash table, sized for the frames' real size
 
+    BSTAMP(0);
     // ---- 0/1: empty hash table; point records (elevate, round, rank, barycentric) ------------
+    // The records (from which every vertex key is recomputed) stay in LDS: key compares during
+    // hash probing are the build's inner loop and must not pay a global-memory round trip each.
     int *slot = lds;
-    for (int i = tid; i < kd.cap; i += kBT) slot[i] = kEmpty;
+    int16_t *r0_s = reinterpret_cast<int16_t *>(lds + lds_ints);            // [Npad*D]
+    uint8_t *rk_s = reinterpret_cast<uint8_t *>(r0_s + (size_t)Npad * D);         // [Npad*D]
+    auto entry_key = [&](int e, int16_t(&key)[D]) {
+        const int pt = e / D1, rem = e - pt * D1;
+#pragma unroll
+        for (int i = 0; i < D; ++i) key[i] = vertex_coord<D>(r0_s[pt * D + i], rk_s[pt * D + i], rem);
+    };
+    for (int i = tid; i < hcap; i += kBT) slot[i] = kEmpty;
     for (int n = tid; n < Npad; n += kBT) {
         float feat[D];
         const float *fp = kd.feat + ((size_t)f * kd.maxN + n) * D;
@@ -81,26 +108,25 @@ __global__ void __launch_bounds__(kBT) k_build_small(KernelDev kd0, KernelDev kd
         uint8_t rk[D];
         float b[D1];
         point_record<D>(feat, kd.scale, kd.inv_dp1, r0, rk, b);
-        int16_t *r0p = kd.rem0 + ((size_t)f * kd.maxNpad + n) * D;
-        uint8_t *rkp = kd.rank + ((size_t)f * kd.maxNpad + n) * D;
         float *bp = kd.bary + fe + (size_t)n * D1;
 #pragma unroll
-        for (int i = 0; i < D; ++i) { r0p[i] = r0[i]; rkp[i] = rk[i]; }
+        for (int i = 0; i < D; ++i) { r0_s[n * D + i] = r0[i]; rk_s[n * D + i] = rk[i]; }
 #pragma unroll
         for (int i = 0; i < D1; ++i) bp[i] = b[i];
     }
     __syncthreads();
+    BSTAMP(1);
 
     // ---- 2: insert every entry's vertex key; a slot keeps the LOWEST entry id with that key ----
     for (int e = tid; e < live; e += kBT) {
         int16_t key[D];
-        load_entry_key<D>(kd, f, e, key);
+        entry_key(e, key);
         unsigned h = hash_key<D>(key) & mask;
         for (;;) {
             const int prev = atomicCAS(&slot[h], kEmpty, e);
             if (prev == kEmpty || prev == e) break;
             int16_t other[D];
-            load_entry_key<D>(kd, f, prev, other);
+            entry_key(prev, other);
             bool same = true;
 #pragma unroll
             for (int i = 0; i < D; ++i) same &= (other[i] == key[i]);
@@ -110,6 +136,7 @@ __global__ void __launch_bounds__(kBT) k_build_small(KernelDev kd0, KernelDev kd
         kd.slot_of[fe + e] = (int)h;
     }
     __syncthreads();
+    BSTAMP(2);
 
     // ---- 3: dense vertex ids = exclusive scan of "first occurrence" flags in entry order -----
     int *prefix = kd.prefix + f1;
@@ -117,6 +144,7 @@ __global__ void __launch_bounds__(kBT) k_build_small(KernelDev kd0, KernelDev kd
         live, [&](int e) { return (int)(slot[kd.slot_of[fe + e]] == e); }, [&](int e, int x) { prefix[e] = x; });
     if (tid == 0) kd.V[f] = V;
     __syncthreads();
+    BSTAMP(3);
 
     // ---- 4: offset[e] = id of e's vertex; first entries register as representatives ------------
     for (int e = tid; e < live; e += kBT) {
@@ -126,12 +154,13 @@ __global__ void __launch_bounds__(kBT) k_build_small(KernelDev kd0, KernelDev kd
         if (r == e) kd.rep[fe + id] = e;
     }
     __syncthreads();
+    BSTAMP(4);
 
     // ---- 5: blur neighbours of every (axis, vertex), permutohedral_cpu.h:408-421 ----------------
     for (int idx = tid; idx < V * D1; idx += kBT) {
         const int j = idx / V, v = idx - j * V;
         int16_t key[D], n1[D], n2[D];
-        load_entry_key<D>(kd, f, kd.rep[fe + v], key);
+        entry_key(kd.rep[fe + v], key);
 #pragma unroll
         for (int t = 0; t < D; ++t) {
             n1[t] = (int16_t)(key[t] - 1);
@@ -149,7 +178,7 @@ __global__ void __launch_bounds__(kBT) k_build_small(KernelDev kd0, KernelDev kd
                 const int e = slot[h];
                 if (e == kEmpty) break;
                 int16_t other[D];
-                load_entry_key<D>(kd, f, e, other);
+                entry_key(e, other);
                 bool same = true;
 #pragma unroll
                 for (int i = 0; i < D; ++i) same &= (other[i] == q[i]);
@@ -161,6 +190,7 @@ __global__ void __launch_bounds__(kBT) k_build_small(KernelDev kd0, KernelDev kd
         reinterpret_cast<int2 *>(kd.nbr)[((size_t)f * D1 + j) * kd.Epad + v] = r;
     }
     __syncthreads();                                      // the hash table is dead from here on
+    BSTAMP(5);
 
     // ---- 6-8: CSR of splat contributions, rows ordered by point (LDS counters, no global atomics)
     int *rowstart = lds;                                  // [V+1]
@@ -181,25 +211,43 @@ __global__ void __launch_bounds__(kBT) k_build_small(KernelDev kd0, KernelDev kd
     }
     for (int v = tid; v < V; v += kBT) atomicMax(&rowmax_s, rowstart[v + 1] - rowstart[v]);
     __syncthreads();
+    BSTAMP(6);
+    float *wsorted = reinterpret_cast<float *>(lds + lds_ints);                  // [E] weights in CSR order
     for (int p = tid; p < E; p += kBT) {
         const int e = unsorted[p];
         const int v = kd.offset[fe + e];
         const int s = rowstart[v], t = rowstart[v + 1];
-        int rank = 0;
-        for (int q = s; q < t; ++q) rank += (unsorted[q] < e);
+        int rank = 0, q = s;                               // rank of e inside its row, 4 compares per LDS read
+        for (; q < t && (q & 3); ++q) rank += (unsorted[q] < e);
+        for (; q + 4 <= t; q += 4) {
+            const int4 u = *reinterpret_cast<const int4 *>(unsorted + q);
+            rank += (u.x < e) + (u.y < e) + (u.z < e) + (u.w < e);
+        }
+        for (; q < t; ++q) rank += (unsorted[q] < e);
+        const float w = kd.bary[fe + e];
         kd.csr_pt[fe + s + rank] = e / D1;
-        kd.csr_w[fe + s + rank] = kd.bary[fe + e];
+        kd.csr_w[fe + s + rank] = w;
+        wsorted[s + rank] = w;
     }
     if (tid == 0) kd.rowmax[f] = rowmax_s;
     __syncthreads();
+    BSTAMP(7);
 
     // ---- 9: norm = 1 / (compute(ones) + 1e-20), pairwise3d.h:22-27; lattice values in LDS -------
     float *val = reinterpret_cast<float *>(cnt);          // [V+1], slot 0 = absent neighbour
     float *nxt = reinterpret_cast<float *>(unsorted);     // [V+1]
     if (tid == 0) { val[0] = 0.0f; nxt[0] = 0.0f; }
-    for (int v = tid; v < V; v += kBT) {
+    for (int v = tid; v < V; v += kBT) {                  // splat of ones: the row's weights, left to right
         float acc = 0.0f;
-        for (int p = rowstart[v]; p < rowstart[v + 1]; ++p) acc += kd.csr_w[fe + p] * 1.0f;
+        int p = rowstart[v];
+        const int t = rowstart[v + 1];
+        for (; p + 8 <= t; p += 8) {
+            const float x0 = wsorted[p], x1 = wsorted[p + 1], x2 = wsorted[p + 2], x3 = wsorted[p + 3];
+            const float x4 = wsorted[p + 4], x5 = wsorted[p + 5], x6 = wsorted[p + 6], x7 = wsorted[p + 7];
+            acc += x0 * 1.0f; acc += x1 * 1.0f; acc += x2 * 1.0f; acc += x3 * 1.0f;
+            acc += x4 * 1.0f; acc += x5 * 1.0f; acc += x6 * 1.0f; acc += x7 * 1.0f;
+        }
+        for (; p < t; ++p) acc += wsorted[p] * 1.0f;
         val[v + 1] = acc;
     }
     __syncthreads();
@@ -219,28 +267,40 @@ __global__ void __launch_bounds__(kBT) k_build_small(KernelDev kd0, KernelDev kd
             t += (kd.bary[fe + (size_t)i * D1 + j] * kd.alpha) * val[kd.offset[fe + (size_t)i * D1 + j] + 1];
         kd.norm[(size_t)f * kd.maxN + i] = 1.0f / (t + 1e-20f);
     }
+    BSTAMP(8);
 }
 
-size_t build_small_lds(const KernelDev &kd)
+// LDS plan for frames of at most NA points: hash table (load factor <= 2/3), later reused for the
+// CSR counters / row starts / unsorted rows and the normalisation's values; then the point records.
+struct SmallPlan { int hcap, ints; size_t bytes; };
+SmallPlan small_plan(const KernelDev &kd, int NA)
 {
-    const size_t ints = std::max<size_t>((size_t)kd.cap, 3 * ((size_t)kd.Epad + 2));
-    return ints * sizeof(int);
+    const long live = (long)((NA + 3) & ~3) * kd.D1;
+    SmallPlan p;
+    p.hcap = 1024;
+    while (p.hcap < live + live / 2) p.hcap <<= 1;
+    p.ints = (int)((std::max<long>(p.hcap, 3 * (live + 2)) + 3) & ~3L);
+    // after the ints: the point records (dead once the neighbours are known), overlaid later by the
+    // E sorted weights of the normalisation's splat
+    p.bytes = (size_t)p.ints * sizeof(int) + std::max<size_t>((size_t)((NA + 3) & ~3) * kd.d * 3 + 16, (size_t)live * sizeof(float));
+    return p;
 }
 
 }  // namespace
 
 // Can kernels kds[0..n) (same d) of this batch be built by the fused kernel?
-bool build_small_supported(const KernelDev *kds, int n)
+bool build_small_supported(const KernelDev *kds, int n, int NA)
 {
-    if (n < 1 || n > 2) return false;
+    if (n < 1 || n > 2 || NA < 0) return false;
     for (int k = 0; k < n; ++k)
-        if (kds[k].d != kds[0].d || kds[k].d > 3 || build_small_lds(kds[k]) > kBuildLdsLimit) return false;
+        if (kds[k].d != kds[0].d || kds[k].d > 3 || small_plan(kds[k], NA).bytes > kBuildLdsLimit) return false;
     return true;
 }
 
-void launch_build_small(const KernelDev *kds, int n, const CrfDev &c, hipStream_t s)
+void launch_build_small(const KernelDev *kds, int n, int NA, const CrfDev &c, hipStream_t s)
 {
-    const size_t lds = std::max(build_small_lds(kds[0]), build_small_lds(kds[n - 1]));
+    const SmallPlan p = small_plan(kds[0], NA);          // same d and same capacities for all n
+    static const bool want_stamps = getenv("LCCRF_BUILD_TIMING") != nullptr;
     const dim3 grid(c.F, n);
     const KernelDev &k0 = kds[0], &k1 = kds[n - 1];
 #define BUILD_CASE(DD)                                                                                  \
@@ -248,7 +308,7 @@ void launch_build_small(const KernelDev *kds, int n, const CrfDev &c, hipStream_
         auto fn = k_build_small<DD>;                                                                    \
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fn),                                  \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBuildLdsLimit);     \
-        fn<<<grid, dim3(kBT), lds, s>>>(k0, k1, c, (int)(lds / sizeof(int)));                           \
+        fn<<<grid, dim3(kBT), p.bytes, s>>>(k0, k1, c, p.ints, p.hcap, (int)want_stamps);                \
     } break;
     switch (kds[0].d) {
         BUILD_CASE(1)
@@ -257,6 +317,14 @@ void launch_build_small(const KernelDev *kds, int n, const CrfDev &c, hipStream_
     default: break;
     }
 #undef BUILD_CASE
+    if (want_stamps) {
+        long long h[32];
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_build_stamps), sizeof(h));
+        fprintf(stderr, "[lccrf build timing] lds=%zu B hcap=%d; phase deltas (shader clocks):", p.bytes, p.hcap);
+        for (int i = 1; i <= 8; ++i) fprintf(stderr, " %lld", h[i] - h[i - 1]);
+        fprintf(stderr, "\n");
+    }
 }
 
 }  // namespace lccrf

@@ -74,8 +74,8 @@ void launch_step_stream(const CrfDev &c, const KernelDev *kds, const int *maxV, 
 void launch_map(const CrfDev &c, hipStream_t s);
 
 // ---- fused build (SLAM sizes; one workgroup per (frame, kernel), hash table in LDS) ------
-bool build_small_supported(const KernelDev *kds, int n);
-void launch_build_small(const KernelDev *kds, int n, const CrfDev &c, hipStream_t s);
+bool build_small_supported(const KernelDev *kds, int n, int max_points);
+void launch_build_small(const KernelDev *kds, int n, int max_points, const CrfDev &c, hipStream_t s);
 
 // ---- fused engine (SLAM sizes; one workgroup per frame, lattice values in LDS) --------
 bool fused_supported(const CrfDev &c, const KernelDev *kds, const int *maxV, const int *maxRow,
