@@ -202,9 +202,11 @@ __global__ void __launch_bounds__(kBT) k_build_small(KernelDev kd0, KernelDev kd
     __syncthreads();
     for (int e = tid; e < E; e += kBT) atomicAdd(&cnt[kd.offset[fe + e]], 1);      // real points only
     __syncthreads();
+    BSTAMP(9);
     int *rowptr = kd.rowptr + f1;
     block_scan(V + 1, [&](int v) { return cnt[v]; }, [&](int v, int x) { rowstart[v] = x; rowptr[v] = x; });
     __syncthreads();
+    BSTAMP(10);
     for (int e = tid; e < E; e += kBT) {
         const int v = kd.offset[fe + e];
         unsorted[rowstart[v] + atomicSub(&cnt[v], 1) - 1] = e;
@@ -323,6 +325,7 @@ void launch_build_small(const KernelDev *kds, int n, int NA, const CrfDev &c, hi
         (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_build_stamps), sizeof(h));
         fprintf(stderr, "[lccrf build timing] lds=%zu B hcap=%d; phase deltas (shader clocks):", p.bytes, p.hcap);
         for (int i = 1; i <= 8; ++i) fprintf(stderr, " %lld", h[i] - h[i - 1]);
+        fprintf(stderr, " | csr: count %lld scan %lld fill %lld", h[9] - h[5], h[10] - h[9], h[6] - h[10]);
         fprintf(stderr, "\n");
     }
 }
