@@ -86,18 +86,25 @@ __global__ void __launch_bounds__(kBT) k_build_small(KernelDev kd0, KernelDev kd
     const size_t fe = (size_t)f * kd.Epad, f1 = (size_t)f * (kd.Epad + 1);
     const unsigned mask = (unsigned)hcap - 1u;          // LDS hash table, sized for the frames' real size
 
-    BSTAMP(0);
-    // ---- 0/1: empty hash table; point records (elevate, round, rank, barycentric) ------------
-    // The records (from which every vertex key is recomputed) stay in LDS: key compares during
-    // hash probing are the build's inner loop and must not pay a global-memory round trip each.
+    // ---- LDS plan (see small_plan): [ints region][tail region] ---------------------------------
+    //   ints region : hash table, later CSR counters / row starts / (unsorted rows | count matrix),
+    //                 later the normalisation's lattice values
+    //   tail region : point records + slot index + vertex-id prefix of every entry (all 16-bit),
+    //                 later the splat weights in CSR order
     int *slot = lds;
-    int16_t *r0_s = reinterpret_cast<int16_t *>(lds + lds_ints);            // [Npad*D]
+    unsigned char *tail = reinterpret_cast<unsigned char *>(lds + lds_ints);
+    int16_t *r0_s = reinterpret_cast<int16_t *>(tail);                            // [Npad*D]
     uint8_t *rk_s = reinterpret_cast<uint8_t *>(r0_s + (size_t)Npad * D);         // [Npad*D]
+    unsigned short *sof = reinterpret_cast<unsigned short *>(tail + (((size_t)Npad * D * 3 + 15) & ~(size_t)15));  // [live] slot -> vertex id
+    unsigned short *pfx = sof + ((live + 7) & ~7);                                // [live+1]
     auto entry_key = [&](int e, int16_t(&key)[D]) {
         const int pt = e / D1, rem = e - pt * D1;
 #pragma unroll
         for (int i = 0; i < D; ++i) key[i] = vertex_coord<D>(r0_s[pt * D + i], rk_s[pt * D + i], rem);
     };
+
+    // ---- 0/1: empty hash table; point records (elevate, round, rank, barycentric) ------------
+    BSTAMP(0);
     for (int i = tid; i < hcap; i += kBT) slot[i] = kEmpty;
     for (int n = tid; n < Npad; n += kBT) {
         float feat[D];
@@ -133,103 +140,183 @@ __global__ void __launch_bounds__(kBT) k_build_small(KernelDev kd0, KernelDev kd
             if (same) { atomicMin(&slot[h], e); break; }
             h = (h + 1u) & mask;
         }
-        kd.slot_of[fe + e] = (int)h;
+        sof[e] = (unsigned short)h;
     }
     __syncthreads();
     BSTAMP(2);
 
     // ---- 3: dense vertex ids = exclusive scan of "first occurrence" flags in entry order -----
-    int *prefix = kd.prefix + f1;
     const int V = block_scan(
-        live, [&](int e) { return (int)(slot[kd.slot_of[fe + e]] == e); }, [&](int e, int x) { prefix[e] = x; });
+        live, [&](int e) { return (int)(slot[sof[e]] == e); }, [&](int e, int x) { pfx[e] = (unsigned short)x; });
     if (tid == 0) kd.V[f] = V;
     __syncthreads();
     BSTAMP(3);
 
-    // ---- 4: offset[e] = id of e's vertex; first entries register as representatives ------------
+    // ---- 4: offset[e] = id of e's vertex (kept in LDS too, over the slot index) ------------------
     for (int e = tid; e < live; e += kBT) {
-        const int r = slot[kd.slot_of[fe + e]];
-        const int id = prefix[r];
+        const int id = pfx[slot[sof[e]]];
         kd.offset[fe + e] = id;
-        if (r == e) kd.rep[fe + id] = e;
+        sof[e] = (unsigned short)id;                      // from here on sof[e] is the vertex id of entry e
     }
-    __syncthreads();
     BSTAMP(4);
 
-    // ---- 5: blur neighbours of every (axis, vertex), permutohedral_cpu.h:408-421 ----------------
-    for (int idx = tid; idx < V * D1; idx += kBT) {
-        const int j = idx / V, v = idx - j * V;
-        int16_t key[D], n1[D], n2[D];
-        entry_key(kd.rep[fe + v], key);
+    // ---- 5: blur neighbours of every (axis, vertex), permutohedral_cpu.h:408-421.  Walk the entries;
+    //         the first entry of a vertex does that vertex's 2(d+1) lookups.
+    for (int e = tid; e < live; e += kBT) {
+        // e is the first entry of its vertex iff the exclusive prefix steps right after it
+        if ((e + 1 < live ? (int)pfx[e + 1] : V) != (int)pfx[e] + 1) continue;
+        int16_t key[D];
+        entry_key(e, key);
+        const int v = pfx[e];
+        for (int j = 0; j < D1; ++j) {
+            int16_t n1[D], n2[D];
 #pragma unroll
-        for (int t = 0; t < D; ++t) {
-            n1[t] = (int16_t)(key[t] - 1);
-            n2[t] = (int16_t)(key[t] + 1);
-        }
-#pragma unroll
-        for (int t = 0; t < D; ++t)
-            if (t == j) { n1[t] = (int16_t)(key[t] + D); n2[t] = (int16_t)(key[t] - D); }
-        int2 r;
-        for (int side = 0; side < 2; ++side) {
-            const int16_t(&q)[D] = side ? n2 : n1;
-            unsigned h = hash_key<D>(q) & mask;
-            int found = -1;
-            for (;;) {
-                const int e = slot[h];
-                if (e == kEmpty) break;
-                int16_t other[D];
-                entry_key(e, other);
-                bool same = true;
-#pragma unroll
-                for (int i = 0; i < D; ++i) same &= (other[i] == q[i]);
-                if (same) { found = prefix[e]; break; }
-                h = (h + 1u) & mask;
+            for (int t = 0; t < D; ++t) {
+                n1[t] = (int16_t)(key[t] - 1);
+                n2[t] = (int16_t)(key[t] + 1);
             }
-            if (side) r.y = found; else r.x = found;
+#pragma unroll
+            for (int t = 0; t < D; ++t)
+                if (t == j) { n1[t] = (int16_t)(key[t] + D); n2[t] = (int16_t)(key[t] - D); }
+            int2 r;
+            for (int side = 0; side < 2; ++side) {
+                const int16_t(&q)[D] = side ? n2 : n1;
+                unsigned h = hash_key<D>(q) & mask;
+                int found = -1;
+                for (;;) {
+                    const int o = slot[h];
+                    if (o == kEmpty) break;
+                    int16_t other[D];
+                    entry_key(o, other);
+                    bool same = true;
+#pragma unroll
+                    for (int i = 0; i < D; ++i) same &= (other[i] == q[i]);
+                    if (same) { found = pfx[o]; break; }
+                    h = (h + 1u) & mask;
+                }
+                if (side) r.y = found; else r.x = found;
+            }
+            reinterpret_cast<int2 *>(kd.nbr)[((size_t)f * D1 + j) * kd.Epad + v] = r;
         }
-        reinterpret_cast<int2 *>(kd.nbr)[((size_t)f * D1 + j) * kd.Epad + v] = r;
     }
-    __syncthreads();                                      // the hash table is dead from here on
+    __syncthreads();                                      // hash table, records and pfx are dead from here on
     BSTAMP(5);
 
-    // ---- 6-8: CSR of splat contributions, rows ordered by point (LDS counters, no global atomics)
-    int *rowstart = lds;                                  // [V+1]
-    int *cnt = lds + (live + 2);                          // [V+1]
-    int *unsorted = lds + 2 * (live + 2);                 // [E]
+    // ---- 6-8: CSR of splat contributions, rows ordered by point (LDS only, no global atomics) ------
+    int *cnt = lds;                                       // [V+1] counters, later each entry's CSR position [E]
+    int *work = lds + (live + 2);                         // [E]: unsorted rows, or the count matrix
+    unsigned short *rowstart = reinterpret_cast<unsigned short *>(lds + (live + 2) + ((E + 3) & ~3));   // [V+1]
     for (int v = tid; v <= V; v += kBT) cnt[v] = 0;
     __shared__ int rowmax_s;
     if (tid == 0) rowmax_s = 0;
     __syncthreads();
-    for (int e = tid; e < E; e += kBT) atomicAdd(&cnt[kd.offset[fe + e]], 1);      // real points only
+    for (int e = tid; e < E; e += kBT) atomicAdd(&cnt[sof[e]], 1);                 // real points only
     __syncthreads();
     BSTAMP(9);
     int *rowptr = kd.rowptr + f1;
-    block_scan(V + 1, [&](int v) { return cnt[v]; }, [&](int v, int x) { rowstart[v] = x; rowptr[v] = x; });
+    block_scan(V + 1, [&](int v) { return cnt[v]; }, [&](int v, int x) { rowstart[v] = (unsigned short)x; rowptr[v] = x; });
     __syncthreads();
     BSTAMP(10);
-    for (int e = tid; e < E; e += kBT) {
-        const int v = kd.offset[fe + e];
-        unsorted[rowstart[v] + atomicSub(&cnt[v], 1) - 1] = e;
-    }
-    for (int v = tid; v < V; v += kBT) atomicMax(&rowmax_s, rowstart[v + 1] - rowstart[v]);
-    __syncthreads();
-    BSTAMP(6);
-    float *wsorted = reinterpret_cast<float *>(lds + lds_ints);                  // [E] weights in CSR order
-    for (int p = tid; p < E; p += kBT) {
-        const int e = unsorted[p];
-        const int v = kd.offset[fe + e];
-        const int s = rowstart[v], t = rowstart[v + 1];
-        int rank = 0, q = s;                               // rank of e inside its row, 4 compares per LDS read
-        for (; q < t && (q & 3); ++q) rank += (unsorted[q] < e);
-        for (; q + 4 <= t; q += 4) {
-            const int4 u = *reinterpret_cast<const int4 *>(unsorted + q);
-            rank += (u.x < e) + (u.y < e) + (u.z < e) + (u.w < e);
+    for (int v = tid; v < V; v += kBT) atomicMax(&rowmax_s, (int)rowstart[v + 1] - (int)rowstart[v]);
+    // sorted weights overlay the (dead) records / slot / prefix arrays
+    float *wsorted = reinterpret_cast<float *>(tail);                            // [E]
+    const int lane = tid & 63, wave = tid >> 6;
+    constexpr int NW = kBT / 64;
+    if (V > 0 && V * NW <= E) {
+        // Few vertices, long rows (the appearance kernel): ONE stable counting pass.  Wavefront w owns
+        // the contiguous entries [w*C, (w+1)*C); mat[w][v] counts its entries per vertex, turned into
+        // each wavefront's first position inside every row; then 64 entries at a time find their rank
+        // among equal-vertex lanes below them with one ballot per vertex-id bit.
+        int *mat = work;                                  // [NW][V]
+        const int C = (E + NW - 1) / NW, e0 = wave * C, e1 = min(E, e0 + C);
+        for (int i = tid; i < NW * V; i += kBT) mat[i] = 0;
+        __syncthreads();
+        for (int e = e0 + lane; e < e1; e += 64) atomicAdd(&mat[wave * V + sof[e]], 1);
+        __syncthreads();
+        for (int v = tid; v < V; v += kBT) {
+            int run = rowstart[v];
+            for (int w = 0; w < NW; ++w) {
+                const int t = mat[w * V + v];
+                mat[w * V + v] = run;
+                run += t;
+            }
         }
-        for (; q < t; ++q) rank += (unsorted[q] < e);
-        const float w = kd.bary[fe + e];
-        kd.csr_pt[fe + s + rank] = e / D1;
-        kd.csr_w[fe + s + rank] = w;
-        wsorted[s + rank] = w;
+        __syncthreads();
+        BSTAMP(6);
+        int nbits = 1;
+        while ((1 << nbits) < V) ++nbits;
+        for (int eb = e0; eb < e1; eb += 64) {
+            const int e = eb + lane;
+            const bool valid = e < e1;
+            const int v = valid ? (int)sof[e] : 0;
+            unsigned long long peers = __ballot(valid);
+            for (int b = 0; b < nbits; ++b) {
+                const unsigned long long bal = __ballot(valid && ((v >> b) & 1));
+                peers &= ((v >> b) & 1) ? bal : ~bal;
+            }
+            const unsigned long long below = peers & ((1ull << lane) - 1ull);
+            int pos = 0;
+            if (valid) pos = mat[wave * V + v] + __popcll(below);
+            __builtin_amdgcn_wave_barrier();              // every lane has read its base before any leader bumps it
+            if (valid && below == 0) mat[wave * V + v] += __popcll(peers);
+            __builtin_amdgcn_wave_barrier();
+            if (valid) cnt[e] = pos;                      // CSR position of entry e
+        }
+    } else {
+        // Many vertices, short rows: scatter, then rank every entry inside its (short) row.
+        int *unsorted = work;
+        for (int e = tid; e < E; e += kBT) {
+            const int v = sof[e];
+            unsorted[rowstart[v] + atomicSub(&cnt[v], 1) - 1] = e;
+        }
+        __syncthreads();
+        BSTAMP(6);
+        for (int p = tid; p < E; p += kBT) {
+            const int e = unsorted[p];
+            const int v = sof[e];
+            const int s = rowstart[v], t = rowstart[v + 1];
+            int rank = 0, q = s;                           // 4 compares per LDS read
+            for (; q < t && (q & 3); ++q) rank += (unsorted[q] < e);
+            for (; q + 4 <= t; q += 4) {
+                const int4 u = *reinterpret_cast<const int4 *>(unsorted + q);
+                rank += (u.x < e) + (u.y < e) + (u.z < e) + (u.w < e);
+            }
+            for (; q < t; ++q) rank += (unsorted[q] < e);
+            cnt[e] = s + rank;                             // (cnt's counters have all run down to zero by now)
+        }
+    }
+    __syncthreads();
+    // scatter (point, weight) to their CSR positions; all of a lane's loads are in flight together
+    {
+        constexpr int kMaxEPT = 12;                       // E <= 12 * 1024 for every frame this kernel accepts
+        float wv[kMaxEPT];
+        int pv[kMaxEPT];
+#pragma unroll
+        for (int u = 0; u < kMaxEPT; ++u) {
+            const int e = tid + u * kBT;
+            wv[u] = (e < E) ? kd.bary[fe + e] : 0.0f;
+            pv[u] = (e < E) ? cnt[e] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < kMaxEPT; ++u) {
+            const int e = tid + u * kBT;
+            if (e < E) {
+                kd.csr_pt[fe + pv[u]] = e / D1;
+                kd.csr_w[fe + pv[u]] = wv[u];
+            }
+        }
+    }
+    __syncthreads();
+    // the normalisation's splat reads the weights in CSR order from LDS (they overlay the dead
+    // records / vertex-id arrays, which the loops above were still reading)
+    {
+        constexpr int kMaxEPT = 12;
+        float wv[kMaxEPT];
+#pragma unroll
+        for (int u = 0; u < kMaxEPT; ++u) wv[u] = (tid + u * kBT < E) ? kd.csr_w[fe + tid + u * kBT] : 0.0f;
+#pragma unroll
+        for (int u = 0; u < kMaxEPT; ++u)
+            if (tid + u * kBT < E) wsorted[tid + u * kBT] = wv[u];
     }
     if (tid == 0) kd.rowmax[f] = rowmax_s;
     __syncthreads();
@@ -237,7 +324,7 @@ __global__ void __launch_bounds__(kBT) k_build_small(KernelDev kd0, KernelDev kd
 
     // ---- 9: norm = 1 / (compute(ones) + 1e-20), pairwise3d.h:22-27; lattice values in LDS -------
     float *val = reinterpret_cast<float *>(cnt);          // [V+1], slot 0 = absent neighbour
-    float *nxt = reinterpret_cast<float *>(unsorted);     // [V+1]
+    float *nxt = reinterpret_cast<float *>(work);         // [V+1]
     if (tid == 0) { val[0] = 0.0f; nxt[0] = 0.0f; }
     for (int v = tid; v < V; v += kBT) {                  // splat of ones: the row's weights, left to right
         float acc = 0.0f;
@@ -281,10 +368,11 @@ SmallPlan small_plan(const KernelDev &kd, int NA)
     SmallPlan p;
     p.hcap = 1024;
     while (p.hcap < live + live / 2) p.hcap <<= 1;
-    p.ints = (int)((std::max<long>(p.hcap, 3 * (live + 2)) + 3) & ~3L);
+    p.ints = (int)((std::max<long>(p.hcap, 2 * (live + 2) + 4 + (live + 4) / 2) + 3) & ~3L);
     // after the ints: the point records (dead once the neighbours are known), overlaid later by the
     // E sorted weights of the normalisation's splat
-    p.bytes = (size_t)p.ints * sizeof(int) + std::max<size_t>((size_t)((NA + 3) & ~3) * kd.d * 3 + 16, (size_t)live * sizeof(float));
+    const size_t rec = (((size_t)((NA + 3) & ~3) * kd.d * 3 + 15) & ~(size_t)15) + (size_t)((live + 7) & ~7) * 2 + (size_t)(live + 8) * 2;
+    p.bytes = (size_t)p.ints * sizeof(int) + std::max<size_t>(rec, (size_t)live * sizeof(float)) + 16;
     return p;
 }
 
@@ -295,7 +383,9 @@ bool build_small_supported(const KernelDev *kds, int n, int NA)
 {
     if (n < 1 || n > 2 || NA < 0) return false;
     for (int k = 0; k < n; ++k)
-        if (kds[k].d != kds[0].d || kds[k].d > 3 || small_plan(kds[k], NA).bytes > kBuildLdsLimit) return false;
+        if (kds[k].d != kds[0].d || kds[k].d > 3 || (long)((NA + 3) & ~3) * kds[k].D1 > 12 * kBT ||
+            small_plan(kds[k], NA).bytes > kBuildLdsLimit)
+            return false;
     return true;
 }
 
