@@ -121,6 +121,7 @@ struct Engine {
     std::vector<KernelDev> kdevs;      // contiguous copy handed to the launchers
     std::vector<int> maxV, maxRow;
     bool unary_set = false, built = false, sizes_known = false, started = false;
+    int built_upto = 0;                // kernels [0, built_upto) have their lattice
     int engine_pref = 0, engine_used = 1;
     size_t fused_lds = 0;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   // build begin/end, inference begin/end
@@ -243,6 +244,7 @@ struct Engine {
         crf.unary = unary_own;
         crf.n_points = npoints_own;
         unary_set = built = sizes_known = started = false;
+        built_upto = 0;
         engine_pref = 0;
         engine_used = 1;
         sync_views();
@@ -270,7 +272,7 @@ struct Engine {
     {
         for (int k = k0; k < k0 + n; ++k) kernels[k].maxV = kernels[k].dev.Epad;
         sync_views();
-        static const bool no_small = getenv("LCCRF_NO_FUSED_BUILD") != nullptr;
+        const bool no_small = getenv("LCCRF_NO_FUSED_BUILD") != nullptr;   // debug / cross-check switch
         int k = k0;
         while (k < k0 + n) {
             int m = 1;
@@ -296,8 +298,20 @@ struct Engine {
     int build_kernel(int k) { return build_kernels(k, 1); }
 
     // After the builds: learn max V per kernel so inference grids are sized to the lattice.
+    // Build every kernel added since the last build (object API: add_pairwise only stages features).
+    int flush_builds()
+    {
+        const int n = (int)kernels.size();
+        if (built_upto >= n) return LCCRF_OK;
+        const int k0 = built_upto;
+        built_upto = n;
+        return build_kernels(k0, n - k0);
+    }
+
     int learn_sizes()
     {
+        int rc0 = flush_builds();
+        if (rc0) return rc0;
         if (sizes_known) return LCCRF_OK;
         HIP_TRY(hipStreamSynchronize(stream));
         for (size_t k = 0; k < kernels.size(); ++k) {
@@ -555,7 +569,11 @@ int lccrf_add_pairwise(lccrf_handle h, const float *features, int d, float w)
         memcpy(ks.feat_stage, features, n * sizeof(float));   // caller may free `features` right away
         HIP_TRY(hipMemcpyAsync(ks.feat_own, ks.feat_stage, n * sizeof(float), hipMemcpyHostToDevice, e.stream));
     }
-    return e.build_kernel(k);
+    // The lattice is built lazily, together with any other pending kernel, by the first call that
+    // needs it (inference, a step, a parity probe): one launch builds all of them side by side.
+    (void)k;
+    e.sizes_known = false;
+    return LCCRF_OK;
 }
 
 int lccrf_add_appearance_kernel(lccrf_handle h, float w, const float *vobserv, const float *verror,
@@ -654,6 +672,7 @@ int lccrf_get_lattice_size(lccrf_handle h, int kernel, int *n_vertices)
     CHECK_H(h);
     CHECK_K(h, kernel);
     if (!n_vertices) return fail(LCCRF_E_INVALID, "n_vertices is NULL");
+    { int rcf = h->eng.flush_builds(); if (rcf) return rcf; }
     HIP_TRY(hipStreamSynchronize(h->eng.stream));
     *n_vertices = h->eng.V_host[(size_t)kernel * h->eng.Fcap];
     return LCCRF_OK;
@@ -664,6 +683,7 @@ int lccrf_get_norm(lccrf_handle h, int kernel, float *norm_out)
     CHECK_H(h);
     CHECK_K(h, kernel);
     if (!norm_out && h->N) return fail(LCCRF_E_INVALID, "norm_out is NULL");
+    { int rcf = h->eng.flush_builds(); if (rcf) return rcf; }
     HIP_TRY(hipStreamSynchronize(h->eng.stream));
     if (h->N) HIP_TRY(hipMemcpy(norm_out, h->eng.kernels[kernel].dev.norm, (size_t)h->N * sizeof(float), hipMemcpyDeviceToHost));
     return LCCRF_OK;
@@ -674,6 +694,7 @@ int lccrf_get_lattice(lccrf_handle h, int kernel, int32_t *offset_out, float *ba
     CHECK_H(h);
     CHECK_K(h, kernel);
     Engine &e = h->eng;
+    { int rcf = e.flush_builds(); if (rcf) return rcf; }
     HIP_TRY(hipStreamSynchronize(e.stream));
     const KernelDev &k = e.kernels[kernel].dev;
     const size_t ne = (size_t)h->N * k.D1;
@@ -814,6 +835,7 @@ int lccrf_batch_build(lccrf_batch_handle b, void *stream)
     HIP_TRY(hipEventRecord(e.ev[0], e.stream));
     int rc = LCCRF_OK;
     if (!e.kernels.empty()) rc = e.build_kernels(0, (int)e.kernels.size());
+    e.built_upto = (int)e.kernels.size();
     if (!rc) {
         hipError_t er = hipEventRecord(e.ev[1], e.stream);
         if (er != hipSuccess) rc = fail(LCCRF_E_HIP, "hipEventRecord: %s", hipGetErrorString(er));

@@ -236,3 +236,61 @@ def test_oversize_frames_fall_back_to_streaming_engine(wl):
     b.set_engine(2)
     with pytest.raises(pkg.LccrfError):
         b.inference(2, True)
+
+
+def test_handle_cache_reuses_resources_across_frame_sizes(po, wl):
+    """The reference builds one DenseCRF3D per frame; destroyed handles are recycled.  A recycled
+    handle must behave like a fresh one for a different N (larger-capacity buffers, stale data)."""
+    pkg.lib().lccrf_trim_cache()
+    for N, seed in ((2000, 1), (500, 2), (1999, 3), (3, 4), (2000, 5)):
+        pb = wl.slam_problem(N, seed=seed)
+        o, h = cc.setup(po.OracleCRF, pb), cc.setup(pkg.DenseCRFHIP, pb)
+        o.inference_native(5, True)
+        h.inference(5, True)
+        assert cc.same_bits(o.probability(), h.probability()), N
+        assert np.array_equal(o.map(), h.map()), N
+        for k in range(2):
+            assert o.kernel(k)["V"] == h.kernel(k)["V"]
+        h.close()
+    assert pkg.lib().lccrf_trim_cache() >= 1
+
+
+@pytest.mark.parametrize("N", [5, 700, 2000, 3000])
+def test_fused_build_equals_streaming_build(po, wl, N):
+    """build_small.hip (one launch) vs the 19-launch streaming build: identical lattices."""
+    pb = wl.slam_problem(N, seed=123)
+    res = {}
+    for mode in ("fused", "streaming"):
+        if mode == "streaming":
+            os.environ["LCCRF_NO_FUSED_BUILD"] = "1"
+        try:
+            h = cc.setup(pkg.DenseCRFHIP, pb)
+            res[mode] = [h.kernel(k) for k in range(2)]
+            h.inference(3, True)
+            res[mode].append(h.probability())
+            h.close()
+        finally:
+            os.environ.pop("LCCRF_NO_FUSED_BUILD", None)
+    for k in range(2):
+        a, b = res["fused"][k], res["streaming"][k]
+        assert a["V"] == b["V"]
+        for name in ("offset", "bary", "nbr", "norm"):
+            assert cc.same_bits(a[name], b[name]), (k, name)
+    assert cc.same_bits(res["fused"][2], res["streaming"][2])
+    o = cc.setup(po.OracleCRF, pb)
+    for k in range(2):
+        ko = o.kernel(k)
+        for name in ("offset", "bary", "nbr", "norm"):
+            assert cc.same_bits(ko[name], res["fused"][k][name]), (k, name)
+
+
+def test_step_api_after_deferred_build(po, wl):
+    """add_pairwise only stages features; the first step / probe triggers one joint build."""
+    pb = wl.slam_problem(900, seed=77)
+    o, h = cc.setup(po.OracleCRF, pb), cc.setup(pkg.DenseCRFHIP, pb)
+    h.start_inference()
+    o.start_inference()
+    assert cc.same_bits(o.probability(), h.probability())        # no lattice needed yet
+    h.step_inference()
+    o.step_inference()
+    assert cc.same_bits(o.probability(), h.probability())
