@@ -168,6 +168,41 @@ int  lccrf_batch_get_engine(lccrf_batch_handle b, int *engine_in_use);
  * duration as seen by events around them (0 if not instrumented).                       */
 int  lccrf_batch_last_timing(lccrf_batch_handle b, float *inference_ms, float *build_ms);
 
+/* ======================================================================================
+ * 3. Unary builder -- the step right before the CRF (first "next" row):
+ *    Tracking::ComputeMapPointErrAndObserv (src/Tracking.cc:1803-1839) for every candidate map
+ *    point, then Tracking::RroughClassify (src/Tracking.cc:1961-2013).  The caller flattens the
+ *    MapPoint -> observations -> KeyFrame graph of the frame into a CSR.  PARITY UNPINNED: the
+ *    reference holds no test or fixture for these two functions.
+ * ==================================================================================== */
+typedef struct lccrf_crf_params {           /* Tracking.cc:151-171, Examples/RGB-D/TUM3.yaml:78-101 */
+    float w1, w2;
+    float u_alpha, stdev_alpha;             /* reprojection error mean / stdev            */
+    float u_beta, stdev_beta;               /* observation count mean / stdev             */
+    float u_gamma, stdev_gamma;             /* epipolar prior (read by the reference, unused here) */
+    float point3d_stdev, point2d_stdev;
+    float u_depth, pth, confidence;
+} lccrf_crf_params;
+
+void lccrf_default_params(lccrf_crf_params *p);       /* the TUM3.yaml / BONN.yaml values */
+
+/* Host arrays in, host arrays out.
+ *   Xw        [n_points][3]   MapPoint::GetWorldPos()
+ *   obs_ptr   [n_points+1]    observations of point i are obs_*[obs_ptr[i] .. obs_ptr[i+1])
+ *   obs_kf    [n_obs]         index of the observing keyframe
+ *   obs_kp    [n_obs][2]      pKF->mvKeysUn[fid].pt as doubles (Point2d, Tracking.cc:1832)
+ *   kf_pose   [n_kf][12]      row-major 3x4 [Rcw | tcw];  kf_intr [n_kf][4] fx fy cx cy;
+ *   kf_bounds [n_kf][4]       mnMinX mnMaxX mnMinY mnMaxY
+ *   match_prob[n_points]      mvFeatureMatchProb per candidate, or NULL if that map is empty
+ * Outputs (each [n_points]): observation count (as float, like the reference's vector<float>),
+ * mean reprojection error, mean depth, rough label (0 moving, 1 static, -1 for a point without
+ * observations, which the reference drops at Tracking.cc:1858).                              */
+int  lccrf_unary_build(int device_id, int n_points, const float *Xw, const int32_t *obs_ptr,
+                       const int32_t *obs_kf, const double *obs_kp, int n_kf, const float *kf_pose,
+                       const float *kf_intr, const float *kf_bounds, const double *match_prob,
+                       const lccrf_crf_params *params, float *observs_out, float *error_out,
+                       float *depth_out, int16_t *label_out);
+
 #ifdef __cplusplus
 }
 #endif

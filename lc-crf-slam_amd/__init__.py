@@ -36,6 +36,13 @@ class LccrfError(RuntimeError):
         self.code = code
 
 
+class CrfParams(C.Structure):
+    """lccrf_crf_params: the CRF block of TUM3.yaml (Tracking.cc:151-171)."""
+    _fields_ = [(n, C.c_float) for n in (
+        "w1", "w2", "u_alpha", "stdev_alpha", "u_beta", "stdev_beta", "u_gamma", "stdev_gamma",
+        "point3d_stdev", "point2d_stdev", "u_depth", "pth", "confidence")]
+
+
 class BatchDesc(C.Structure):
     _fields_ = [("max_frames", C.c_int), ("max_points", C.c_int), ("n_labels", C.c_int),
                 ("n_kernels", C.c_int), ("feat_dims", C.c_int * MAX_KERNELS),
@@ -100,6 +107,11 @@ def lib():
     L.lccrf_batch_set_engine.argtypes = [vp, C.c_int]
     L.lccrf_batch_get_engine.argtypes = [vp, C.POINTER(C.c_int)]
     L.lccrf_batch_last_timing.argtypes = [vp, _f32p, _f32p]
+    L.lccrf_default_params.argtypes = [C.POINTER(CrfParams)]
+    L.lccrf_default_params.restype = None
+    L.lccrf_unary_build.argtypes = [C.c_int, C.c_int, _f32p, _i32p, _i32p, C.POINTER(C.c_double), C.c_int, _f32p,
+                                    _f32p, _f32p, C.POINTER(C.c_double), C.POINTER(CrfParams), _f32p, _f32p, _f32p,
+                                    _i16p]
     _lib = L
     return L
 
@@ -325,3 +337,33 @@ class BatchCRF:
         a, b = C.c_float(0), C.c_float(0)
         _check(lib().lccrf_batch_last_timing(self.h, C.byref(a), C.byref(b)))
         return dict(inference_ms=a.value, build_ms=b.value)
+
+
+def default_params():
+    p = CrfParams()
+    lib().lccrf_default_params(C.byref(p))
+    return p
+
+
+def unary_build(Xw, obs_ptr, obs_kf, obs_kp, kf_pose, kf_intr, kf_bounds, match_prob=None, params=None, device=0):
+    """ComputeMapPointErrAndObserv + RroughClassify for a whole frame on the GPU
+    (src/Tracking.cc:1803-1839, 1961-2013; include/lccrf.h section 3)."""
+    if params is None:
+        params = default_params()
+    Xw = _f32(Xw).reshape(-1, 3)
+    n = Xw.shape[0]
+    ptr = np.ascontiguousarray(obs_ptr, np.int32)
+    kf = np.ascontiguousarray(obs_kf, np.int32)
+    kp = np.ascontiguousarray(obs_kp, np.float64).reshape(-1, 2)
+    pose, intr, bnd = _f32(kf_pose).reshape(-1, 12), _f32(kf_intr).reshape(-1, 4), _f32(kf_bounds).reshape(-1, 4)
+    mp = None
+    if match_prob is not None:
+        match_prob = np.ascontiguousarray(match_prob, np.float64)
+        mp = match_prob.ctypes.data_as(C.POINTER(C.c_double))
+    obs, err, dep = (np.empty(n, np.float32) for _ in range(3))
+    lab = np.empty(n, np.int16)
+    _check(lib().lccrf_unary_build(int(device), n, _p(Xw, _f32p), _p(ptr, _i32p), _p(kf, _i32p),
+                                   kp.ctypes.data_as(C.POINTER(C.c_double)), pose.shape[0], _p(pose, _f32p),
+                                   _p(intr, _f32p), _p(bnd, _f32p), mp, C.byref(params), _p(obs, _f32p),
+                                   _p(err, _f32p), _p(dep, _f32p), _p(lab, _i16p)))
+    return obs, err, dep, lab

@@ -946,6 +946,41 @@ int lccrf_batch_get_engine(lccrf_batch_handle b, int *engine_in_use)
     return LCCRF_OK;
 }
 
+void lccrf_default_params(lccrf_crf_params *p)       // Examples/RGB-D/TUM3.yaml:78-101
+{
+    if (!p) return;
+    p->w1 = 10.0f; p->w2 = 30.0f;
+    p->u_alpha = 1.7f; p->stdev_alpha = 0.6f;
+    p->u_beta = 5.4f; p->stdev_beta = 1.5f;
+    p->u_gamma = 0.3f; p->stdev_gamma = 0.2f;
+    p->point3d_stdev = 0.5f; p->point2d_stdev = 18.0f;
+    p->u_depth = 2.75f; p->pth = 0.8f; p->confidence = 0.7f;
+}
+
+int lccrf_unary_build(int device_id, int n_points, const float *Xw, const int32_t *obs_ptr, const int32_t *obs_kf,
+                      const double *obs_kp, int n_kf, const float *kf_pose, const float *kf_intr, const float *kf_bounds,
+                      const double *match_prob, const lccrf_crf_params *params, float *observs_out, float *error_out,
+                      float *depth_out, int16_t *label_out)
+{
+    if (n_points < 0 || n_kf < 0) return fail(LCCRF_E_INVALID, "negative size");
+    if (!params || !obs_ptr) return fail(LCCRF_E_INVALID, "params / obs_ptr is NULL");
+    if (n_points && (!Xw || !observs_out || !error_out || !depth_out || !label_out))
+        return fail(LCCRF_E_INVALID, "NULL array");
+    const int n_obs = n_points ? obs_ptr[n_points] : 0;
+    if (n_obs < 0 || (n_obs && (!obs_kf || !obs_kp || !kf_pose || !kf_intr || !kf_bounds)))
+        return fail(LCCRF_E_INVALID, "observation arrays missing");
+    for (int i = 0; i < n_points; ++i)
+        if (obs_ptr[i + 1] < obs_ptr[i]) return fail(LCCRF_E_INVALID, "obs_ptr not monotone at %d", i);
+    for (int o = 0; o < n_obs; ++o)
+        if (obs_kf[o] < 0 || obs_kf[o] >= n_kf) return fail(LCCRF_E_INVALID, "obs_kf[%d]=%d out of range", o, obs_kf[o]);
+    int rc = use_device(device_id);
+    if (rc) return rc;
+    hipError_t e = run_unary_build(device_id, n_points, Xw, obs_ptr, obs_kf, obs_kp, n_kf, kf_pose, kf_intr, kf_bounds,
+                                   match_prob, params, observs_out, error_out, depth_out, label_out);
+    if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? LCCRF_E_NOMEM : LCCRF_E_HIP, "unary builder: %s", hipGetErrorString(e));
+    return LCCRF_OK;
+}
+
 int lccrf_batch_last_timing(lccrf_batch_handle b, float *inference_ms, float *build_ms)
 {
     CHECK_H(b);

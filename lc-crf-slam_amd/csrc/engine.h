@@ -83,4 +83,10 @@ bool fused_supported(const CrfDev &c, const KernelDev *kds, const int *maxV, con
 void launch_inference_fused(const CrfDev &c, const KernelDev *kds, const int *maxV, const int *maxRow,
                             int n_iter, int with_map, float relax, hipStream_t s);
 
+// ---- unary builder (the step before the CRF) ------------------------
+hipError_t run_unary_build(int device_id, int n_points, const float *Xw, const int32_t *obs_ptr, const int32_t *obs_kf,
+                           const double *obs_kp, int n_kf, const float *kf_pose, const float *kf_intr,
+                           const float *kf_bounds, const double *match_prob, const lccrf_crf_params *params,
+                           float *observs_out, float *error_out, float *depth_out, int16_t *label_out);
+
 }  // namespace lccrf

@@ -106,3 +106,44 @@ def generic_problem(N, d_list, L, seed, spread=4.0, lattice_ties=False):
         kernels.append((f, np.float32(rng.uniform(1.0, 12.0))))
     unary = rng.uniform(0.05, 3.0, (N, L)).astype(np.float32)
     return dict(N=N, L=L, unary=unary, kernels=kernels)
+
+
+def map_point_scene(n_points, n_kf, seed, max_obs=12):
+    """A synthetic local map for the unary builder (Tracking.cc:1803-1839): keyframes on a short arc
+    looking roughly down +z, map points in front of them, each point observed by a random subset of
+    keyframes at its projection plus pixel noise (static points: ~1 px, dynamic ones: several px).
+    Some observations fall behind the camera or outside the image, some points have none."""
+    rng = np.random.default_rng([int(seed), int(n_points), int(n_kf)])
+    fx = fy = np.float32(535.4)
+    cx, cy = np.float32(320.1), np.float32(247.6)
+    poses = np.zeros((n_kf, 3, 4), np.float32)
+    for k in range(n_kf):
+        a = rng.normal(0, 0.08)
+        R = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]])
+        b = rng.normal(0, 0.05)
+        Rx = np.array([[1, 0, 0], [0, np.cos(b), -np.sin(b)], [0, np.sin(b), np.cos(b)]])
+        poses[k, :, :3] = (R @ Rx).astype(np.float32)
+        poses[k, :, 3] = rng.normal(0, 0.3, 3).astype(np.float32)
+    if n_kf:
+        poses[n_kf // 2, 2, 2] *= -1            # one keyframe that sees most points behind it
+    intr = np.tile(np.array([fx, fy, cx, cy], np.float32), (n_kf, 1))
+    bounds = np.tile(np.array([0, 640, 0, 480], np.float32), (n_kf, 1))
+    Xw = np.stack([rng.uniform(-2.5, 2.5, n_points), rng.uniform(-1.8, 1.8, n_points),
+                   rng.uniform(0.6, 6.0, n_points)], 1).astype(np.float32)
+    dyn = rng.random(n_points) < 0.2
+    counts = np.where(dyn, rng.poisson(1.0, n_points), 1 + rng.poisson(5.0, n_points))
+    counts = np.minimum(counts, min(max_obs, n_kf)).astype(np.int32)
+    obs_ptr = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+    obs_kf = np.empty(obs_ptr[-1], np.int32)
+    obs_kp = np.empty((obs_ptr[-1], 2), np.float64)
+    for i in range(n_points):
+        ks = np.sort(rng.choice(n_kf, counts[i], replace=False)) if counts[i] else np.zeros(0, np.int64)
+        obs_kf[obs_ptr[i]:obs_ptr[i + 1]] = ks
+        for j, k in enumerate(ks):
+            xc = poses[k, :, :3].astype(np.float64) @ Xw[i].astype(np.float64) + poses[k, :, 3]
+            z = xc[2] if abs(xc[2]) > 1e-6 else 1e-6
+            u, v = fx * xc[0] / z + cx, fy * xc[1] / z + cy
+            noise = rng.normal(0, 4.5 if dyn[i] else 1.2, 2)
+            obs_kp[obs_ptr[i] + j] = (u + noise[0], v + noise[1])
+    return dict(Xw=Xw, obs_ptr=obs_ptr, obs_kf=obs_kf, obs_kp=obs_kp, kf_pose=poses.reshape(n_kf, 12),
+                kf_intr=intr, kf_bounds=bounds, dynamic=dyn)

@@ -573,10 +573,13 @@ void orc_map_point_err_observ(int n_obs, const float *Xw, const float *poses,
         const float *P = poses + (size_t)o * 12;
         float xc3[3];
         for (int r = 0; r < 3; r++) {
-            /* cv::Mat 3x3 * 3x1 in CV_32F accumulates in double, then + tcw in float */
-            double acc = 0.0;
-            for (int c = 0; c < 3; c++) acc += (double)P[r * 4 + c] * (double)Xw[c];
-            xc3[r] = (float)acc + P[r * 4 + 3];
+            /* `Rcw * x3Dw + tcw` is one cv::gemm(A,B,1,C,1).  Third-party dependency, absent from
+             * /root/reference: OpenCV 3.x (CMakeLists.txt:31), modules/core/src/matmul.cpp, the
+             * small-matrix path taken when 2 <= len <= 4 (here CV_32F, len == 3 == d_size.height,
+             * d_size.width == 1): t = a0*b0 + a1*b1 + a2*b2 in float, d = (float)(t*alpha + c*beta)
+             * with double alpha = beta = 1. */
+            float t = P[r * 4 + 0] * Xw[0] + P[r * 4 + 1] * Xw[1] + P[r * 4 + 2] * Xw[2];
+            xc3[r] = (float)((double)t * 1.0 + (double)P[r * 4 + 3] * 1.0);
         }
         float xc = xc3[0], yc = xc3[1];
         float invzc = (float)(1.0 / (double)xc3[2]);                     /* :1821 */
@@ -593,4 +596,36 @@ void orc_map_point_err_observ(int n_obs, const float *Xw, const float *poses,
     }
     *error = err / (float)n_obs;          /* divides by ALL observations, :1837-1838 */
     *depth = dep / (float)n_obs;
+}
+
+/* Whole-frame form of the two functions above, mirroring lccrf_unary_build's arguments
+ * (include/lccrf.h section 3).  label -1 marks a point without observations, which the
+ * reference drops at src/Tracking.cc:1858. */
+void orc_unary_build(int n_points, const float *Xw, const int32_t *obs_ptr, const int32_t *obs_kf,
+                     const double *obs_kp, const float *kf_pose, const float *kf_intr, const float *kf_bounds,
+                     const double *match_prob, const orc_crf_params *p, float *observs, float *error,
+                     float *depth, int16_t *label)
+{
+    for (int i = 0; i < n_points; i++) {
+        const int o0 = obs_ptr[i], n = obs_ptr[i + 1] - obs_ptr[i];
+        float *poses = (float *)malloc(sizeof(float) * 12 * (size_t)(n > 0 ? n : 1));
+        float *intr = (float *)malloc(sizeof(float) * 4 * (size_t)(n > 0 ? n : 1));
+        float *bnd = (float *)malloc(sizeof(float) * 4 * (size_t)(n > 0 ? n : 1));
+        for (int o = 0; o < n; o++) {
+            const int kf = obs_kf[o0 + o];
+            memcpy(poses + 12 * o, kf_pose + 12 * (size_t)kf, sizeof(float) * 12);
+            memcpy(intr + 4 * o, kf_intr + 4 * (size_t)kf, sizeof(float) * 4);
+            memcpy(bnd + 4 * o, kf_bounds + 4 * (size_t)kf, sizeof(float) * 4);
+        }
+        int nobs = 0;
+        float e = 0, d = 0;
+        orc_map_point_err_observ(n, Xw + 3 * (size_t)i, poses, intr, bnd, obs_kp + 2 * (size_t)o0, &nobs, &e, &d);
+        observs[i] = (float)nobs;
+        error[i] = e;
+        depth[i] = d;
+        const double mp = match_prob ? match_prob[i] : 0.0;
+        orc_rough_classify(1, &observs[i], &error[i], &depth[i], match_prob ? &mp : NULL, p, &label[i]);
+        if (n == 0) label[i] = -1;
+        free(poses); free(intr); free(bnd);
+    }
 }

@@ -115,6 +115,12 @@ void orc_map_point_err_observ(int n_obs, const float *Xw, const float *poses,
                               const double *kp, int *observs, float *error,
                               float *depth);
 
+/* Whole-frame form (arguments as lccrf_unary_build, include/lccrf.h section 3). */
+void orc_unary_build(int n_points, const float *Xw, const int32_t *obs_ptr, const int32_t *obs_kf,
+                     const double *obs_kp, const float *kf_pose, const float *kf_intr, const float *kf_bounds,
+                     const double *match_prob, const orc_crf_params *p, float *observs, float *error,
+                     float *depth, int16_t *label);
+
 #ifdef __cplusplus
 }
 #endif

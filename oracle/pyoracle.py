@@ -96,6 +96,8 @@ def oracle_lib():
         lib.orc_map_point_err_observ.argtypes = [
             C.c_int, _f32p, _f32p, _f32p, _f32p, C.POINTER(C.c_double),
             C.POINTER(C.c_int), _f32p, _f32p]
+        lib.orc_unary_build.argtypes = [C.c_int, _f32p, _i32p, _i32p, C.POINTER(C.c_double), _f32p, _f32p, _f32p,
+                                        C.POINTER(C.c_double), C.POINTER(CrfParams), _f32p, _f32p, _f32p, _i16p]
         _olib = lib
     return _olib
 
@@ -366,3 +368,27 @@ def default_params():
     p = CrfParams()
     oracle_lib().orc_default_params(C.byref(p))
     return p
+
+
+def oracle_unary_build(Xw, obs_ptr, obs_kf, obs_kp, kf_pose, kf_intr, kf_bounds, match_prob=None, params=None):
+    """Whole-frame ComputeMapPointErrAndObserv + RroughClassify (oracle)."""
+    lib = oracle_lib()
+    if params is None:
+        params = default_params()
+    Xw = _f32(Xw).reshape(-1, 3)
+    n = Xw.shape[0]
+    ptr = np.ascontiguousarray(obs_ptr, np.int32)
+    kf = np.ascontiguousarray(obs_kf, np.int32)
+    kp = np.ascontiguousarray(obs_kp, np.float64).reshape(-1, 2)
+    pose, intr, bnd = _f32(kf_pose).reshape(-1, 12), _f32(kf_intr).reshape(-1, 4), _f32(kf_bounds).reshape(-1, 4)
+    mp = None
+    if match_prob is not None:
+        match_prob = np.ascontiguousarray(match_prob, np.float64)
+        mp = match_prob.ctypes.data_as(C.POINTER(C.c_double))
+    obs, err, dep = (np.empty(n, np.float32) for _ in range(3))
+    lab = np.empty(n, np.int16)
+    lib.orc_unary_build(n, _ptr(Xw, _f32p), _ptr(ptr, _i32p), _ptr(kf, _i32p),
+                        kp.ctypes.data_as(C.POINTER(C.c_double)), _ptr(pose, _f32p), _ptr(intr, _f32p),
+                        _ptr(bnd, _f32p), mp, C.byref(params), _ptr(obs, _f32p), _ptr(err, _f32p),
+                        _ptr(dep, _f32p), _ptr(lab, _i16p))
+    return obs, err, dep, lab
