@@ -134,9 +134,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # Rehearsal knobs for a 1-GPU box (scripts/rehearse_multi.sh): every rank on one device and a
+    # backend that tolerates that.  The driver's runs never set them.
+    if "LCCRF_BENCH_DEVICE" in os.environ:
+        local_rank = int(os.environ["LCCRF_BENCH_DEVICE"])
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)   # "nccl" is RCCL on ROCm
+        dist.init_process_group(os.environ.get("LCCRF_BENCH_BACKEND", "nccl"),   # "nccl" is RCCL on ROCm
+                                rank=rank, world_size=world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -180,6 +185,8 @@ def main():
     for _ in range(args.warmup):
         b.inference(n_iter, True)
     b.synchronize()
+    if world > 1:                                   # untimed: RCCL sets its rings up on first use
+        sh.gather_labels(map_view, d_np)
 
     kernel_ms = []
     barrier()

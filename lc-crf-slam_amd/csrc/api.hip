@@ -64,6 +64,11 @@ int use_device(int device_id)
 // Owns every device / pinned allocation of one engine.
 struct Arena {
     std::vector<void *> dev, pinned;
+    // Allocations are zeroed ON THE OWNER'S STREAM.  hipMemset on the null stream is asynchronous
+    // and the engine streams are non-blocking, i.e. unordered with the null stream: a null-stream
+    // memset could land after the first copy into the new buffer (seen as a one-in-hundreds lattice
+    // of all-zero features).
+    hipStream_t stream = nullptr;
     template <typename T>
     int alloc(T **out, size_t count, bool zero = true)
     {
@@ -71,7 +76,10 @@ struct Arena {
         const size_t bytes = (count ? count : 1) * sizeof(T);
         HIP_TRY(hipMalloc(&p, bytes));
         dev.push_back(p);
-        if (zero) HIP_TRY(hipMemset(p, 0, bytes));
+        if (zero) {
+            HIP_TRY(hipMemsetAsync(p, 0, bytes, stream));
+            if (!stream) HIP_TRY(hipStreamSynchronize(nullptr));
+        }
         *out = static_cast<T *>(p);
         return LCCRF_OK;
     }
@@ -135,6 +143,7 @@ struct Engine {
         maxNpad = (max_points + 3) & ~3;
         L = n_labels;
         HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        mem.stream = stream;
         for (auto &e : ev) HIP_TRY(hipEventCreate(&e));
         const size_t nl = (size_t)Fcap * maxN * L;
         int rc;
@@ -219,6 +228,7 @@ struct Engine {
         if ((rc = mem.alloc(&k.rowptr, Fz * (E + 1)))) return rc;
         if ((rc = mem.alloc(&k.csr_pt, Fz * E))) return rc;
         if ((rc = mem.alloc(&k.csr_w, Fz * E))) return rc;
+        if ((rc = mem.alloc(&k.csr_pos, Fz * E))) return rc;
         if ((rc = mem.alloc(&k.norm, Fz * maxN))) return rc;
         if ((rc = mem.alloc(&k.val0, Fz * k.vstride))) return rc;
         if ((rc = mem.alloc(&k.val1, Fz * k.vstride))) return rc;

@@ -303,6 +303,7 @@ __global__ void __launch_bounds__(kBT) k_build_small(KernelDev kd0, KernelDev kd
             if (e < E) {
                 kd.csr_pt[fe + pv[u]] = e / D1;
                 kd.csr_w[fe + pv[u]] = wv[u];
+                kd.csr_pos[fe + e] = pv[u];
             }
         }
     }

@@ -49,6 +49,7 @@ struct KernelDev {
     int *rowptr;          // [F][Epad+1]       CSR: vertex -> range of splat contributions
     int *csr_pt;          // [F][Epad]         contributing point, ascending within a row
     float *csr_w;         // [F][Epad]         its barycentric weight
+    int *csr_pos;         // [F][Epad]         entry -> its position in csr_pt/csr_w (inverse of the row ordering)
     float *norm;          // [F][maxN]         1/(K*1 + 1e-20)  (PottsPotential3D::norm_)
     float *val0, *val1;   // [F][vstride]      lattice values (see vbase)
 };

@@ -20,6 +20,7 @@
 #include "engine.h"
 #include "device_math.h"
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 
@@ -32,14 +33,15 @@ constexpr int kMaxFusedK = 2;
 constexpr size_t kLdsLimit = 160 * 1024;  // MI355X: 160 KiB LDS per CU, one workgroup may own it all
 
 struct FusedLayout {                      // byte offsets into dynamic LDS
-    int q;                                // float2 [Nq]
-    int prod[kMaxFusedK];                 // float  [2][E_k]   (label-major), may alias when !prod_all
-    int val[kMaxFusedK][2];               // float2 [V_k+1]    slot 0 = absent neighbour = 0
-    int nbr[kMaxFusedK];                  // u32    [D1][V_k]  (n1+1) | (n2+1)<<16
+    int zero;                             // 64 bytes of zeros (what a finished chain lane keeps reading)
+    int prod[kMaxFusedK];                 // float  [2][Ecap_k] (label-major), aliased when !prod_all
+    int val[kMaxFusedK][2];               // float2 [V_k+1]     slot 0 = absent neighbour = 0
+    int nbr[kMaxFusedK];                  // u32    [D1][V_k]   (n1+1) | (n2+1)<<16
     int row[kMaxFusedK];                  // u16    [V_k+1]
-    int Ecap[kMaxFusedK];                 // capacity of prod in entries
+    int Ecap[kMaxFusedK];                 // floats per label plane of prod
     int Vcap[kMaxFusedK];
     int prod_all;                         // 1: every kernel has its own product buffer
+    int chain0;                           // 1: kernel 0 has long splat rows, S runs chain_rows on them
     int total;
 };
 
@@ -48,161 +50,377 @@ struct FusedArgs {
     FusedLayout lay;
     int n_iter, with_map;
     float relax;
-    long long *timing;                    // debug: shader-clock stamps of workgroup 0 (LCCRF_FUSED_TIMING=1)
+    long long *timing;                    // debug: shader-clock stamps of one workgroup (LCCRF_FUSED_TIMING=<block index + 1>)
+    int timing_block;
+    int dbg;                              // LCCRF_FUSED_DBG: 1 skip short-row S, 2 skip chain S (timing only, wrong results); 4 poison LDS
 };
 
+#define PSTAMP() do { if (a.dbg & 8) STAMP(); } while (0)   /* prologue breakdown, LCCRF_FUSED_DBG=8 */
+// prologue breakdown: LCCRF_FUSED_DBG=8
+#define PSTAMP()                      \
+    do {                              \
+        if (a.dbg & 8) STAMP();       \
+    } while (0)
 #define STAMP()                                                        \
     do {                                                               \
-        if (a.timing && blockIdx.x == 0 && tid == 0) a.timing[n_stamp++] = clock64(); \
+        if (a.timing && blockIdx.x == a.timing_block && tid == 0) a.timing[n_stamp++] = clock64(); \
     } while (0)
 
-template <int PPT, int K, int D, bool CSR_REG>
+// ---- ordered row sums for kernels with long splat rows -----------------------------------
+// The appearance kernel of a SLAM frame puts ~2000 points on ~120 lattice vertices: a few rows
+// hold 300-600 products that must be added strictly left to right.  The compiler's schedule of
+// that loop (8 ds_read_b32, s_waitcnt 0, 8 adds) runs at ~30 cycles per product; the floor is the
+// dependent v_add_f32 latency, 5.2 cycles.  chain_rows streams a row through a ring of four
+// 8-product units (two ds_read_b128 each): while unit u is added, units u+1..u+3 are in flight,
+// i.e. every load has 24 adds (~125 cycles) to land, which covers the LDS latency even with the
+// bank conflicts of 64 lanes walking 64 different rows.  The loads and the s_waitcnt are issued by
+// hand: the compiler does not see the loads as pending, so it adds no wait of its own, and LDS data
+// returns in order, so lgkmcnt(6) right after a unit was issued means the oldest of the four
+// units in flight has landed.
+// One lane per (vertex,label) row; long rows go to the first wavefronts so that the others retire
+// early.  Rows are padded to 4 products with +0.0f and a lane that has run out of units reads a
+// block of zeros: both are exact, because the accumulator starts at +0 and x + (+0) == x bit for
+// bit for every x != -0, and -0 cannot arise from +0 + ... (x + -x rounds to +0).
+//   addr  LDS byte address of the lane's row (16-byte aligned)    nh    its full 8-product units
+//   tq    1 if a 4-product group follows the units                 wmax  max nh over the wavefront
+//   zaddr LDS byte address of 64 bytes of zeros, >= 128
+typedef float f4_t __attribute__((ext_vector_type(4)));
+
+#define LCCRF_LDS_UNIT(XA, XB, BASE, OFF0, OFF1)                                                     \
+    asm volatile("ds_read_b128 %0, %2 offset:" OFF0 "\n\tds_read_b128 %1, %2 offset:" OFF1           \
+                 : "=&v"(XA), "=&v"(XB) : "v"(BASE) : "memory")
+#define LCCRF_LDS_WAIT(N, XA, XB) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(XA), "+v"(XB) : : "memory")
+#define LCCRF_ADD4(ACC, X) ACC += X.x; ACC += X.y; ACC += X.z; ACC += X.w
+#define LCCRF_ADD8(ACC, XA, XB) LCCRF_ADD4(ACC, XA); LCCRF_ADD4(ACC, XB)
+
+__device__ __forceinline__ float chain_rows(unsigned addr, unsigned nh, unsigned tq, unsigned wmax, unsigned zaddr)
+{
+    float acc = 0.0f;
+    const unsigned tad = tq ? addr + nh * 32u : zaddr;
+    if (wmax != 0) {
+        f4_t R0a, R0b, R1a, R1b, R2a, R2b, R3a, R3b;
+        // unit u of this lane: addr + 32u while u < nh, the zero block afterwards.  `base` is
+        // chosen so that base + immediate offset gives that address.
+        unsigned base = 0 < nh ? addr : zaddr;
+        LCCRF_LDS_UNIT(R0a, R0b, base, "0", "16");
+        base = 1 < nh ? addr : zaddr - 32u;
+        LCCRF_LDS_UNIT(R1a, R1b, base, "32", "48");
+        base = 2 < nh ? addr : zaddr - 64u;
+        LCCRF_LDS_UNIT(R2a, R2b, base, "64", "80");
+        for (unsigned h = 0; h < wmax; h += 4) {
+            base = h + 3 < nh ? addr : zaddr - 96u;
+            LCCRF_LDS_UNIT(R3a, R3b, base, "96", "112");
+            LCCRF_LDS_WAIT(6, R0a, R0b);
+            LCCRF_ADD8(acc, R0a, R0b);
+            addr += 128u;
+            base = h + 4 < nh ? addr : zaddr;
+            LCCRF_LDS_UNIT(R0a, R0b, base, "0", "16");
+            LCCRF_LDS_WAIT(6, R1a, R1b);
+            LCCRF_ADD8(acc, R1a, R1b);
+            base = h + 5 < nh ? addr : zaddr - 32u;
+            LCCRF_LDS_UNIT(R1a, R1b, base, "32", "48");
+            LCCRF_LDS_WAIT(6, R2a, R2b);
+            LCCRF_ADD8(acc, R2a, R2b);
+            base = h + 6 < nh ? addr : zaddr - 64u;
+            LCCRF_LDS_UNIT(R2a, R2b, base, "64", "80");
+            LCCRF_LDS_WAIT(6, R3a, R3b);
+            LCCRF_ADD8(acc, R3a, R3b);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(R0a), "+v"(R0b), "+v"(R1a), "+v"(R1b), "+v"(R2a), "+v"(R2b) : : "memory");   // drain the unused prefetches
+    }
+    f4_t T;                               // the trailing group of four, if any
+    asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(T) : "v"(tad) : "memory");
+    LCCRF_ADD4(acc, T);
+    return acc;
+}
+
+// One workgroup per frame.  Lane t owns points t, t+1024, ... (PPT of them) and keeps everything
+// they need in registers for the whole launch: unary, Q, and per kernel the three vertex ids,
+// barycentric weights, product slots and w*norm.  LDS holds only lattice-side data.
+//   P  every point writes its 3 products bary*Q per kernel into its vertices' rows (slot = the
+//      point's place in the row, ascending point order -- found once per launch)
+//   S  row sums, strictly left to right (chain_rows for a long-row kernel 0: CH = 1)
+//   B  three Jacobi blur passes            X  slice + apply + softmax, all in registers
+template <int PPT, int K, int CH>
 __global__ void __launch_bounds__(kNT) k_fused(CrfDev c, FusedArgs a)
 {
-    constexpr int D1 = D + 1;
-    constexpr int EPT = PPT * D1;         // splat entries per lane and kernel: ceil(N*D1 / kNT)
+    constexpr int D1 = 3;
     int n_stamp = 0;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int f = blockIdx.x;
     const int tid = threadIdx.x;
     const int N = c.n_points[f];
-
-    float2 *Q = reinterpret_cast<float2 *>(smem + a.lay.q);
+    STAMP();
+    if (a.dbg & 4) {                      // debugging aid: NaN-poison the LDS so that reads of unwritten LDS show up
+        for (int i = tid; i < a.lay.total / 4; i += kNT) reinterpret_cast<unsigned *>(smem)[i] = 0x7fc00000u + (unsigned)i;
+        __syncthreads();
+    }
 
     // ---- per-thread point state (registers) ------------------------------------------
     float2 un[PPT], q[PPT];
-    int off[PPT][K][D1];
-    float wgt[PPT][K][D1];
+    unsigned offp[PPT][K][2];             // (id0+1) | (id1+1) << 16,  id2+1     (index into val, 0 = absent)
+    unsigned slp[PPT][K][2];              // slot0 | slot1 << 16,  slot2         (index into prod)
+    float bary[PPT][K][D1];
     float wn[PPT][K];
+    int V[K];
 #pragma unroll
-    for (int s = 0; s < PPT; ++s) {
-        const int i = tid + s * kNT;
-        un[s] = make_float2(0.f, 0.f);
-        q[s] = make_float2(0.f, 0.f);
-        if (i < N) {
-            un[s] = reinterpret_cast<const float2 *>(c.unary)[(size_t)f * c.maxN + i];
-#pragma unroll
-            for (int k = 0; k < K; ++k) {
-                const KernelDev &kd = a.kd[k];
-                const size_t e0 = (size_t)f * kd.Epad + (size_t)i * D1;
-#pragma unroll
-                for (int j = 0; j < D1; ++j) {
-                    off[s][k][j] = kd.offset[e0 + j] + 1;
-                    wgt[s][k][j] = kd.bary[e0 + j] * kd.alpha;            // permutohedral_cpu.h:689
-                }
-                wn[s][k] = kd.w * kd.norm[(size_t)f * kd.maxN + i];      // pairwise3d.h:77 (w_*norm_[i])
-            }
-            // startInference: Q = softmax(-unary), densecrf_base.h:78-80
-            float in[2] = {un[s].x, un[s].y}, out[2] = {0.f, 0.f};
-            exp_and_normalize_reg<2>(in, out, -1.0f, 1.0f);
-            q[s] = make_float2(out[0], out[1]);
-            Q[i] = q[s];
-        }
-    }
+    for (int k = 0; k < K; ++k) V[k] = a.kd[k].V[f];
 
-    // ---- per-frame lattice tables into LDS --------------------------------------------
-    int V[K], E[K];
+    if (N <= 0) return;                   // nothing to infer (and nothing below may index an empty frame)
+
+    // All global loads of the prologue are issued before anything waits on them: the lattice
+    // tables first (their LDS stores come last), then the per-point records.  Indices are clamped
+    // instead of branched on, so that the loads stay back to back.
+    constexpr int kNbrRounds = 4, kRowRounds = 2;         // covers V <= 1365 in registers; larger lattices finish in copy loops
+    int2 g_nbr[K][kNbrRounds];
+    int g_row[K][kRowRounds];
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         const KernelDev &kd = a.kd[k];
-        V[k] = kd.V[f];
-        E[k] = N * D1;
-        unsigned *nbr = reinterpret_cast<unsigned *>(smem + a.lay.nbr[k]);
         const int2 *gn = reinterpret_cast<const int2 *>(kd.nbr) + (size_t)f * D1 * kd.Epad;
-        for (int idx = tid; idx < D1 * V[k]; idx += kNT) {
-            const int j = idx / V[k], v = idx - j * V[k];
-            const int2 n = gn[(size_t)j * kd.Epad + v];
+        const int *gr = kd.rowptr + (size_t)f * (kd.Epad + 1);
+#pragma unroll
+        for (int r = 0; r < kNbrRounds; ++r) {            // element idx = j*V + v, j-major like the LDS copy
+            const int idx = min(tid + r * kNT, D1 * V[k] - 1);
+            const int j = idx >= 2 * V[k] ? 2 : (idx >= V[k] ? 1 : 0);
+            g_nbr[k][r] = gn[(size_t)j * kd.Epad + (idx - j * V[k])];
+        }
+#pragma unroll
+        for (int r = 0; r < kRowRounds; ++r) g_row[k][r] = gr[min(tid + r * kNT, V[k])];
+    }
+    int pos[PPT][K][D1], offs[PPT][K][D1];
+#pragma unroll
+    for (int s = 0; s < PPT; ++s) {
+        const int ic = min(tid + s * kNT, N - 1);
+        un[s] = reinterpret_cast<const float2 *>(c.unary)[(size_t)f * c.maxN + ic];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const KernelDev &kd = a.kd[k];
+            const size_t e0 = (size_t)f * kd.Epad + (size_t)ic * D1;
+#pragma unroll
+            for (int j = 0; j < D1; ++j) {
+                offs[s][k][j] = kd.offset[e0 + j];
+                bary[s][k][j] = kd.bary[e0 + j];
+                pos[s][k][j] = kd.csr_pos[e0 + j];
+            }
+            wn[s][k] = kd.norm[(size_t)f * kd.maxN + ic];
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < PPT; ++s) {
+        q[s] = make_float2(0.f, 0.f);
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            offp[s][k][0] = (unsigned)(offs[s][k][0] + 1) | ((unsigned)(offs[s][k][1] + 1) << 16);
+            offp[s][k][1] = (unsigned)(offs[s][k][2] + 1);
+            slp[s][k][0] = slp[s][k][1] = 0;
+            wn[s][k] = a.kd[k].w * wn[s][k];                              // pairwise3d.h:77 (w_*norm_[i])
+        }
+    }
+    PSTAMP();
+
+    // ---- per-frame lattice tables into LDS --------------------------------------------
+    int *hist = reinterpret_cast<int *>(smem + a.lay.prod[0]);            // chain ranking scratch: [64] counts, [64] bases
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        unsigned *nbr = reinterpret_cast<unsigned *>(smem + a.lay.nbr[k]);
+        unsigned short *row = reinterpret_cast<unsigned short *>(smem + a.lay.row[k]);
+#pragma unroll
+        for (int r = 0; r < kNbrRounds; ++r) {
+            const int idx = tid + r * kNT;
+            if (idx < D1 * V[k]) nbr[idx] = (unsigned)(g_nbr[k][r].x + 1) | ((unsigned)(g_nbr[k][r].y + 1) << 16);
+        }
+#pragma unroll
+        for (int r = 0; r < kRowRounds; ++r)
+            if (tid + r * kNT <= V[k]) row[tid + r * kNT] = (unsigned short)g_row[k][r];
+        // lattices with more vertices than the register rounds cover (sparse frames): plain copy loops
+        const KernelDev &kd = a.kd[k];
+        const int2 *gn = reinterpret_cast<const int2 *>(kd.nbr) + (size_t)f * D1 * kd.Epad;
+        for (int idx = tid + kNbrRounds * kNT; idx < D1 * V[k]; idx += kNT) {
+            const int j = idx >= 2 * V[k] ? 2 : (idx >= V[k] ? 1 : 0);
+            const int2 n = gn[(size_t)j * kd.Epad + (idx - j * V[k])];
             nbr[idx] = (unsigned)(n.x + 1) | ((unsigned)(n.y + 1) << 16);
         }
-        unsigned short *row = reinterpret_cast<unsigned short *>(smem + a.lay.row[k]);
         const int *gr = kd.rowptr + (size_t)f * (kd.Epad + 1);
-        for (int v = tid; v <= V[k]; v += kNT) row[v] = (unsigned short)gr[v];
-        if (tid == 0) {
+        for (int v = tid + kRowRounds * kNT; v <= V[k]; v += kNT) row[v] = (unsigned short)gr[v];
+    }
+    if (tid < 16) reinterpret_cast<float *>(smem + a.lay.zero)[tid] = 0.0f;
+    if (CH && tid < 128) hist[tid] = 0;
+    if (tid == 0) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
             reinterpret_cast<float2 *>(smem + a.lay.val[k][0])[0] = make_float2(0.f, 0.f);
             reinterpret_cast<float2 *>(smem + a.lay.val[k][1])[0] = make_float2(0.f, 0.f);
         }
     }
-    // The splat contributions (CSR order) never change between iterations: when they fit,
-    // each lane keeps its EPT entries per kernel in registers and the loop touches no HBM/L2.
-    float cw_r[CSR_REG ? K : 1][CSR_REG ? EPT : 1];
-    int cp_r[CSR_REG ? K : 1][CSR_REG ? EPT : 1];
-    if constexpr (CSR_REG) {
 #pragma unroll
-        for (int k = 0; k < K; ++k) {
-            const float *cw = a.kd[k].csr_w + (size_t)f * a.kd[k].Epad;
-            const int *cp = a.kd[k].csr_pt + (size_t)f * a.kd[k].Epad;
-#pragma unroll
-            for (int u = 0; u < EPT; ++u) {
-                const int p = tid + u * kNT;
-                cw_r[k][u] = (p < E[k]) ? cw[p] : 0.0f;
-                cp_r[k][u] = (p < E[k]) ? cp[p] : 0;
-            }
+    for (int s = 0; s < PPT; ++s) {                       // startInference: Q = softmax(-unary), densecrf_base.h:78-80
+        if (tid + s * kNT < N) {
+            float in[2] = {un[s].x, un[s].y}, out[2] = {0.f, 0.f};
+            exp_and_normalize_reg<2>(in, out, -1.0f, 1.0f);
+            q[s] = make_float2(out[0], out[1]);
         }
     }
     __syncthreads();
+    PSTAMP();
+
+    // ---- where does each of my products go?  (once per launch) -----------------------
+    // The build recorded the place of entry (i, j) in its vertex's row (ascending point order,
+    // the reference's splat order).  A plain kernel stores its products at exactly that CSR
+    // position.  The chain kernel re-places row v at pst(v) = ceil4(row[v] + 3v): starts are
+    // multiples of 4 and consecutive rows cannot overlap (pst(v+1) - pst(v) is a multiple of 4
+    // that is >= the row's length), so every row is padded to 4 products without any scan.
+    auto pst = [](int r0, int v) { return (r0 + 3 * v + 3) & ~3; };
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const unsigned short *row = reinterpret_cast<const unsigned short *>(smem + a.lay.row[k]);
+#pragma unroll
+        for (int s = 0; s < PPT; ++s) {
+            if (tid + s * kNT < N) {
+                unsigned sl[D1];
+#pragma unroll
+                for (int j = 0; j < D1; ++j) {
+                    sl[j] = (unsigned)pos[s][k][j];
+                    if ((CH >> k) & 1) {
+                        const int v = (int)((j == 0) ? (offp[s][k][0] & 0xffffu) : (j == 1) ? (offp[s][k][0] >> 16) : offp[s][k][1]) - 1;
+                        const int r0 = row[v];
+                        sl[j] = (unsigned)(pst(r0, v) + (pos[s][k][j] - r0));
+                    }
+                }
+                slp[s][k][0] = sl[0] | (sl[1] << 16);
+                slp[s][k][1] = sl[2];
+            }
+        }
+    }
+    // Chain lanes: one lane per (vertex,label) row, long rows first so that whole wavefronts
+    // retire early.  Rank = counting sort on the row's 16-product block count (64 buckets,
+    // longest first; order inside a bucket is whatever the LDS atomics give -- it only decides
+    // which lane sums which row, never the order inside a row).
+    unsigned ch_a = 0, ch_b = 0;          // row address | wavefront max units << 18 ;
+                                          // 8-product units | tail group << 13 | pad slots << 14 | output index << 16
+    if constexpr (CH != 0) {
+        constexpr int k = 0;
+        const unsigned short *row = reinterpret_cast<const unsigned short *>(smem + a.lay.row[k]);
+        unsigned short *srt = reinterpret_cast<unsigned short *>(smem + a.lay.prod[k]) + 256;   // [V] vertex of rank r
+        int key = 0, len = 0;
+        if (tid < V[k]) {
+            len = (int)row[tid + 1] - (int)row[tid];
+            key = 63 - min((len + 3) >> 4, 63);
+            atomicAdd(&hist[key], 1);
+        }
+        __syncthreads();
+        if (tid < 64) {                                   // exclusive scan of the 64 bucket counts
+            const int x = hist[tid];
+            int incl = x;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int y = __shfl_up(incl, o, 64);
+                if (tid >= o) incl += y;
+            }
+            hist[64 + tid] = incl - x;
+        }
+        __syncthreads();
+        if (tid < V[k]) srt[atomicAdd(&hist[64 + key], 1)] = (unsigned short)tid;
+        __syncthreads();
+        // wavefront w owns label (w & 1) of the rows ranked 64*(w >> 1) .. +63: the two longest-row
+        // wavefronts are 0 and 1, and a wavefront reads one label plane only
+        const int Vr = (V[k] + 63) & ~63;
+        const int l = (tid >> 6) & 1, r = ((tid >> 7) << 6) | (tid & 63);
+        unsigned nblk = 0, addr = 0;
+        if (tid < 2 * Vr && r < V[k]) {
+            const int v = srt[r];
+            const int r0 = row[v], rl = (int)row[v + 1] - r0, len4 = (rl + 3) & ~3;
+            addr = (unsigned)(a.lay.prod[k] + 4 * (l * a.lay.Ecap[k] + pst(r0, v)));               // < 2^18
+            nblk = (unsigned)(len4 >> 3);                                                          // 8-product units, < 2^13
+            ch_b = nblk | ((unsigned)((len4 >> 2) & 1) << 13) | ((unsigned)(len4 - rl) << 14) |
+                   ((unsigned)((v + 1) * 2 + l) << 16);
+        }
+        unsigned m = nblk;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+        ch_a = addr | (m << 18);
+        __syncthreads();                  // the ranking scratch becomes the product buffer
+    }
     STAMP();
 
     for (int it = 0; it < a.n_iter; ++it) {
+        // The packed ids / slots and the weights are loop invariants.  Left alone, the compiler
+        // hoists every LDS address and every bary*alpha out of the loop, which costs ~50 more live
+        // registers than the 128 a 1024-lane workgroup has, and spills.  Make them opaque per trip.
+#pragma unroll
+        for (int s = 0; s < PPT; ++s) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                asm volatile("" : "+v"(slp[s][k][0]), "+v"(slp[s][k][1]), "+v"(offp[s][k][0]), "+v"(offp[s][k][1]));
+                asm volatile("" : "+v"(bary[s][k][0]), "+v"(bary[s][k][1]), "+v"(bary[s][k][2]));
+            }
+        }
         // ---- splat = products (P) + ordered row sums (S) ------------------------------
         auto phase_P = [&](int k) {
-            const KernelDev &kd = a.kd[k];
             float *p0 = reinterpret_cast<float *>(smem + a.lay.prod[k]);
             float *p1 = p0 + a.lay.Ecap[k];
-            if constexpr (CSR_REG) {
-                float2 x[EPT];
+            float2 *p2 = reinterpret_cast<float2 *>(p0);
 #pragma unroll
-                for (int u = 0; u < EPT; ++u) x[u] = Q[cp_r[k][u]];
-#pragma unroll
-                for (int u = 0; u < EPT; ++u) {
-                    const int p = tid + u * kNT;
-                    if (p < E[k]) {
-                        p0[p] = cw_r[k][u] * x[u].x;
-                        p1[p] = cw_r[k][u] * x[u].y;
-                    }
-                }
-            } else {
-                const float *cw = kd.csr_w + (size_t)f * kd.Epad;
-                const int *cp = kd.csr_pt + (size_t)f * kd.Epad;
-#pragma unroll 1
-                for (int u0 = 0; u0 < EPT; u0 += D1) {                  // D1 entries at a time: bounded registers
-                    float w[D1];
-                    int pt[D1];
-#pragma unroll
-                    for (int u = 0; u < D1; ++u) {
-                        const int p = tid + (u0 + u) * kNT;
-                        w[u] = (p < E[k]) ? cw[p] : 0.0f;
-                        pt[u] = (p < E[k]) ? cp[p] : 0;
-                    }
-#pragma unroll
-                    for (int u = 0; u < D1; ++u) {
-                        const int p = tid + (u0 + u) * kNT;
-                        const float2 x = Q[pt[u]];
-                        if (p < E[k]) {
-                            p0[p] = w[u] * x.x;
-                            p1[p] = w[u] * x.y;
-                        }
+            for (int s = 0; s < PPT; ++s) {
+                const int i = tid + s * kNT;
+                if (i < N) {
+                    const unsigned s0 = slp[s][k][0] & 0xffffu, s1 = slp[s][k][0] >> 16, s2 = slp[s][k][1];
+                    if ((CH >> k) & 1) {                                  // chain kernel: one plane per label
+                        p0[s0] = bary[s][k][0] * q[s].x;
+                        p1[s0] = bary[s][k][0] * q[s].y;
+                        p0[s1] = bary[s][k][1] * q[s].x;
+                        p1[s1] = bary[s][k][1] * q[s].y;
+                        p0[s2] = bary[s][k][2] * q[s].x;
+                        p1[s2] = bary[s][k][2] * q[s].y;
+                    } else {                                              // short rows: labels interleaved
+                        p2[s0] = make_float2(bary[s][k][0] * q[s].x, bary[s][k][0] * q[s].y);
+                        p2[s1] = make_float2(bary[s][k][1] * q[s].x, bary[s][k][1] * q[s].y);
+                        p2[s2] = make_float2(bary[s][k][2] * q[s].x, bary[s][k][2] * q[s].y);
                     }
                 }
             }
-        };
-        auto phase_S = [&](int k) {
-            const float *p0 = reinterpret_cast<const float *>(smem + a.lay.prod[k]);
-            const unsigned short *row = reinterpret_cast<const unsigned short *>(smem + a.lay.row[k]);
-            float *val = reinterpret_cast<float *>(smem + a.lay.val[k][0]);
-            for (int idx = tid; idx < 2 * V[k]; idx += kNT) {
-                const int v = idx >> 1, l = idx & 1;
-                const float *pl = p0 + l * a.lay.Ecap[k];
-                const int s = row[v], t = row[v + 1];
-                float acc = 0.0f;
-                int p = s;
-                for (; p + 8 <= t; p += 8) {                            // 8 loads in flight, then
-                    const float x0 = pl[p], x1 = pl[p + 1], x2 = pl[p + 2], x3 = pl[p + 3];
-                    const float x4 = pl[p + 4], x5 = pl[p + 5], x6 = pl[p + 6], x7 = pl[p + 7];
-                    acc += x0; acc += x1; acc += x2; acc += x3;         // strictly left to right
-                    acc += x4; acc += x5; acc += x6; acc += x7;
+            if ((CH >> k) & 1) {          // the row's padding (the buffer may have held another kernel's products)
+                const unsigned npad = (ch_b >> 14) & 3u;
+                if (npad) {
+                    float *e = reinterpret_cast<float *>(smem + (ch_a & 0x3ffffu)) + ((ch_b & 0x1fffu) * 8u + ((ch_b >> 13) & 1u) * 4u);
+                    for (unsigned z = 1; z <= npad; ++z) e[-(int)z] = 0.0f;
                 }
-                for (; p < t; ++p) acc += pl[p];
-                val[(v + 1) * 2 + l] = acc;
+            }
+        };
+        // lanes [s_lo, kNT) share the short-row kernels; the wavefront that owns the chain
+        // kernel's longest rows keeps out of them
+        auto phase_S = [&](int k, int s_lo) {
+            float *val = reinterpret_cast<float *>(smem + a.lay.val[k][0]);
+            if ((CH >> k) & 1) {
+                const int Vr = (V[k] + 63) & ~63;
+                if (tid < 2 * Vr && !(a.dbg & 2)) {                                       // whole wavefronts
+                    PSTAMP();
+                    const float acc = chain_rows(ch_a & 0x3ffffu, ch_b & 0x1fffu, (ch_b >> 13) & 1u,
+                                                 (unsigned)__builtin_amdgcn_readfirstlane((int)(ch_a >> 18)),
+                                                 (unsigned)a.lay.zero);
+                    if ((ch_b >> 16) != 0) val[ch_b >> 16] = acc;
+                    PSTAMP();
+                }
+                return;
+            }
+            // short rows: one lane per vertex sums both labels (products are stored label-interleaved),
+            // 8 at a time with all loads issued before the first add; a lane past the end of its row
+            // reads the zero block (x + 0 is exact, see chain_rows)
+            const float2 *pl = reinterpret_cast<const float2 *>(smem + a.lay.prod[k]);
+            const float2 *zero = reinterpret_cast<const float2 *>(smem + a.lay.zero);
+            const unsigned short *row = reinterpret_cast<const unsigned short *>(smem + a.lay.row[k]);
+            if (tid < s_lo || (a.dbg & 1)) return;
+            for (int v = tid - s_lo; v < V[k]; v += kNT - s_lo) {
+                const int t = row[v + 1];
+                float a0 = 0.0f, a1 = 0.0f;
+                for (int p = row[v]; p < t; p += 8) {
+                    float2 x[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) x[u] = *((p + u < t) ? pl + p + u : zero);
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) { a0 += x[u].x; a1 += x[u].y; }   // strictly left to right
+                }
+                reinterpret_cast<float2 *>(val)[v + 1] = make_float2(a0, a1);
             }
         };
         if (a.lay.prod_all) {
@@ -210,8 +428,9 @@ __global__ void __launch_bounds__(kNT) k_fused(CrfDev c, FusedArgs a)
             for (int k = 0; k < K; ++k) phase_P(k);
             __syncthreads();
             STAMP();
+            const int s_lo = (K > 1 && (CH & 1)) ? 128 : 0;
 #pragma unroll
-            for (int k = 0; k < K; ++k) phase_S(k);
+            for (int k = 0; k < K; ++k) phase_S(k, s_lo);                 // the chain kernel is kernel 0: it starts first
             __syncthreads();
             STAMP();
         } else {
@@ -219,7 +438,7 @@ __global__ void __launch_bounds__(kNT) k_fused(CrfDev c, FusedArgs a)
             for (int k = 0; k < K; ++k) {
                 phase_P(k);
                 __syncthreads();
-                phase_S(k);
+                phase_S(k, 0);
                 __syncthreads();
             }
         }
@@ -245,7 +464,8 @@ __global__ void __launch_bounds__(kNT) k_fused(CrfDev c, FusedArgs a)
         }
         STAMP();
 
-        // ---- slice + apply + softmax per point ----------------------------------------
+        // ---- slice + apply + softmax per point (no barrier needed before the next P: it only
+        //      writes the product buffers, whose readers finished two barriers ago) ---------
 #pragma unroll
         for (int s = 0; s < PPT; ++s) {
             const int i = tid + s * kNT;
@@ -254,23 +474,21 @@ __global__ void __launch_bounds__(kNT) k_fused(CrfDev c, FusedArgs a)
 #pragma unroll
                 for (int k = 0; k < K; ++k) {
                     const float2 *val = reinterpret_cast<const float2 *>(smem + a.lay.val[k][D1 & 1]);
+                    const float alpha = a.kd[k].alpha;
+                    const float2 x0 = val[offp[s][k][0] & 0xffffu], x1 = val[offp[s][k][0] >> 16], x2 = val[offp[s][k][1]];
+                    const float w0 = bary[s][k][0] * alpha, w1 = bary[s][k][1] * alpha, w2 = bary[s][k][2] * alpha;   // permutohedral_cpu.h:689
                     float t0 = 0.0f, t1 = 0.0f;
-#pragma unroll
-                    for (int j = 0; j < D1; ++j) {
-                        const float2 x = val[off[s][k][j]];
-                        t0 += wgt[s][k][j] * x.x;
-                        t1 += wgt[s][k][j] * x.y;
-                    }
+                    t0 += w0 * x0.x; t1 += w0 * x0.y;
+                    t0 += w1 * x1.x; t1 += w1 * x1.y;
+                    t0 += w2 * x2.x; t1 += w2 * x2.y;
                     nx[0] += wn[s][k] * t0;                               // pairwise3d.h:77
                     nx[1] += wn[s][k] * t1;
                 }
                 float out[2] = {q[s].x, q[s].y};
                 exp_and_normalize_reg<2>(nx, out, 1.0f, a.relax);
                 q[s] = make_float2(out[0], out[1]);
-                Q[i] = q[s];
             }
         }
-        __syncthreads();
         STAMP();
     }
 
@@ -284,27 +502,36 @@ __global__ void __launch_bounds__(kNT) k_fused(CrfDev c, FusedArgs a)
         }
     }
     STAMP();
-    if (a.timing && blockIdx.x == 0 && tid == 0) a.timing[63] = n_stamp;
+    if (a.timing && blockIdx.x == a.timing_block && tid == 0) a.timing[63] = n_stamp;
 }
 
-bool make_layout(const CrfDev &c, const KernelDev *kds, const int *maxV, FusedLayout *lay)
+constexpr int kChainMinRow = 64;          // kernel 0 runs chain_rows when its longest splat row has at least this many products ...
+constexpr int kChainMaxV = 512;           // ... and it has at most this many vertices (one lane per (vertex,label), ranking is O(V) per lane)
+
+bool make_layout(const CrfDev &c, const KernelDev *kds, const int *maxV, const int *maxRow, FusedLayout *lay)
 {
     if (c.L != 2 || c.K < 1 || c.K > kMaxFusedK) return false;
     const int NA = c.activeN > 0 ? c.activeN : c.maxN;   // size LDS and the points-per-lane variant by the frames' real size
     if (NA < 1 || NA > 4 * kNT) return false;
     for (int k = 0; k < c.K; ++k) {
         if (kds[k].d != kds[0].d || kds[k].d != 2) return false;
-        if (maxV[k] >= 65535 || kds[k].Epad >= 65535) return false;     // u16 row pointers / neighbour ids
+        if (maxV[k] >= 65535 || kds[k].Epad >= 65535) return false;     // u16 row pointers / neighbour ids / slots
     }
-    for (int all = 1; all >= 0; --all) {
+    const int chain0 = maxRow && maxRow[0] >= kChainMinRow && maxV[0] <= kChainMaxV &&
+                       NA * kds[0].D1 + 3 * maxV[0] + 64 < 65535;
+    for (int all = 1; all >= 0; --all) {                  // own product buffers, else one shared buffer
         FusedLayout L{};
         size_t o = 0;
         auto take = [&](size_t bytes) { size_t r = o; o += (bytes + 15) & ~(size_t)15; return (int)r; };
         L.prod_all = all;
-        L.q = take((size_t)NA * sizeof(float2));
+        L.chain0 = chain0;
+        (void)take(128);                                   // chain_rows wants the zero block at an address >= 128
+        L.zero = take(64);
         size_t shared_prod = 0;
         for (int k = 0; k < c.K; ++k) {
-            L.Ecap[k] = NA * kds[k].D1;
+            const int E = NA * kds[k].D1;
+            // chain rows are padded to 4 products; every plane is a multiple of 64 floats
+            L.Ecap[k] = ((k == 0 && chain0 ? E + 3 * maxV[k] : E) + 63) & ~63;
             L.Vcap[k] = maxV[k];
             L.val[k][0] = take((size_t)(maxV[k] + 1) * sizeof(float2));
             L.val[k][1] = take((size_t)(maxV[k] + 1) * sizeof(float2));
@@ -327,32 +554,45 @@ bool make_layout(const CrfDev &c, const KernelDev *kds, const int *maxV, FusedLa
     return false;
 }
 
-template <int PPT, int K>
+template <int PPT, int K, int CH>
 void launch_fused(const CrfDev &c, const FusedArgs &a, hipStream_t s)
 {
-    auto fn = k_fused<PPT, K, 2, (PPT <= 2)>;
+    auto fn = k_fused<PPT, K, CH>;
     // per (function, device); cheap enough to repeat and safe with several devices in one process
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)kLdsLimit);
     fn<<<dim3(c.F), dim3(kNT), a.lay.total, s>>>(c, a);
 }
 
+template <int PPT>
+void launch_fused_ppt(const CrfDev &c, const FusedArgs &a, hipStream_t s)
+{
+    if (c.K == 1) {
+        if (a.lay.chain0) launch_fused<PPT, 1, 1>(c, a, s);
+        else launch_fused<PPT, 1, 0>(c, a, s);
+    } else {
+        if (a.lay.chain0) launch_fused<PPT, 2, 1>(c, a, s);
+        else launch_fused<PPT, 2, 0>(c, a, s);
+    }
+}
+
 }  // namespace
 
-bool fused_supported(const CrfDev &c, const KernelDev *kds, const int *maxV, const int * /*maxRow*/,
-                     size_t *lds_bytes)
+bool fused_supported(const CrfDev &c, const KernelDev *kds, const int *maxV, const int *maxRow, size_t *lds_bytes)
 {
     FusedLayout lay;
-    const bool ok = make_layout(c, kds, maxV, &lay);
+    const bool ok = make_layout(c, kds, maxV, maxRow, &lay);
     if (lds_bytes) *lds_bytes = ok ? (size_t)lay.total : 0;
     return ok;
 }
 
-void launch_inference_fused(const CrfDev &c, const KernelDev *kds, const int *maxV, const int * /*maxRow*/,
-                            int n_iter, int with_map, float relax, hipStream_t s)
+void launch_inference_fused(const CrfDev &c, const KernelDev *kds, const int *maxV, const int *maxRow, int n_iter,
+                            int with_map, float relax, hipStream_t s)
 {
     FusedArgs a{};
-    if (!make_layout(c, kds, maxV, &a.lay)) return;
+    if (!make_layout(c, kds, maxV, maxRow, &a.lay)) return;
+    static const bool no_chain = getenv("LCCRF_NO_CHAIN") != nullptr;     // debugging aid: compiler-scheduled S phase
+    if (no_chain) a.lay.chain0 = 0;                                        // (the padded plane size is harmless)
     for (int k = 0; k < c.K; ++k) a.kd[k] = kds[k];
     a.n_iter = n_iter;
     a.with_map = with_map;
@@ -361,20 +601,18 @@ void launch_inference_fused(const CrfDev &c, const KernelDev *kds, const int *ma
     static const bool want_timing = getenv("LCCRF_FUSED_TIMING") != nullptr;
     if (want_timing && !timing_buf) (void)hipMalloc(&timing_buf, 64 * sizeof(long long));
     a.timing = want_timing ? timing_buf : nullptr;
+    a.timing_block = want_timing ? std::max(atoi(getenv("LCCRF_FUSED_TIMING")) - 1, 0) : 0;
+    if (a.timing_block >= c.F) a.timing_block = 0;
+    static const int dbg = getenv("LCCRF_FUSED_DBG") ? atoi(getenv("LCCRF_FUSED_DBG")) : 0;
+    a.dbg = dbg;
     const int ppt = ((c.activeN > 0 ? c.activeN : c.maxN) + kNT - 1) / kNT;
-#define FUSED_CASE(P)                                            \
-    case P:                                                      \
-        if (c.K == 1) launch_fused<P, 1>(c, a, s);               \
-        else launch_fused<P, 2>(c, a, s);                        \
-        break;
     switch (ppt) {
-        FUSED_CASE(1)
-        FUSED_CASE(2)
-        FUSED_CASE(3)
-        FUSED_CASE(4)
+    case 1: launch_fused_ppt<1>(c, a, s); break;
+    case 2: launch_fused_ppt<2>(c, a, s); break;
+    case 3: launch_fused_ppt<3>(c, a, s); break;
+    case 4: launch_fused_ppt<4>(c, a, s); break;
     default: break;
     }
-#undef FUSED_CASE
     if (a.timing) {                       // debug only: synchronous read-back of workgroup 0's phase stamps
         long long h[64];
         (void)hipStreamSynchronize(s);

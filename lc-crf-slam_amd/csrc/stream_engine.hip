@@ -253,6 +253,7 @@ __global__ void __launch_bounds__(kBlock) k_csr_order(KernelDev kd, const int *_
     for (int q = s; q < t; ++q) rank += (rows[q] < e);
     kd.csr_pt[fe + s + rank] = e / kd.D1;
     kd.csr_w[fe + s + rank] = kd.bary[fe + e];
+    kd.csr_pos[fe + e] = s + rank;
 }
 
 // ---------------------------------------------------------------------------------------

@@ -184,7 +184,7 @@ def test_hip_full_size_properties(wl):
 
 
 @pytest.mark.parametrize("N,n_iter,relax", [(2000, 5, 1.0), (3000, 5, 1.0), (1000, 10, 1.0), (257, 3, 0.5),
-                                             (1, 2, 1.0), (3400, 2, 1.0)])
+                                             (1, 2, 1.0), (3400, 2, 1.0), (4096, 2, 1.0)])
 def test_fused_and_streaming_engines_agree_bitwise(wl, N, n_iter, relax):
     """Engine 2 (one workgroup per frame, LDS) vs engine 1 (streaming kernels)."""
     F = 6
@@ -223,9 +223,9 @@ def test_fused_engine_single_kernel(po, wl):
 
 
 def test_oversize_frames_fall_back_to_streaming_engine(wl):
-    """4096 keypoints do not fit one workgroup's 160 KiB of LDS: automatic engine choice
-    must pick the streaming engine, and forcing the fused one must fail loudly."""
-    N = 4096
+    """More than 4 x 1024 keypoints do not fit the fused engine's one workgroup per frame:
+    automatic engine choice must pick the streaming engine, and forcing the fused one must fail loudly."""
+    N = 4100
     pb = wl.slam_problem(N, seed=3)
     feats = [pb["kernels"][k][0][None] for k in range(2)]
     b = pkg.BatchCRF(1, N, 2, [2, 2], [10.0, 30.0])
