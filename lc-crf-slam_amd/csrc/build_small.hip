@@ -26,10 +26,16 @@ namespace {
 __device__ long long g_build_stamps[32];    // debug: shader-clock stamps of workgroup (0,0) (LCCRF_BUILD_TIMING=1)
 #define BSTAMP(i)                                                                              \
     do {                                                                                       \
-        if (stamps && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_build_stamps[i] = clock64(); \
+        if (stamps && blockIdx.x == 0 && (int)blockIdx.y == stamps - 1 && threadIdx.x == 0) g_build_stamps[i] = clock64(); \
     } while (0)
 
 constexpr int kBT = 1024;
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every global store
+// of the wave to be acknowledged (a full round trip to L2); where the data behind the barrier lives
+// in LDS that wait buys nothing.  Global data written here and read by OTHER lanes later is always
+// separated from its readers by at least one full __syncthreads().
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 constexpr size_t kBuildLdsLimit = 158 * 1024;   // dynamic part; the kernel also has a few static LDS words
 
 // exclusive scan of n values over the whole workgroup; `get(i)` yields the value, `put(i, x)`
@@ -92,6 +98,7 @@ __global__ void __launch_bounds__(kBT) k_build_small(KernelDev kd0, KernelDev kd
     //   tail region : point records + slot index + vertex-id prefix of every entry (all 16-bit),
     //                 later the splat weights in CSR order
     int *slot = lds;
+    unsigned short *rep_s = reinterpret_cast<unsigned short *>(lds + hcap);      // [V] vertex -> its first entry (phases 4-5)
     unsigned char *tail = reinterpret_cast<unsigned char *>(lds + lds_ints);
     int16_t *r0_s = reinterpret_cast<int16_t *>(tail);                            // [Npad*D]
     uint8_t *rk_s = reinterpret_cast<uint8_t *>(r0_s + (size_t)Npad * D);         // [Npad*D]
@@ -106,22 +113,36 @@ __global__ void __launch_bounds__(kBT) k_build_small(KernelDev kd0, KernelDev kd
     // ---- 0/1: empty hash table; point records (elevate, round, rank, barycentric) ------------
     BSTAMP(0);
     for (int i = tid; i < hcap; i += kBT) slot[i] = kEmpty;
-    for (int n = tid; n < Npad; n += kBT) {
-        float feat[D];
-        const float *fp = kd.feat + ((size_t)f * kd.maxN + n) * D;
+    {
+        constexpr int kPR = 12 / D1;                      // point rounds: live <= 12 * 1024
+        float feat[kPR][D];
 #pragma unroll
-        for (int j = 0; j < D; ++j) feat[j] = (n < N) ? fp[j] : 0.0f;      // phantom lanes, :299
-        int16_t r0[D];
-        uint8_t rk[D];
-        float b[D1];
-        point_record<D>(feat, kd.scale, kd.inv_dp1, r0, rk, b);
-        float *bp = kd.bary + fe + (size_t)n * D1;
+        for (int r = 0; r < kPR; ++r) {                   // every round's features requested up front
+            const int n = tid + r * kBT;
+            const float *fp = kd.feat + ((size_t)f * kd.maxN + min(n, max(N - 1, 0))) * D;
 #pragma unroll
-        for (int i = 0; i < D; ++i) { r0_s[n * D + i] = r0[i]; rk_s[n * D + i] = rk[i]; }
+            for (int j = 0; j < D; ++j) feat[r][j] = fp[j];
+        }
 #pragma unroll
-        for (int i = 0; i < D1; ++i) bp[i] = b[i];
+        for (int r = 0; r < kPR; ++r) {
+            const int n = tid + r * kBT;
+            if (n < Npad) {
+                float ft[D];
+#pragma unroll
+                for (int j = 0; j < D; ++j) ft[j] = (n < N) ? feat[r][j] : 0.0f;   // phantom lanes, :299
+                int16_t r0[D];
+                uint8_t rk[D];
+                float b[D1];
+                point_record<D>(ft, kd.scale, kd.inv_dp1, r0, rk, b);
+                float *bp = kd.bary + fe + (size_t)n * D1;
+#pragma unroll
+                for (int i = 0; i < D; ++i) { r0_s[n * D + i] = r0[i]; rk_s[n * D + i] = rk[i]; }
+#pragma unroll
+                for (int i = 0; i < D1; ++i) bp[i] = b[i];
+            }
+        }
     }
-    __syncthreads();
+    lds_barrier();
     BSTAMP(1);
 
     // ---- 2: insert every entry's vertex key; a slot keeps the LOWEST entry id with that key ----
@@ -154,20 +175,21 @@ __global__ void __launch_bounds__(kBT) k_build_small(KernelDev kd0, KernelDev kd
 
     // ---- 4: offset[e] = id of e's vertex (kept in LDS too, over the slot index) ------------------
     for (int e = tid; e < live; e += kBT) {
-        const int id = pfx[slot[sof[e]]];
+        const int first = slot[sof[e]];
+        const int id = pfx[first];
         kd.offset[fe + e] = id;
         sof[e] = (unsigned short)id;                      // from here on sof[e] is the vertex id of entry e
+        if (first == e) rep_s[id] = (unsigned short)e;
     }
+    lds_barrier();
     BSTAMP(4);
 
     // ---- 5: blur neighbours of every (axis, vertex), permutohedral_cpu.h:408-421.  Walk the entries;
-    //         the first entry of a vertex does that vertex's 2(d+1) lookups.
-    for (int e = tid; e < live; e += kBT) {
-        // e is the first entry of its vertex iff the exclusive prefix steps right after it
-        if ((e + 1 < live ? (int)pfx[e + 1] : V) != (int)pfx[e] + 1) continue;
+    //         a vertex's key is rebuilt from its first entry.
+    for (int v = tid; v < V; v += kBT) {                   // one lane per vertex (dense: no idle lanes)
+        const int e = rep_s[v];
         int16_t key[D];
         entry_key(e, key);
-        const int v = pfx[e];
         for (int j = 0; j < D1; ++j) {
             int16_t n1[D], n2[D];
 #pragma unroll
@@ -215,9 +237,15 @@ __global__ void __launch_bounds__(kBT) k_build_small(KernelDev kd0, KernelDev kd
     BSTAMP(9);
     int *rowptr = kd.rowptr + f1;
     block_scan(V + 1, [&](int v) { return cnt[v]; }, [&](int v, int x) { rowstart[v] = (unsigned short)x; rowptr[v] = x; });
-    __syncthreads();
+    lds_barrier();
     BSTAMP(10);
-    for (int v = tid; v < V; v += kBT) atomicMax(&rowmax_s, (int)rowstart[v + 1] - (int)rowstart[v]);
+    {                                                     // longest row: wave maximum first, one LDS atomic per wavefront
+        int m = 0;
+        for (int v = tid; v < V; v += kBT) m = max(m, (int)rowstart[v + 1] - (int)rowstart[v]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o, 64));
+        if ((tid & 63) == 0 && m > 0) atomicMax(&rowmax_s, m);
+    }
     // sorted weights overlay the (dead) records / slot / prefix arrays
     float *wsorted = reinterpret_cast<float *>(tail);                            // [E]
     const int lane = tid & 63, wave = tid >> 6;
@@ -249,16 +277,21 @@ __global__ void __launch_bounds__(kBT) k_build_small(KernelDev kd0, KernelDev kd
             const int e = eb + lane;
             const bool valid = e < e1;
             const int v = valid ? (int)sof[e] : 0;
-            unsigned long long peers = __ballot(valid);
+            // peers = lanes holding the same vertex; 32-bit halves, v_mbcnt for "how many below me"
+            const unsigned long long all = __ballot(valid);
+            unsigned plo = (unsigned)all, phi = (unsigned)(all >> 32);
             for (int b = 0; b < nbits; ++b) {
-                const unsigned long long bal = __ballot(valid && ((v >> b) & 1));
-                peers &= ((v >> b) & 1) ? bal : ~bal;
+                const bool bit = (v >> b) & 1;
+                const unsigned long long bal = __ballot(valid && bit);
+                const unsigned blo = (unsigned)bal, bhi = (unsigned)(bal >> 32);
+                plo &= bit ? blo : ~blo;
+                phi &= bit ? bhi : ~bhi;
             }
-            const unsigned long long below = peers & ((1ull << lane) - 1ull);
+            const int below = (int)__builtin_amdgcn_mbcnt_hi(phi, __builtin_amdgcn_mbcnt_lo(plo, 0u));
             int pos = 0;
-            if (valid) pos = mat[wave * V + v] + __popcll(below);
+            if (valid) pos = mat[wave * V + v] + below;
             __builtin_amdgcn_wave_barrier();              // every lane has read its base before any leader bumps it
-            if (valid && below == 0) mat[wave * V + v] += __popcll(peers);
+            if (valid && below == 0) mat[wave * V + v] += __popc(plo) + __popc(phi);
             __builtin_amdgcn_wave_barrier();
             if (valid) cnt[e] = pos;                      // CSR position of entry e
         }
@@ -286,38 +319,38 @@ __global__ void __launch_bounds__(kBT) k_build_small(KernelDev kd0, KernelDev kd
         }
     }
     __syncthreads();
-    // scatter (point, weight) to their CSR positions; all of a lane's loads are in flight together
+    BSTAMP(11);
+    // scatter (point, weight) to their CSR positions -- in LDS, so that the global copies below are
+    // coalesced (a scattered 4-byte global store touches one cache line per lane).  The sorted
+    // weights overlay the dead records / vertex-id arrays, the sorted points the dead work area.
+    unsigned short *pts = reinterpret_cast<unsigned short *>(work);               // [E]
     {
         constexpr int kMaxEPT = 12;                       // E <= 12 * 1024 for every frame this kernel accepts
         float wv[kMaxEPT];
         int pv[kMaxEPT];
 #pragma unroll
         for (int u = 0; u < kMaxEPT; ++u) {
-            const int e = tid + u * kBT;
-            wv[u] = (e < E) ? kd.bary[fe + e] : 0.0f;
-            pv[u] = (e < E) ? cnt[e] : 0;
+            const int e = min(tid + u * kBT, max(E - 1, 0));
+            wv[u] = kd.bary[fe + e];
+            pv[u] = cnt[e];
         }
+        __syncthreads();                                  // every position is in registers: cnt / work / tail may be overwritten
+        BSTAMP(12);
 #pragma unroll
         for (int u = 0; u < kMaxEPT; ++u) {
             const int e = tid + u * kBT;
             if (e < E) {
-                kd.csr_pt[fe + pv[u]] = e / D1;
-                kd.csr_w[fe + pv[u]] = wv[u];
+                wsorted[pv[u]] = wv[u];
+                pts[pv[u]] = (unsigned short)(e / D1);
                 kd.csr_pos[fe + e] = pv[u];
             }
         }
     }
-    __syncthreads();
-    // the normalisation's splat reads the weights in CSR order from LDS (they overlay the dead
-    // records / vertex-id arrays, which the loops above were still reading)
-    {
-        constexpr int kMaxEPT = 12;
-        float wv[kMaxEPT];
-#pragma unroll
-        for (int u = 0; u < kMaxEPT; ++u) wv[u] = (tid + u * kBT < E) ? kd.csr_w[fe + tid + u * kBT] : 0.0f;
-#pragma unroll
-        for (int u = 0; u < kMaxEPT; ++u)
-            if (tid + u * kBT < E) wsorted[tid + u * kBT] = wv[u];
+    lds_barrier();
+    BSTAMP(13);
+    for (int p = tid; p < E; p += kBT) {
+        kd.csr_pt[fe + p] = pts[p];
+        kd.csr_w[fe + p] = wsorted[p];
     }
     if (tid == 0) kd.rowmax[f] = rowmax_s;
     __syncthreads();
@@ -326,36 +359,69 @@ __global__ void __launch_bounds__(kBT) k_build_small(KernelDev kd0, KernelDev kd
     // ---- 9: norm = 1 / (compute(ones) + 1e-20), pairwise3d.h:22-27; lattice values in LDS -------
     float *val = reinterpret_cast<float *>(cnt);          // [V+1], slot 0 = absent neighbour
     float *nxt = reinterpret_cast<float *>(work);         // [V+1]
-    if (tid == 0) { val[0] = 0.0f; nxt[0] = 0.0f; }
+    if (tid == 0) { val[0] = 0.0f; nxt[0] = 0.0f; }      // (the barrier above: nobody reads pts any more)
+    // what the blur and the slice will need from global memory (this workgroup wrote it earlier) is
+    // requested now, so that it arrives while the rows are summed
+    constexpr int kVR = 2;                                // vertex rounds held in registers (V <= 2048)
+    constexpr int kPR = 12 / D1;                          // point rounds: live <= 12 * 1024
+    const int2 *nbr = reinterpret_cast<const int2 *>(kd.nbr) + (size_t)f * D1 * kd.Epad;
+    int2 nb[D1][kVR];
+#pragma unroll
+    for (int j = 0; j < D1; ++j)
+#pragma unroll
+        for (int r = 0; r < kVR; ++r) nb[j][r] = nbr[(size_t)j * kd.Epad + min(tid + r * kBT, max(V - 1, 0))];
+    float bw[kPR][D1];
+    int bo[kPR][D1];
+#pragma unroll
+    for (int r = 0; r < kPR; ++r) {
+        const size_t e0 = fe + (size_t)min(tid + r * kBT, max(N - 1, 0)) * D1;
+#pragma unroll
+        for (int j = 0; j < D1; ++j) { bw[r][j] = kd.bary[e0 + j]; bo[r][j] = kd.offset[e0 + j]; }
+    }
     for (int v = tid; v < V; v += kBT) {                  // splat of ones: the row's weights, left to right
         float acc = 0.0f;
         int p = rowstart[v];
         const int t = rowstart[v + 1];
-        for (; p + 8 <= t; p += 8) {
-            const float x0 = wsorted[p], x1 = wsorted[p + 1], x2 = wsorted[p + 2], x3 = wsorted[p + 3];
-            const float x4 = wsorted[p + 4], x5 = wsorted[p + 5], x6 = wsorted[p + 6], x7 = wsorted[p + 7];
-            acc += x0 * 1.0f; acc += x1 * 1.0f; acc += x2 * 1.0f; acc += x3 * 1.0f;
-            acc += x4 * 1.0f; acc += x5 * 1.0f; acc += x6 * 1.0f; acc += x7 * 1.0f;
+        for (; p + 16 <= t; p += 16) {                    // 16 loads in flight, then 16 ordered adds
+            float x[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) x[u] = wsorted[p + u];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) acc += x[u] * 1.0f;
         }
-        for (; p < t; ++p) acc += wsorted[p] * 1.0f;
+        if (p < t) {                                      // the rest of the row, padded with +0 (x + 0 is exact here)
+            float x[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) x[u] = (p + u < t) ? wsorted[p + u] * 1.0f : 0.0f;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) acc += x[u];
+        }
         val[v + 1] = acc;
     }
     __syncthreads();
-    const int2 *nbr = reinterpret_cast<const int2 *>(kd.nbr) + (size_t)f * D1 * kd.Epad;
+#pragma unroll
     for (int j = 0; j < D1; ++j) {
-        for (int v = tid; v < V; v += kBT) {
-            const int2 nb = nbr[(size_t)j * kd.Epad + v];
-            nxt[v + 1] = val[v + 1] + 0.5f * (val[nb.x + 1] + val[nb.y + 1]);
+#pragma unroll
+        for (int r = 0; r < kVR; ++r) {
+            const int v = tid + r * kBT;
+            if (v < V) nxt[v + 1] = val[v + 1] + 0.5f * (val[nb[j][r].x + 1] + val[nb[j][r].y + 1]);
+        }
+        for (int v = tid + kVR * kBT; v < V; v += kBT) {  // lattices beyond the register rounds
+            const int2 n2 = nbr[(size_t)j * kd.Epad + v];
+            nxt[v + 1] = val[v + 1] + 0.5f * (val[n2.x + 1] + val[n2.y + 1]);
         }
         __syncthreads();
         float *t = val; val = nxt; nxt = t;
     }
-    for (int i = tid; i < N; i += kBT) {
-        float t = 0.0f;
 #pragma unroll
-        for (int j = 0; j < D1; ++j)
-            t += (kd.bary[fe + (size_t)i * D1 + j] * kd.alpha) * val[kd.offset[fe + (size_t)i * D1 + j] + 1];
-        kd.norm[(size_t)f * kd.maxN + i] = 1.0f / (t + 1e-20f);
+    for (int r = 0; r < kPR; ++r) {
+        const int i = tid + r * kBT;
+        if (i < N) {
+            float t = 0.0f;
+#pragma unroll
+            for (int j = 0; j < D1; ++j) t += (bw[r][j] * kd.alpha) * val[bo[r][j] + 1];
+            kd.norm[(size_t)f * kd.maxN + i] = 1.0f / (t + 1e-20f);
+        }
     }
     BSTAMP(8);
 }
@@ -369,7 +435,7 @@ SmallPlan small_plan(const KernelDev &kd, int NA)
     SmallPlan p;
     p.hcap = 1024;
     while (p.hcap < live + live / 2) p.hcap <<= 1;
-    p.ints = (int)((std::max<long>(p.hcap, 2 * (live + 2) + 4 + (live + 4) / 2) + 3) & ~3L);
+    p.ints = (int)((std::max<long>(p.hcap + (live + 1) / 2, 2 * (live + 2) + 4 + (live + 4) / 2) + 3) & ~3L);   // hash table + rep[] | CSR arrays
     // after the ints: the point records (dead once the neighbours are known), overlaid later by the
     // E sorted weights of the normalisation's splat
     const size_t rec = (((size_t)((NA + 3) & ~3) * kd.d * 3 + 15) & ~(size_t)15) + (size_t)((live + 7) & ~7) * 2 + (size_t)(live + 8) * 2;
@@ -393,7 +459,7 @@ bool build_small_supported(const KernelDev *kds, int n, int NA)
 void launch_build_small(const KernelDev *kds, int n, int NA, const CrfDev &c, hipStream_t s)
 {
     const SmallPlan p = small_plan(kds[0], NA);          // same d and same capacities for all n
-    static const bool want_stamps = getenv("LCCRF_BUILD_TIMING") != nullptr;
+    static const int want_stamps = getenv("LCCRF_BUILD_TIMING") ? std::max(atoi(getenv("LCCRF_BUILD_TIMING")), 1) : 0;   // 1 + kernel index
     const dim3 grid(c.F, n);
     const KernelDev &k0 = kds[0], &k1 = kds[n - 1];
 #define BUILD_CASE(DD)                                                                                  \
@@ -416,7 +482,8 @@ void launch_build_small(const KernelDev *kds, int n, int NA, const CrfDev &c, hi
         (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_build_stamps), sizeof(h));
         fprintf(stderr, "[lccrf build timing] lds=%zu B hcap=%d; phase deltas (shader clocks):", p.bytes, p.hcap);
         for (int i = 1; i <= 8; ++i) fprintf(stderr, " %lld", h[i] - h[i - 1]);
-        fprintf(stderr, " | csr: count %lld scan %lld fill %lld", h[9] - h[5], h[10] - h[9], h[6] - h[10]);
+        fprintf(stderr, " | csr: count %lld scan %lld fill %lld | order %lld load %lld scatter %lld copy %lld", h[9] - h[5], h[10] - h[9],
+                h[6] - h[10], h[11] - h[6], h[12] - h[11], h[13] - h[12], h[7] - h[13]);
         fprintf(stderr, "\n");
     }
 }
