@@ -30,6 +30,8 @@ namespace {
 
 constexpr int kNT = 1024;                 // lanes per workgroup (16 wavefronts)
 constexpr int kMaxFusedK = 2;
+constexpr int kChainGap = 14;               // product slots reserved per chain row beyond its products (see pst)
+constexpr int kChainTop = 16;               // rows of the first chain wavefront pair (see the prologue)
 constexpr size_t kLdsLimit = 160 * 1024;  // MI355X: 160 KiB LDS per CU, one workgroup may own it all
 
 struct FusedLayout {                      // byte offsets into dynamic LDS
@@ -68,69 +70,67 @@ struct FusedArgs {
 
 // ---- ordered row sums for kernels with long splat rows -----------------------------------
 // The appearance kernel of a SLAM frame puts ~2000 points on ~120 lattice vertices: a few rows
-// hold 300-600 products that must be added strictly left to right.  The compiler's schedule of
-// that loop (8 ds_read_b32, s_waitcnt 0, 8 adds) runs at ~30 cycles per product; the floor is the
-// dependent v_add_f32 latency, 5.2 cycles.  chain_rows streams a row through a ring of four
-// 8-product units (two ds_read_b128 each): while unit u is added, units u+1..u+3 are in flight,
-// i.e. every load has 24 adds (~125 cycles) to land, which covers the LDS latency even with the
-// bank conflicts of 64 lanes walking 64 different rows.  The loads and the s_waitcnt are issued by
-// hand: the compiler does not see the loads as pending, so it adds no wait of its own, and LDS data
-// returns in order, so lgkmcnt(6) right after a unit was issued means the oldest of the four
-// units in flight has landed.
-// One lane per (vertex,label) row; long rows go to the first wavefronts so that the others retire
-// early.  Rows are padded to 4 products with +0.0f and a lane that has run out of units reads a
-// block of zeros: both are exact, because the accumulator starts at +0 and x + (+0) == x bit for
-// bit for every x != -0, and -0 cannot arise from +0 + ... (x + -x rounds to +0).
-//   addr  LDS byte address of the lane's row (16-byte aligned)    nh    its full 8-product units
-//   tq    1 if a 4-product group follows the units                 wmax  max nh over the wavefront
-//   zaddr LDS byte address of 64 bytes of zeros, >= 128
-typedef float f4_t __attribute__((ext_vector_type(4)));
+// hold 300-600 products that must be added strictly left to right, one lane per (vertex,label)
+// row.  The floor is the dependent v_add_f32 latency, 5.1 cycles per product; the compiler's
+// schedule of the plain loop (8 ds_read_b32, s_waitcnt 0, 8 adds) runs at ~30, and its schedule
+// of a software-pipelined C++ loop at ~13 (scripts/ubench/rowchain.hip, feedcost.hip).
+// chain_rows is that loop written out by hand, ~8 cycles per product:
+//   * a ring of four 8-product units in v96..v127 (two ds_read_b128 each): while unit u is added,
+//     units u+1..u+3 are in flight; LDS data returns in order, so lgkmcnt(6) right after a unit
+//     was issued means the oldest of the four has landed;
+//   * a row is stored as [products][+0 up to a multiple of 4][eight +0]: a lane that has run out
+//     of row keeps reading its own eight zeros (address clamp = one v_min_u32 per unit; no
+//     compare/select, no EXEC games), and a row whose padded length is 8n+4 needs no tail code.
+// Adding +0 is exact here: the accumulator starts at +0, and x + (+0) == x bit for bit for every
+// x != -0, which cannot arise from +0 + ... (x + -x rounds to +0).
+//   addr  LDS byte address of the lane's row (16-byte aligned)    units  ceil(row length / 8)
+//   end   LDS byte address of the row's eight zeros                 trips  ceil(max units of the wavefront / 4)
+#define LCCRF_ASM_ADD8(a, b, c, d, e, f, g, h)                                                        \
+    "v_add_f32_e32 %[acc], %[acc], " #a "\n\tv_add_f32_e32 %[acc], %[acc], " #b "\n\t"               \
+    "v_add_f32_e32 %[acc], %[acc], " #c "\n\tv_add_f32_e32 %[acc], %[acc], " #d "\n\t"               \
+    "v_add_f32_e32 %[acc], %[acc], " #e "\n\tv_add_f32_e32 %[acc], %[acc], " #f "\n\t"               \
+    "v_add_f32_e32 %[acc], %[acc], " #g "\n\tv_add_f32_e32 %[acc], %[acc], " #h "\n\t"
 
-#define LCCRF_LDS_UNIT(XA, XB, BASE, OFF0, OFF1)                                                     \
-    asm volatile("ds_read_b128 %0, %2 offset:" OFF0 "\n\tds_read_b128 %1, %2 offset:" OFF1           \
-                 : "=&v"(XA), "=&v"(XB) : "v"(BASE) : "memory")
-#define LCCRF_LDS_WAIT(N, XA, XB) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(XA), "+v"(XB) : : "memory")
-#define LCCRF_ADD4(ACC, X) ACC += X.x; ACC += X.y; ACC += X.z; ACC += X.w
-#define LCCRF_ADD8(ACC, XA, XB) LCCRF_ADD4(ACC, XA); LCCRF_ADD4(ACC, XB)
-
-__device__ __forceinline__ float chain_rows(unsigned addr, unsigned nh, unsigned tq, unsigned wmax, unsigned zaddr)
+__device__ __forceinline__ float chain_rows(unsigned addr, unsigned end, unsigned trips)
 {
     float acc = 0.0f;
-    const unsigned tad = tq ? addr + nh * 32u : zaddr;
-    if (wmax != 0) {
-        f4_t R0a, R0b, R1a, R1b, R2a, R2b, R3a, R3b;
-        // unit u of this lane: addr + 32u while u < nh, the zero block afterwards.  `base` is
-        // chosen so that base + immediate offset gives that address.
-        unsigned base = 0 < nh ? addr : zaddr;
-        LCCRF_LDS_UNIT(R0a, R0b, base, "0", "16");
-        base = 1 < nh ? addr : zaddr - 32u;
-        LCCRF_LDS_UNIT(R1a, R1b, base, "32", "48");
-        base = 2 < nh ? addr : zaddr - 64u;
-        LCCRF_LDS_UNIT(R2a, R2b, base, "64", "80");
-        for (unsigned h = 0; h < wmax; h += 4) {
-            base = h + 3 < nh ? addr : zaddr - 96u;
-            LCCRF_LDS_UNIT(R3a, R3b, base, "96", "112");
-            LCCRF_LDS_WAIT(6, R0a, R0b);
-            LCCRF_ADD8(acc, R0a, R0b);
-            addr += 128u;
-            base = h + 4 < nh ? addr : zaddr;
-            LCCRF_LDS_UNIT(R0a, R0b, base, "0", "16");
-            LCCRF_LDS_WAIT(6, R1a, R1b);
-            LCCRF_ADD8(acc, R1a, R1b);
-            base = h + 5 < nh ? addr : zaddr - 32u;
-            LCCRF_LDS_UNIT(R1a, R1b, base, "32", "48");
-            LCCRF_LDS_WAIT(6, R2a, R2b);
-            LCCRF_ADD8(acc, R2a, R2b);
-            base = h + 6 < nh ? addr : zaddr - 64u;
-            LCCRF_LDS_UNIT(R2a, R2b, base, "64", "80");
-            LCCRF_LDS_WAIT(6, R3a, R3b);
-            LCCRF_ADD8(acc, R3a, R3b);
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(R0a), "+v"(R0b), "+v"(R1a), "+v"(R1b), "+v"(R2a), "+v"(R2b) : : "memory");   // drain the unused prefetches
-    }
-    f4_t T;                               // the trailing group of four, if any
-    asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(T) : "v"(tad) : "memory");
-    LCCRF_ADD4(acc, T);
+    if (trips == 0) return acc;
+    const unsigned e1 = end - 32u, e2 = end - 64u, e3 = end - 96u;      // min(addr, end - k) + k == min(addr + k, end)
+    unsigned sel;
+    asm volatile(
+        "v_min_u32_e32 %[sel], %[ad], %[e0]\n\t"
+        "ds_read_b128 v[96:99], %[sel]\n\tds_read_b128 v[100:103], %[sel] offset:16\n\t"
+        "v_min_u32_e32 %[sel], %[ad], %[e1]\n\t"
+        "ds_read_b128 v[104:107], %[sel] offset:32\n\tds_read_b128 v[108:111], %[sel] offset:48\n\t"
+        "v_min_u32_e32 %[sel], %[ad], %[e2]\n\t"
+        "ds_read_b128 v[112:115], %[sel] offset:64\n\tds_read_b128 v[116:119], %[sel] offset:80\n\t"
+        "1:\n\t"
+        "v_min_u32_e32 %[sel], %[ad], %[e3]\n\t"
+        "ds_read_b128 v[120:123], %[sel] offset:96\n\tds_read_b128 v[124:127], %[sel] offset:112\n\t"
+        "s_waitcnt lgkmcnt(6)\n\t"
+        LCCRF_ASM_ADD8(v96, v97, v98, v99, v100, v101, v102, v103)
+        "v_add_u32_e32 %[ad], 0x80, %[ad]\n\t"
+        "v_min_u32_e32 %[sel], %[ad], %[e0]\n\t"
+        "ds_read_b128 v[96:99], %[sel]\n\tds_read_b128 v[100:103], %[sel] offset:16\n\t"
+        "s_waitcnt lgkmcnt(6)\n\t"
+        LCCRF_ASM_ADD8(v104, v105, v106, v107, v108, v109, v110, v111)
+        "v_min_u32_e32 %[sel], %[ad], %[e1]\n\t"
+        "ds_read_b128 v[104:107], %[sel] offset:32\n\tds_read_b128 v[108:111], %[sel] offset:48\n\t"
+        "s_waitcnt lgkmcnt(6)\n\t"
+        LCCRF_ASM_ADD8(v112, v113, v114, v115, v116, v117, v118, v119)
+        "v_min_u32_e32 %[sel], %[ad], %[e2]\n\t"
+        "ds_read_b128 v[112:115], %[sel] offset:64\n\tds_read_b128 v[116:119], %[sel] offset:80\n\t"
+        "s_waitcnt lgkmcnt(6)\n\t"
+        LCCRF_ASM_ADD8(v120, v121, v122, v123, v124, v125, v126, v127)
+        "s_sub_u32 %[n], %[n], 1\n\t"
+        "s_cmp_lg_u32 %[n], 0\n\t"
+        "s_cbranch_scc1 1b\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        : [acc] "+v"(acc), [ad] "+v"(addr), [n] "+s"(trips), [sel] "=&v"(sel)
+        : [e0] "v"(end), [e1] "v"(e1), [e2] "v"(e2), [e3] "v"(e3)
+        : "scc", "memory", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107",
+          "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120",
+          "v121", "v122", "v123", "v124", "v125", "v126", "v127");
     return acc;
 }
 
@@ -267,10 +267,11 @@ __global__ void __launch_bounds__(kNT) k_fused(CrfDev c, FusedArgs a)
     // ---- where does each of my products go?  (once per launch) -----------------------
     // The build recorded the place of entry (i, j) in its vertex's row (ascending point order,
     // the reference's splat order).  A plain kernel stores its products at exactly that CSR
-    // position.  The chain kernel re-places row v at pst(v) = ceil4(row[v] + 3v): starts are
-    // multiples of 4 and consecutive rows cannot overlap (pst(v+1) - pst(v) is a multiple of 4
-    // that is >= the row's length), so every row is padded to 4 products without any scan.
-    auto pst = [](int r0, int v) { return (r0 + 3 * v + 3) & ~3; };
+    // position.  The chain kernel re-places row v at pst(v) = ceil4(row[v] + 14v): starts are
+    // multiples of 4 and pst(v+1) - pst(v) is a multiple of 4 that is >= the row's length + 11,
+    // i.e. there is room for the row padded to 4 products plus the eight zeros chain_rows wants
+    // behind it -- without any scan.
+    auto pst = [](int r0, int v) { return (r0 + kChainGap * v + 3) & ~3; };
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         const unsigned short *row = reinterpret_cast<const unsigned short *>(smem + a.lay.row[k]);
@@ -297,7 +298,7 @@ __global__ void __launch_bounds__(kNT) k_fused(CrfDev c, FusedArgs a)
     // longest first; order inside a bucket is whatever the LDS atomics give -- it only decides
     // which lane sums which row, never the order inside a row).
     unsigned ch_a = 0, ch_b = 0;          // row address | wavefront max units << 18 ;
-                                          // 8-product units | tail group << 13 | pad slots << 14 | output index << 16
+                                          // 8-product units | (padded length is 8n+4) << 13 | pad slots << 14 | output index << 16
     if constexpr (CH != 0) {
         constexpr int k = 0;
         const unsigned short *row = reinterpret_cast<const unsigned short *>(smem + a.lay.row[k]);
@@ -322,16 +323,20 @@ __global__ void __launch_bounds__(kNT) k_fused(CrfDev c, FusedArgs a)
         __syncthreads();
         if (tid < V[k]) srt[atomicAdd(&hist[64 + key], 1)] = (unsigned short)tid;
         __syncthreads();
-        // wavefront w owns label (w & 1) of the rows ranked 64*(w >> 1) .. +63: the two longest-row
-        // wavefronts are 0 and 1, and a wavefront reads one label plane only
-        const int Vr = (V[k] + 63) & ~63;
-        const int l = (tid >> 6) & 1, r = ((tid >> 7) << 6) | (tid & 63);
+        // Wavefront pair p = (2p, 2p+1) owns labels 0 and 1 of a rank range, so a wavefront reads one
+        // label plane only.  Pair 0 takes just the kChainTop longest rows, four lanes in each of the
+        // four 16-lane groups a ds_read_b128 is served in: the cost of a ring unit grows with the
+        // bank conflicts among the ACTIVE lanes (~75 cycles with 16 rows, ~110 with 64), and it is
+        // the longest rows' wavefront that everybody waits for.  Pair p >= 1: 64 rows each.
+        const int l = (tid >> 6) & 1, pr = tid >> 7, ln = tid & 63;
+        const int r = pr == 0 ? (((ln & 0x18) == 0) ? ((ln & 7) | ((ln >> 5) << 3)) : V[k])
+                              : kChainTop + ((pr - 1) << 6) + ln;
         unsigned nblk = 0, addr = 0;
-        if (tid < 2 * Vr && r < V[k]) {
+        if (r < V[k]) {
             const int v = srt[r];
             const int r0 = row[v], rl = (int)row[v + 1] - r0, len4 = (rl + 3) & ~3;
             addr = (unsigned)(a.lay.prod[k] + 4 * (l * a.lay.Ecap[k] + pst(r0, v)));               // < 2^18
-            nblk = (unsigned)(len4 >> 3);                                                          // 8-product units, < 2^13
+            nblk = (unsigned)((len4 + 7) >> 3);                                                    // 8-product units, < 2^13
             ch_b = nblk | ((unsigned)((len4 >> 2) & 1) << 13) | ((unsigned)(len4 - rl) << 14) |
                    ((unsigned)((v + 1) * 2 + l) << 16);
         }
@@ -379,11 +384,14 @@ __global__ void __launch_bounds__(kNT) k_fused(CrfDev c, FusedArgs a)
                     }
                 }
             }
-            if ((CH >> k) & 1) {          // the row's padding (the buffer may have held another kernel's products)
-                const unsigned npad = (ch_b >> 14) & 3u;
-                if (npad) {
-                    float *e = reinterpret_cast<float *>(smem + (ch_a & 0x3ffffu)) + ((ch_b & 0x1fffu) * 8u + ((ch_b >> 13) & 1u) * 4u);
+            if ((CH >> k) & 1) {          // behind the row: +0 up to a multiple of 4, then eight +0 (the buffer may
+                                          // have held another kernel's products)
+                if (ch_b >> 16) {
+                    float *e = reinterpret_cast<float *>(smem + (ch_a & 0x3ffffu)) + ((ch_b & 0x1fffu) * 8u - ((ch_b >> 13) & 1u) * 4u);
+                    const unsigned npad = (ch_b >> 14) & 3u;
                     for (unsigned z = 1; z <= npad; ++z) e[-(int)z] = 0.0f;
+                    reinterpret_cast<float4 *>(e)[0] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    reinterpret_cast<float4 *>(e)[1] = make_float4(0.f, 0.f, 0.f, 0.f);
                 }
             }
         };
@@ -392,12 +400,12 @@ __global__ void __launch_bounds__(kNT) k_fused(CrfDev c, FusedArgs a)
         auto phase_S = [&](int k, int s_lo) {
             float *val = reinterpret_cast<float *>(smem + a.lay.val[k][0]);
             if ((CH >> k) & 1) {
-                const int Vr = (V[k] + 63) & ~63;
-                if (tid < 2 * Vr && !(a.dbg & 2)) {                                       // whole wavefronts
+                const int npairs = 1 + ((max(V[k] - kChainTop, 0) + 63) >> 6);
+                if ((tid >> 7) < npairs && !(a.dbg & 2)) {                                // whole wavefronts
                     PSTAMP();
-                    const float acc = chain_rows(ch_a & 0x3ffffu, ch_b & 0x1fffu, (ch_b >> 13) & 1u,
-                                                 (unsigned)__builtin_amdgcn_readfirstlane((int)(ch_a >> 18)),
-                                                 (unsigned)a.lay.zero);
+                    const unsigned row_addr = ch_a & 0x3ffffu;
+                    const float acc = chain_rows(row_addr, row_addr + ((ch_b & 0x1fffu) * 8u - ((ch_b >> 13) & 1u) * 4u) * 4u,
+                                                 ((unsigned)__builtin_amdgcn_readfirstlane((int)(ch_a >> 18)) + 3u) >> 2);
                     if ((ch_b >> 16) != 0) val[ch_b >> 16] = acc;
                     PSTAMP();
                 }
@@ -506,7 +514,7 @@ __global__ void __launch_bounds__(kNT) k_fused(CrfDev c, FusedArgs a)
 }
 
 constexpr int kChainMinRow = 64;          // kernel 0 runs chain_rows when its longest splat row has at least this many products ...
-constexpr int kChainMaxV = 512;           // ... and it has at most this many vertices (one lane per (vertex,label), ranking is O(V) per lane)
+constexpr int kChainMaxV = kChainTop + 7 * 64;           // ... and it has at most this many vertices (one lane per (vertex,label), ranking is O(V) per lane)
 
 bool make_layout(const CrfDev &c, const KernelDev *kds, const int *maxV, const int *maxRow, FusedLayout *lay)
 {
@@ -518,7 +526,7 @@ bool make_layout(const CrfDev &c, const KernelDev *kds, const int *maxV, const i
         if (maxV[k] >= 65535 || kds[k].Epad >= 65535) return false;     // u16 row pointers / neighbour ids / slots
     }
     const int chain0 = maxRow && maxRow[0] >= kChainMinRow && maxV[0] <= kChainMaxV &&
-                       NA * kds[0].D1 + 3 * maxV[0] + 64 < 65535;
+                       NA * kds[0].D1 + kChainGap * maxV[0] + 64 < 65535;
     for (int all = 1; all >= 0; --all) {                  // own product buffers, else one shared buffer
         FusedLayout L{};
         size_t o = 0;
@@ -530,8 +538,8 @@ bool make_layout(const CrfDev &c, const KernelDev *kds, const int *maxV, const i
         size_t shared_prod = 0;
         for (int k = 0; k < c.K; ++k) {
             const int E = NA * kds[k].D1;
-            // chain rows are padded to 4 products; every plane is a multiple of 64 floats
-            L.Ecap[k] = ((k == 0 && chain0 ? E + 3 * maxV[k] : E) + 63) & ~63;
+            // chain rows carry kChainGap extra slots each; every plane is a multiple of 64 floats
+            L.Ecap[k] = ((k == 0 && chain0 ? E + kChainGap * maxV[k] + 16 : E) + 63) & ~63;
             L.Vcap[k] = maxV[k];
             L.val[k][0] = take((size_t)(maxV[k] + 1) * sizeof(float2));
             L.val[k][1] = take((size_t)(maxV[k] + 1) * sizeof(float2));

@@ -133,81 +133,80 @@ __global__ void __launch_bounds__(kNT) k_rows_asm(const float *src, int total, c
     if (tid == 0) cyc[0] = t1 - t0;
 }
 
-typedef float f4_t __attribute__((ext_vector_type(4)));
+#define LCCRF_ASM_ADD8(a, b, c, d, e, f, g, h)                                                        \
+    "v_add_f32_e32 %[acc], %[acc], " #a "\n\tv_add_f32_e32 %[acc], %[acc], " #b "\n\t"               \
+    "v_add_f32_e32 %[acc], %[acc], " #c "\n\tv_add_f32_e32 %[acc], %[acc], " #d "\n\t"               \
+    "v_add_f32_e32 %[acc], %[acc], " #e "\n\tv_add_f32_e32 %[acc], %[acc], " #f "\n\t"               \
+    "v_add_f32_e32 %[acc], %[acc], " #g "\n\tv_add_f32_e32 %[acc], %[acc], " #h "\n\t"
 
-#define LCCRF_LDS_UNIT(XA, XB, BASE, OFF0, OFF1)                                                     \
-    asm volatile("ds_read_b128 %0, %2 offset:" OFF0 "\n\tds_read_b128 %1, %2 offset:" OFF1           \
-                 : "=&v"(XA), "=&v"(XB) : "v"(BASE) : "memory")
-#define LCCRF_LDS_WAIT(N, XA, XB) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(XA), "+v"(XB) : : "memory")
-#define LCCRF_ADD4(ACC, X) ACC += X.x; ACC += X.y; ACC += X.z; ACC += X.w
-#define LCCRF_ADD8(ACC, XA, XB) LCCRF_ADD4(ACC, XA); LCCRF_ADD4(ACC, XB)
-
-__device__ __forceinline__ float chain_rows(unsigned addr, unsigned nh, unsigned tq, unsigned wmax, unsigned zaddr)
+__device__ __forceinline__ float chain_rows(unsigned addr, unsigned end, unsigned trips)
 {
     float acc = 0.0f;
-    const unsigned tad = tq ? addr + nh * 32u : zaddr;
-    if (wmax != 0) {
-        f4_t R0a, R0b, R1a, R1b, R2a, R2b, R3a, R3b;
-        // unit u of this lane: addr + 32u while u < nh, the zero block afterwards.  `base` is
-        // chosen so that base + immediate offset gives that address.
-        unsigned base = 0 < nh ? addr : zaddr;
-        LCCRF_LDS_UNIT(R0a, R0b, base, "0", "16");
-        base = 1 < nh ? addr : zaddr - 32u;
-        LCCRF_LDS_UNIT(R1a, R1b, base, "32", "48");
-        base = 2 < nh ? addr : zaddr - 64u;
-        LCCRF_LDS_UNIT(R2a, R2b, base, "64", "80");
-        for (unsigned h = 0; h < wmax; h += 4) {
-            base = h + 3 < nh ? addr : zaddr - 96u;
-            LCCRF_LDS_UNIT(R3a, R3b, base, "96", "112");
-            LCCRF_LDS_WAIT(6, R0a, R0b);
-            LCCRF_ADD8(acc, R0a, R0b);
-            addr += 128u;
-            base = h + 4 < nh ? addr : zaddr;
-            LCCRF_LDS_UNIT(R0a, R0b, base, "0", "16");
-            LCCRF_LDS_WAIT(6, R1a, R1b);
-            LCCRF_ADD8(acc, R1a, R1b);
-            base = h + 5 < nh ? addr : zaddr - 32u;
-            LCCRF_LDS_UNIT(R1a, R1b, base, "32", "48");
-            LCCRF_LDS_WAIT(6, R2a, R2b);
-            LCCRF_ADD8(acc, R2a, R2b);
-            base = h + 6 < nh ? addr : zaddr - 64u;
-            LCCRF_LDS_UNIT(R2a, R2b, base, "64", "80");
-            LCCRF_LDS_WAIT(6, R3a, R3b);
-            LCCRF_ADD8(acc, R3a, R3b);
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(R0a), "+v"(R0b), "+v"(R1a), "+v"(R1b), "+v"(R2a), "+v"(R2b) : : "memory");   // drain the unused prefetches
-    }
-    f4_t T;                               // the trailing group of four, if any
-    asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(T) : "v"(tad) : "memory");
-    LCCRF_ADD4(acc, T);
+    if (trips == 0) return acc;
+    const unsigned e1 = end - 32u, e2 = end - 64u, e3 = end - 96u;      // min(addr, end - k) + k == min(addr + k, end)
+    unsigned sel;
+    asm volatile(
+        "v_min_u32_e32 %[sel], %[ad], %[e0]\n\t"
+        "ds_read_b128 v[96:99], %[sel]\n\tds_read_b128 v[100:103], %[sel] offset:16\n\t"
+        "v_min_u32_e32 %[sel], %[ad], %[e1]\n\t"
+        "ds_read_b128 v[104:107], %[sel] offset:32\n\tds_read_b128 v[108:111], %[sel] offset:48\n\t"
+        "v_min_u32_e32 %[sel], %[ad], %[e2]\n\t"
+        "ds_read_b128 v[112:115], %[sel] offset:64\n\tds_read_b128 v[116:119], %[sel] offset:80\n\t"
+        "1:\n\t"
+        "v_min_u32_e32 %[sel], %[ad], %[e3]\n\t"
+        "ds_read_b128 v[120:123], %[sel] offset:96\n\tds_read_b128 v[124:127], %[sel] offset:112\n\t"
+        "s_waitcnt lgkmcnt(6)\n\t"
+        LCCRF_ASM_ADD8(v96, v97, v98, v99, v100, v101, v102, v103)
+        "v_add_u32_e32 %[ad], 0x80, %[ad]\n\t"
+        "v_min_u32_e32 %[sel], %[ad], %[e0]\n\t"
+        "ds_read_b128 v[96:99], %[sel]\n\tds_read_b128 v[100:103], %[sel] offset:16\n\t"
+        "s_waitcnt lgkmcnt(6)\n\t"
+        LCCRF_ASM_ADD8(v104, v105, v106, v107, v108, v109, v110, v111)
+        "v_min_u32_e32 %[sel], %[ad], %[e1]\n\t"
+        "ds_read_b128 v[104:107], %[sel] offset:32\n\tds_read_b128 v[108:111], %[sel] offset:48\n\t"
+        "s_waitcnt lgkmcnt(6)\n\t"
+        LCCRF_ASM_ADD8(v112, v113, v114, v115, v116, v117, v118, v119)
+        "v_min_u32_e32 %[sel], %[ad], %[e2]\n\t"
+        "ds_read_b128 v[112:115], %[sel] offset:64\n\tds_read_b128 v[116:119], %[sel] offset:80\n\t"
+        "s_waitcnt lgkmcnt(6)\n\t"
+        LCCRF_ASM_ADD8(v120, v121, v122, v123, v124, v125, v126, v127)
+        "s_sub_u32 %[n], %[n], 1\n\t"
+        "s_cmp_lg_u32 %[n], 0\n\t"
+        "s_cbranch_scc1 1b\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        : [acc] "+v"(acc), [ad] "+v"(addr), [n] "+s"(trips), [sel] "=&v"(sel)
+        : [e0] "v"(end), [e1] "v"(e1), [e2] "v"(e2), [e3] "v"(e3)
+        : "scc", "memory", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107",
+          "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120",
+          "v121", "v122", "v123", "v124", "v125", "v126", "v127");
     return acc;
 }
 
-
-// the shipped chain_rows (copied from csrc/fused_engine.hip by scripts/ubench/sync_rowchain.py): rows sorted
+// the shipped chain_rows (copied from csrc/fused_engine.hip): rows sorted
 // longest-first, wavefront w owns label (w & 1) of rows 64*(w >> 1)..+63, `waves` limits who runs
 __global__ void __launch_bounds__(kNT) k_rows_ring(const float *src, int total, const int *start, const int *len, int V,
-                                                    int plane, int waves, float *out, long long *cyc)
+                                                    int plane, int waves, int lanes, float *out, long long *cyc)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     for (int i = threadIdx.x; i < 2 * plane + 64; i += kNT) lds[i] = i < 48 ? 0.0f : src[(i - 48) % total];
     __syncthreads();
-    long long t0 = clock64();
     const int tid = threadIdx.x;
     const int Vr = (V + 63) & ~63;
     const int l = (tid >> 6) & 1, r = ((tid >> 7) << 6) | (tid & 63);
-    if (tid < 2 * Vr && (tid >> 6) < waves) {
-        const bool live = r < V;
-        const int len4 = live ? (len[r] + 3) & ~3 : 0;
-        const unsigned addr = (unsigned)(size_t)(lds) + (48 + l * plane + (live ? start[r] : 0)) * 4u;
-        const unsigned nh = (unsigned)(len4 >> 3), tq = (unsigned)((len4 >> 2) & 1);
-        unsigned m = nh;
-        for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
-        const float acc = chain_rows(addr, nh, tq, __builtin_amdgcn_readfirstlane(m), (unsigned)(size_t)(lds) + 128u);
-        if (live) out[l * V + r] = acc;
-    }
+    const bool run = tid < 2 * Vr && (tid >> 6) < waves;
+    const bool live = run && r < V && (tid & 63) < lanes;
+    const int len4 = live ? (len[r] + 3) & ~3 : 0;
+    const unsigned addr = (unsigned)(size_t)(lds) + (48 + l * plane + (live ? start[r] : 0)) * 4u;
+    const unsigned nh = (unsigned)((len4 + 7) >> 3);
+    unsigned m = nh;
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+    m = __builtin_amdgcn_readfirstlane(m);
+    float acc = 0.f;
     __syncthreads();
+    long long t0 = clock64();
+    if (run) acc = chain_rows(addr, addr + len4 * 4u, (m + 3u) >> 2);
     long long t1 = clock64();
+    if (live) out[l * V + r] = acc;
     if (tid == 0) cyc[0] = t1 - t0;
 }
 
@@ -264,7 +263,7 @@ int main()
         const bool aligned = getenv("ROWCHAIN_CONFLICT_FREE") != nullptr;   // give lane r the quad slot r % 16
         for (int v = 0; v < V; ++v) {
             if (aligned) while (((tot >> 2) & 15) != (v & 15)) tot += 4;
-            sstart[v] = tot; tot += (slen[v] + 3) & ~3;
+            sstart[v] = tot; tot += ((slen[v] + 3) & ~3) + 8;     // the row, +0 up to a multiple of 4, eight +0
         }
         printf("placement: %s, %d floats per plane\n", aligned ? "conflict-free quad slots" : "packed", tot);
         const int plane = (tot + 63) & ~63;
@@ -280,20 +279,21 @@ int main()
         hipMemcpy(ds, sstart.data(), V * 4, hipMemcpyHostToDevice); hipMemcpy(dl, slen.data(), V * 4, hipMemcpyHostToDevice);
         hipFuncSetAttribute((const void *)k_rows_ring, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         // NOTE: the kernel copies src linearly behind 48 floats of zeros: lds[48 + i] = s2[i]
-        for (int waves : {1, 2, 4}) {
+        for (int cfg = 0; cfg < 5; ++cfg) {
+            const int waves = cfg < 3 ? (1 << cfg) : 1, lanes = cfg == 3 ? 16 : (cfg == 4 ? 1 : 64);
             for (int rep = 0; rep < 2; ++rep) {
                 hipMemset(dout, 0, R * 4);
-                k_rows_ring<<<1, kNT, (2 * plane + 64) * 4>>>(d2, (int)s2.size(), ds, dl, V, plane, waves, dout, dc);
+                k_rows_ring<<<1, kNT, (2 * plane + 64) * 4>>>(d2, (int)s2.size(), ds, dl, V, plane, waves, lanes, dout, dc);
                 hipDeviceSynchronize();
                 long long c; std::vector<float> o(R);
                 hipMemcpy(&c, dc, 8, hipMemcpyDeviceToHost); hipMemcpy(o.data(), dout, R * 4, hipMemcpyDeviceToHost);
                 int bad = 0, chk = 0;
                 for (int l = 0; l < 2; ++l) for (int v = 0; v < V; ++v) {
                     const int w = 2 * (v >> 6) + l;
-                    if (w < waves) { ++chk; bad += (o[l * V + v] != ref2[l * V + v]); }
+                    if (w < waves && (v & 63) < lanes) { ++chk; bad += (o[l * V + v] != ref2[l * V + v]); }
                 }
-                printf("ring chain, %d wavefront(s): %lld cycles, %.2f per entry of the longest row (%d), mismatches %d of %d\n",
-                       waves, c, (double)c / slen[0], slen[0], bad, chk);
+                printf("shipped chain_rows, %d wavefront(s) x %d lanes: %lld cycles, %.2f per entry of the longest row (%d), mismatches %d of %d\n",
+                       waves, lanes, c, (double)c / slen[0], slen[0], bad, chk);
             }
         }
     }
