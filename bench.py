@@ -167,7 +167,9 @@ def main():
     b.set_engine(args.engine)
     b.bind_inputs_device(F, d_np.data_ptr(), [t.data_ptr() for t in d_feats], d_label=d_label.data_ptr(),
                          conf=pbs[0]["conf"])
-    b.build()
+    b.build()                                        # first build: also allocates and zeroes the lattice arrays
+    b.synchronize()
+    b.build()                                        # steady state (what a replay loop pays per batch)
     b.synchronize()
     build_ms = b.last_timing()["build_ms"]
     engine = b.engine()
