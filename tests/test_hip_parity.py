@@ -76,6 +76,48 @@ def test_hip_matches_oracle_slam_sizes(po, wl, N):
     assert np.array_equal(o.map(), h.map())
 
 
+def _shaped_problem(wl, N, shape, seed):
+    """SLAM-shaped frames whose lattices stress one code path of the fused engine each."""
+    pb = wl.slam_problem(N, seed=seed)
+    rng = np.random.default_rng(seed)
+    f0, f1 = pb["kernels"][0][0].copy(), pb["kernels"][1][0].copy()
+    if shape == "one_cell":            # every point in one lattice cell: 3 vertices, rows of N products
+        f0[:] = f0[0]
+        f1[:] = f1[0]
+    elif shape == "two_clusters":      # two very long rows per kernel plus stragglers
+        half = N // 2
+        f0[:half], f0[half:] = f0[0], f0[-1] + np.float32(7.5)
+        f0[::97] += rng.normal(0, 3, f0[::97].shape).astype(np.float32)
+    elif shape == "rows_of_8":         # row lengths around the 8-product units of chain_rows
+        cells = max(N // 8, 1)
+        f0 = (np.stack([np.arange(N) % cells, np.arange(N) % cells], 1) * np.float32(4.0)).astype(np.float32)
+    elif shape == "sparse":            # every point its own cell: V = 3N, far beyond the chain's vertex limit
+        f0 = (np.stack([np.arange(N), (np.arange(N) * 7) % 1013], 1) * np.float32(9.0)).astype(np.float32)
+    pb["kernels"] = [(f0, pb["kernels"][0][1]), (f1, pb["kernels"][1][1])]
+    return pb
+
+
+@pytest.mark.parametrize("shape,N", [("one_cell", 2000), ("one_cell", 4096), ("one_cell", 70), ("two_clusters", 2047),
+                                     ("two_clusters", 2600), ("rows_of_8", 2000), ("rows_of_8", 1030),
+                                     ("sparse", 1200)])
+def test_fused_engine_on_adversarial_lattices(po, wl, shape, N):
+    """Very long rows (chain path, also with the shared product buffer and 3-4 points per lane), row
+    lengths on the chain's unit boundaries, and lattices too large for the chain path: the engine
+    the library picks must still reproduce the oracle bit for bit."""
+    pb = _shaped_problem(wl, N, shape, seed=5)
+    o, h = cc.setup(po.OracleCRF, pb), cc.setup(pkg.DenseCRFHIP, pb)
+    o.inference_native(4, True)
+    h.inference(4, True)
+    assert cc.same_bits(o.probability(), h.probability())
+    assert np.array_equal(o.map(), h.map())
+    pb["kernels"] = pb["kernels"][:1]                      # and as the only kernel (K = 1)
+    o, h = cc.setup(po.OracleCRF, pb), cc.setup(pkg.DenseCRFHIP, pb)
+    o.inference_native(3, True, 0.8)
+    h.inference(3, True, 0.8)
+    assert cc.same_bits(o.probability(), h.probability())
+    assert np.array_equal(o.map(), h.map())
+
+
 @pytest.mark.parametrize("d,L", [(1, 2), (2, 3), (3, 2), (4, 4), (5, 21), (6, 2), (7, 2), (8, 5)])
 def test_hip_matches_oracle_generic(po, wl, d, L):
     pb = wl.generic_problem(403, [d], L, seed=31, lattice_ties=True)
