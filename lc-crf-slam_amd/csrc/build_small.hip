@@ -219,6 +219,7 @@ __global__ void __launch_bounds__(kBT) k_build_small(KernelDev kd0, KernelDev kd
                 if (side) r.y = found; else r.x = found;
             }
             reinterpret_cast<int2 *>(kd.nbr)[((size_t)f * D1 + j) * kd.Epad + v] = r;
+            kd.nbr16[((size_t)f * D1 + j) * kd.Epad + v] = (unsigned)(r.x + 1) | ((unsigned)(r.y + 1) << 16);
         }
     }
     __syncthreads();                                      // hash table, records and pfx are dead from here on
@@ -328,11 +329,13 @@ __global__ void __launch_bounds__(kBT) k_build_small(KernelDev kd0, KernelDev kd
         constexpr int kMaxEPT = 12;                       // E <= 12 * 1024 for every frame this kernel accepts
         float wv[kMaxEPT];
         int pv[kMaxEPT];
+        unsigned vv[kMaxEPT];
 #pragma unroll
         for (int u = 0; u < kMaxEPT; ++u) {
             const int e = min(tid + u * kBT, max(E - 1, 0));
             wv[u] = kd.bary[fe + e];
             pv[u] = cnt[e];
+            vv[u] = sof[e];
         }
         __syncthreads();                                  // every position is in registers: cnt / work / tail may be overwritten
         BSTAMP(12);
@@ -343,6 +346,7 @@ __global__ void __launch_bounds__(kBT) k_build_small(KernelDev kd0, KernelDev kd
                 wsorted[pv[u]] = wv[u];
                 pts[pv[u]] = (unsigned short)(e / D1);
                 kd.csr_pos[fe + e] = pv[u];
+                kd.pk[fe + e] = (vv[u] + 1u) | ((unsigned)pv[u] << 16);
             }
         }
     }

@@ -50,6 +50,9 @@ struct KernelDev {
     int *csr_pt;          // [F][Epad]         contributing point, ascending within a row
     float *csr_w;         // [F][Epad]         its barycentric weight
     int *csr_pos;         // [F][Epad]         entry -> its position in csr_pt/csr_w (inverse of the row ordering)
+    // compact copies for the fused engine's prologue (frames with Epad < 65535 only; undefined otherwise)
+    unsigned *pk;         // [F][Epad]         (offset + 1) | csr_pos << 16 of every real entry
+    unsigned *nbr16;      // [F][D1][Epad]     (n1 + 1) | (n2 + 1) << 16 per (axis, vertex), 0 = absent
     float *norm;          // [F][maxN]         1/(K*1 + 1e-20)  (PottsPotential3D::norm_)
     float *val0, *val1;   // [F][vstride]      lattice values (see vbase)
 };

@@ -172,12 +172,12 @@ __global__ void __launch_bounds__(kNT) k_fused(CrfDev c, FusedArgs a)
     // tables first (their LDS stores come last), then the per-point records.  Indices are clamped
     // instead of branched on, so that the loads stay back to back.
     constexpr int kNbrRounds = 4, kRowRounds = 2;         // covers V <= 1365 in registers; larger lattices finish in copy loops
-    int2 g_nbr[K][kNbrRounds];
+    unsigned g_nbr[K][kNbrRounds];
     int g_row[K][kRowRounds];
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         const KernelDev &kd = a.kd[k];
-        const int2 *gn = reinterpret_cast<const int2 *>(kd.nbr) + (size_t)f * D1 * kd.Epad;
+        const unsigned *gn = kd.nbr16 + (size_t)f * D1 * kd.Epad;            // already (n1+1) | (n2+1) << 16
         const int *gr = kd.rowptr + (size_t)f * (kd.Epad + 1);
 #pragma unroll
         for (int r = 0; r < kNbrRounds; ++r) {            // element idx = j*V + v, j-major like the LDS copy
@@ -188,7 +188,7 @@ __global__ void __launch_bounds__(kNT) k_fused(CrfDev c, FusedArgs a)
 #pragma unroll
         for (int r = 0; r < kRowRounds; ++r) g_row[k][r] = gr[min(tid + r * kNT, V[k])];
     }
-    int pos[PPT][K][D1], offs[PPT][K][D1];
+    unsigned pk[PPT][K][D1];              // (vertex id + 1) | place in the row << 16
 #pragma unroll
     for (int s = 0; s < PPT; ++s) {
         const int ic = min(tid + s * kNT, N - 1);
@@ -199,9 +199,8 @@ __global__ void __launch_bounds__(kNT) k_fused(CrfDev c, FusedArgs a)
             const size_t e0 = (size_t)f * kd.Epad + (size_t)ic * D1;
 #pragma unroll
             for (int j = 0; j < D1; ++j) {
-                offs[s][k][j] = kd.offset[e0 + j];
+                pk[s][k][j] = kd.pk[e0 + j];
                 bary[s][k][j] = kd.bary[e0 + j];
-                pos[s][k][j] = kd.csr_pos[e0 + j];
             }
             wn[s][k] = kd.norm[(size_t)f * kd.maxN + ic];
         }
@@ -211,8 +210,8 @@ __global__ void __launch_bounds__(kNT) k_fused(CrfDev c, FusedArgs a)
         q[s] = make_float2(0.f, 0.f);
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-            offp[s][k][0] = (unsigned)(offs[s][k][0] + 1) | ((unsigned)(offs[s][k][1] + 1) << 16);
-            offp[s][k][1] = (unsigned)(offs[s][k][2] + 1);
+            offp[s][k][0] = (pk[s][k][0] & 0xffffu) | (pk[s][k][1] << 16);
+            offp[s][k][1] = pk[s][k][2] & 0xffffu;
             slp[s][k][0] = slp[s][k][1] = 0;
             wn[s][k] = a.kd[k].w * wn[s][k];                              // pairwise3d.h:77 (w_*norm_[i])
         }
@@ -228,18 +227,17 @@ __global__ void __launch_bounds__(kNT) k_fused(CrfDev c, FusedArgs a)
 #pragma unroll
         for (int r = 0; r < kNbrRounds; ++r) {
             const int idx = tid + r * kNT;
-            if (idx < D1 * V[k]) nbr[idx] = (unsigned)(g_nbr[k][r].x + 1) | ((unsigned)(g_nbr[k][r].y + 1) << 16);
+            if (idx < D1 * V[k]) nbr[idx] = g_nbr[k][r];
         }
 #pragma unroll
         for (int r = 0; r < kRowRounds; ++r)
             if (tid + r * kNT <= V[k]) row[tid + r * kNT] = (unsigned short)g_row[k][r];
         // lattices with more vertices than the register rounds cover (sparse frames): plain copy loops
         const KernelDev &kd = a.kd[k];
-        const int2 *gn = reinterpret_cast<const int2 *>(kd.nbr) + (size_t)f * D1 * kd.Epad;
+        const unsigned *gn = kd.nbr16 + (size_t)f * D1 * kd.Epad;
         for (int idx = tid + kNbrRounds * kNT; idx < D1 * V[k]; idx += kNT) {
             const int j = idx >= 2 * V[k] ? 2 : (idx >= V[k] ? 1 : 0);
-            const int2 n = gn[(size_t)j * kd.Epad + (idx - j * V[k])];
-            nbr[idx] = (unsigned)(n.x + 1) | ((unsigned)(n.y + 1) << 16);
+            nbr[idx] = gn[(size_t)j * kd.Epad + (idx - j * V[k])];
         }
         const int *gr = kd.rowptr + (size_t)f * (kd.Epad + 1);
         for (int v = tid + kRowRounds * kNT; v <= V[k]; v += kNT) row[v] = (unsigned short)gr[v];
@@ -281,11 +279,11 @@ __global__ void __launch_bounds__(kNT) k_fused(CrfDev c, FusedArgs a)
                 unsigned sl[D1];
 #pragma unroll
                 for (int j = 0; j < D1; ++j) {
-                    sl[j] = (unsigned)pos[s][k][j];
+                    sl[j] = pk[s][k][j] >> 16;
                     if ((CH >> k) & 1) {
-                        const int v = (int)((j == 0) ? (offp[s][k][0] & 0xffffu) : (j == 1) ? (offp[s][k][0] >> 16) : offp[s][k][1]) - 1;
+                        const int v = (int)(pk[s][k][j] & 0xffffu) - 1;
                         const int r0 = row[v];
-                        sl[j] = (unsigned)(pst(r0, v) + (pos[s][k][j] - r0));
+                        sl[j] = (unsigned)(pst(r0, v) + ((int)(pk[s][k][j] >> 16) - r0));
                     }
                 }
                 slp[s][k][0] = sl[0] | (sl[1] << 16);

@@ -204,6 +204,7 @@ __global__ void __launch_bounds__(kBlock) k_neighbors(KernelDev kd)
     r.x = find_vertex<D>(kd, f, n1);
     r.y = find_vertex<D>(kd, f, n2);
     reinterpret_cast<int2 *>(kd.nbr)[((size_t)f * D1 + j) * kd.Epad + v] = r;
+    if (kd.Epad < 65535) kd.nbr16[((size_t)f * D1 + j) * kd.Epad + v] = (unsigned)(r.x + 1) | ((unsigned)(r.y + 1) << 16);
 }
 
 // ---- CSR of splat contributions: vertex -> (point, weight), points ascending ------------
@@ -254,6 +255,7 @@ __global__ void __launch_bounds__(kBlock) k_csr_order(KernelDev kd, const int *_
     kd.csr_pt[fe + s + rank] = e / kd.D1;
     kd.csr_w[fe + s + rank] = kd.bary[fe + e];
     kd.csr_pos[fe + e] = s + rank;
+    if (kd.Epad < 65535) kd.pk[fe + e] = (unsigned)(v + 1) | ((unsigned)(s + rank) << 16);
 }
 
 // ---------------------------------------------------------------------------------------
