@@ -268,6 +268,8 @@ struct Engine {
         maxV.resize(kernels.size());
         maxRow.resize(kernels.size());
         for (size_t i = 0; i < kernels.size(); ++i) {
+            kernels[i].dev.V_host = V_host + i * Fcap;
+            kernels[i].dev.rowmax_host = row_host + i * Fcap;
             kdevs[i] = kernels[i].dev;
             maxV[i] = kernels[i].maxV;
             maxRow[i] = kernels[i].maxRow;
@@ -291,17 +293,15 @@ struct Engine {
             const int NA = activeN > 0 ? activeN : maxN;
             if (!no_small && k + 1 < k0 + n && build_small_supported(&kdevs[k], 2, NA)) m = 2;
             if (!no_small && build_small_supported(&kdevs[k], m, NA)) {
-                launch_build_small(&kdevs[k], m, NA, crf, stream);
+                launch_build_small(&kdevs[k], m, NA, crf, stream);   // writes V / rowmax to the pinned mirrors itself
             } else {
                 m = 1;
                 launch_build_kernel(kdevs[k], crf, kernels[k].maxV, stream);
                 launch_norm(kdevs[k], crf, kernels[k].maxV, stream);
+                HIP_TRY(hipMemcpyAsync(V_host + (size_t)k * Fcap, kernels[k].dev.V, sizeof(int) * F, hipMemcpyDeviceToHost, stream));
+                HIP_TRY(hipMemcpyAsync(row_host + (size_t)k * Fcap, kernels[k].dev.rowmax, sizeof(int) * F, hipMemcpyDeviceToHost, stream));
             }
             k += m;
-        }
-        for (k = k0; k < k0 + n; ++k) {
-            HIP_TRY(hipMemcpyAsync(V_host + (size_t)k * Fcap, kernels[k].dev.V, sizeof(int) * F, hipMemcpyDeviceToHost, stream));
-            HIP_TRY(hipMemcpyAsync(row_host + (size_t)k * Fcap, kernels[k].dev.rowmax, sizeof(int) * F, hipMemcpyDeviceToHost, stream));
         }
         HIP_TRY(hipGetLastError());
         sizes_known = false;
@@ -402,6 +402,8 @@ struct lccrf_crf {
     int16_t *stage_i16 = nullptr;   // pinned [cap]
     float *stage_f32 = nullptr;     // pinned [cap*L]
     int *stage_n = nullptr;         // pinned [1]
+    bool label_stage_busy = false;  // a kernel that reads stage_i16 may still be pending
+    int16_t *map_pin = nullptr;     // pinned [cap]: the kernels write the MAP labels straight into host memory
 };
 
 namespace {
@@ -474,6 +476,7 @@ int lccrf_create(lccrf_handle *out, int device_id, int n_points, int n_labels)
         if (!rc) rc = h->eng.mem.alloc_pinned(&h->stage_i16, h->cap);
         if (!rc) rc = h->eng.mem.alloc_pinned(&h->stage_f32, (size_t)h->cap * n_labels);
         if (!rc) rc = h->eng.mem.alloc_pinned(&h->stage_n, 1);
+        if (!rc) rc = h->eng.mem.alloc_pinned(&h->map_pin, h->cap);
         if (rc) {
             h->eng.destroy();
             delete h;
@@ -482,6 +485,8 @@ int lccrf_create(lccrf_handle *out, int device_id, int n_points, int n_labels)
     }
     h->N = n_points;
     h->eng.activeN = n_points;
+    h->eng.crf.map = h->map_pin;
+    h->label_stage_busy = false;    // a parked engine's stream is idle (recycle() synchronised it)
     h->eng.sync_views();
     *h->stage_n = n_points;
     hipError_t e = hipMemcpyAsync(h->eng.npoints_own, h->stage_n, sizeof(int), hipMemcpyHostToDevice, h->eng.stream);
@@ -553,16 +558,20 @@ int lccrf_set_unary_from_label(lccrf_handle h, const int16_t *label, const float
     if ((!label && h->N) || !conf) return fail(LCCRF_E_INVALID, "label/conf is NULL");
     Engine &e = h->eng;
     if (e.L < 2) return fail(LCCRF_E_INVALID, "setUnaryEnergyFromLabel needs >= 2 labels");
-    HIP_TRY(hipStreamSynchronize(e.stream));
-    int rc = e.set_unary_from_label_tables(conf);
-    if (rc) return rc;
-    if (h->N) {
-        memcpy(h->stage_i16, label, (size_t)h->N * sizeof(int16_t));
-        HIP_TRY(hipMemcpyAsync(e.label_own, h->stage_i16, (size_t)h->N * sizeof(int16_t), hipMemcpyHostToDevice, e.stream));
+    if (h->label_stage_busy) HIP_TRY(hipStreamSynchronize(e.stream));   // an earlier call's kernel may still read the staging buffer
+    // No uploads: the 2L+1 energies travel as a kernel argument and the kernel reads the labels from
+    // pinned host memory (each tiny DMA command costs ~10 us of stream time; this path is latency-bound).
+    UnaryTable tb;                                        // densecrf3d.h:109-115, logf: see set_unary_from_label_tables
+    tb.v[0] = -logf(1.0f / e.L);
+    for (int i = 0; i < e.L; ++i) {
+        tb.v[1 + i] = -logf((1.0f - conf[i]) / (e.L - 1));
+        tb.v[1 + e.L + i] = -logf(conf[i]);
     }
+    if (h->N) memcpy(h->stage_i16, label, (size_t)h->N * sizeof(int16_t));
     e.crf.unary = e.unary_own;
-    launch_unary_from_label(e.crf, e.label_own, e.tbl, e.stream);
+    launch_unary_from_label_tbl(e.crf, h->stage_i16, tb, e.stream);
     HIP_TRY(hipGetLastError());
+    h->label_stage_busy = true;
     e.unary_set = true;
     return LCCRF_OK;
 }
@@ -577,10 +586,10 @@ int lccrf_add_pairwise(lccrf_handle h, const float *features, int d, float w)
     const int k = (int)e.kernels.size() - 1;
     KernelState &ks = e.kernels[k];
     const size_t n = (size_t)h->N * d;
-    if (n) {
-        memcpy(ks.feat_stage, features, n * sizeof(float));   // caller may free `features` right away
-        HIP_TRY(hipMemcpyAsync(ks.feat_own, ks.feat_stage, n * sizeof(float), hipMemcpyHostToDevice, e.stream));
-    }
+    if (n) memcpy(ks.feat_stage, features, n * sizeof(float));   // caller may free `features` right away
+    // the build reads the features once, straight from this pinned buffer (no upload command)
+    ks.dev.feat = ks.feat_stage;
+    e.sync_views();
     // The lattice is built lazily, together with any other pending kernel, by the first call that
     // needs it (inference, a step, a parity probe): one launch builds all of them side by side.
     (void)k;
@@ -644,9 +653,8 @@ int lccrf_get_map(lccrf_handle h, int16_t *map_out)
     CHECK_H(h);
     if (!map_out && h->N) return fail(LCCRF_E_INVALID, "map_out is NULL");
     Engine &e = h->eng;
-    if (h->N) HIP_TRY(hipMemcpyAsync(h->stage_i16, e.crf.map, (size_t)h->N * sizeof(int16_t), hipMemcpyDeviceToHost, e.stream));
     HIP_TRY(hipStreamSynchronize(e.stream));
-    if (h->N) memcpy(map_out, h->stage_i16, (size_t)h->N * sizeof(int16_t));
+    if (h->N) memcpy(map_out, h->map_pin, (size_t)h->N * sizeof(int16_t));   // written there by the kernels
     return LCCRF_OK;
 }
 

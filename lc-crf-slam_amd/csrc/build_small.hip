@@ -169,7 +169,10 @@ __global__ void __launch_bounds__(kBT) k_build_small(KernelDev kd0, KernelDev kd
     // ---- 3: dense vertex ids = exclusive scan of "first occurrence" flags in entry order -----
     const int V = block_scan(
         live, [&](int e) { return (int)(slot[sof[e]] == e); }, [&](int e, int x) { pfx[e] = (unsigned short)x; });
-    if (tid == 0) kd.V[f] = V;
+    if (tid == 0) {
+        kd.V[f] = V;
+        if (kd.V_host) kd.V_host[f] = V;                 // straight into pinned host memory: no read-back copy
+    }
     __syncthreads();
     BSTAMP(3);
 
@@ -356,7 +359,10 @@ __global__ void __launch_bounds__(kBT) k_build_small(KernelDev kd0, KernelDev kd
         kd.csr_pt[fe + p] = pts[p];
         kd.csr_w[fe + p] = wsorted[p];
     }
-    if (tid == 0) kd.rowmax[f] = rowmax_s;
+    if (tid == 0) {
+        kd.rowmax[f] = rowmax_s;
+        if (kd.rowmax_host) kd.rowmax_host[f] = rowmax_s;
+    }
     __syncthreads();
     BSTAMP(7);
 

@@ -53,6 +53,7 @@ struct KernelDev {
     // compact copies for the fused engine's prologue (frames with Epad < 65535 only; undefined otherwise)
     unsigned *pk;         // [F][Epad]         (offset + 1) | csr_pos << 16 of every real entry
     unsigned *nbr16;      // [F][D1][Epad]     (n1 + 1) | (n2 + 1) << 16 per (axis, vertex), 0 = absent
+    int *V_host, *rowmax_host;   // [F] pinned host mirrors of V / rowmax written by the fused build (or null)
     float *norm;          // [F][maxN]         1/(K*1 + 1e-20)  (PottsPotential3D::norm_)
     float *val0, *val1;   // [F][vstride]      lattice values (see vbase)
 };
@@ -72,6 +73,9 @@ struct CrfDev {
 void launch_build_kernel(const KernelDev &kd, const CrfDev &c, int maxV_hint, hipStream_t s);
 void launch_norm(const KernelDev &kd, const CrfDev &c, int maxV, hipStream_t s);
 void launch_unary_from_label(const CrfDev &c, const int16_t *label, const float *tbl, hipStream_t s);
+// same, with the 2L+1 energies passed by value (no table upload; `label` may be pinned host memory)
+struct UnaryTable { float v[2 * LCCRF_MAX_LABELS + 1]; };
+void launch_unary_from_label_tbl(const CrfDev &c, const int16_t *label, const UnaryTable &tbl, hipStream_t s);
 void launch_start(const CrfDev &c, hipStream_t s);
 void launch_step_stream(const CrfDev &c, const KernelDev *kds, const int *maxV, float relax,
                         hipStream_t s);

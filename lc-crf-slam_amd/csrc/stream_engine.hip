@@ -417,6 +417,19 @@ __global__ void __launch_bounds__(kBlock) k_unary_from_label(CrfDev c, const int
     c.unary[((size_t)f * c.maxN + i) * c.L + m] = u;
 }
 
+__global__ void __launch_bounds__(kBlock) k_unary_from_label_tbl(CrfDev c, const int16_t *__restrict__ label, UnaryTable tbl)
+{
+    const int f = blockIdx.y;
+    const int idx = blockIdx.x * kBlock + threadIdx.x;
+    if (idx >= c.n_points[f] * c.L) return;
+    const int i = idx / c.L, m = idx - i * c.L;
+    const int t = label[(size_t)f * c.maxN + i];
+    float u;
+    if (t < 0 || t >= c.L) u = tbl.v[0];
+    else u = (m == t) ? tbl.v[1 + c.L + t] : tbl.v[1 + t];
+    c.unary[((size_t)f * c.maxN + i) * c.L + m] = u;
+}
+
 // out = softmax_fe(scale * in) (blended with the old out when relax != 1).
 __global__ void __launch_bounds__(kBlock) k_softmax(CrfDev c, const float *__restrict__ in,
                                                     float *__restrict__ out, float scale, float relax)
@@ -500,6 +513,11 @@ void launch_norm(const KernelDev &kd, const CrfDev &c, int maxV, hipStream_t s)
 void launch_unary_from_label(const CrfDev &c, const int16_t *label, const float *tbl, hipStream_t s)
 {
     k_unary_from_label<<<grid_for((long)c.maxN * c.L, c.F), kBlock, 0, s>>>(c, label, tbl);
+}
+
+void launch_unary_from_label_tbl(const CrfDev &c, const int16_t *label, const UnaryTable &tbl, hipStream_t s)
+{
+    k_unary_from_label_tbl<<<grid_for((long)c.maxN * c.L, c.F), kBlock, 0, s>>>(c, label, tbl);
 }
 
 void launch_start(const CrfDev &c, hipStream_t s)   // densecrf_base.h:78-80
