@@ -203,6 +203,23 @@ int  lccrf_unary_build(int device_id, int n_points, const float *Xw, const int32
                        const lccrf_crf_params *params, float *observs_out, float *error_out,
                        float *depth_out, int16_t *label_out);
 
+/* ======================================================================================
+ * 4. Static-feature matcher (another "next" row)
+ *
+ * Tracking::BfMatch (src/Tracking.cc:1747-1766): cv::BFMatcher(NORM_HAMMING).knnMatch(k = 2)
+ * of the current frame's ORB descriptors (query) against a frame 15 frames back (train), kept
+ * when `match[0].distance < match[1].distance * 0.6`.  Host arrays in, host arrays out:
+ *   desc_query [n_query][32], desc_train [n_train][32]   256-bit ORB descriptors (Frame::mDescriptors rows)
+ *   ratio                                                0.6 in the reference
+ *   train_of_query_out [n_query]                         asso[fid1] = fid2 of :1762, or -1 (no entry)
+ *   n_matches_out                                        asso.size(), may be NULL
+ * Ties follow OpenCV's batchDistance: the two nearest are the two smallest (distance, train
+ * index) pairs.  Parity is unpinned (no OpenCV here); exact against the oracle's restatement.
+ * Fewer than two train descriptors give no matches (match.size() != 2).                    */
+int  lccrf_bf_match(int device_id, int n_query, const uint8_t *desc_query, int n_train,
+                    const uint8_t *desc_train, double ratio, int32_t *train_of_query_out,
+                    int32_t *n_matches_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -107,6 +107,7 @@ def lib():
     L.lccrf_batch_set_engine.argtypes = [vp, C.c_int]
     L.lccrf_batch_get_engine.argtypes = [vp, C.POINTER(C.c_int)]
     L.lccrf_batch_last_timing.argtypes = [vp, _f32p, _f32p]
+    L.lccrf_bf_match.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_double, _i32p, _i32p]
     L.lccrf_default_params.argtypes = [C.POINTER(CrfParams)]
     L.lccrf_default_params.restype = None
     L.lccrf_unary_build.argtypes = [C.c_int, C.c_int, _f32p, _i32p, _i32p, C.POINTER(C.c_double), C.c_int, _f32p,
@@ -367,3 +368,15 @@ def unary_build(Xw, obs_ptr, obs_kf, obs_kp, kf_pose, kf_intr, kf_bounds, match_
                                    _p(intr, _f32p), _p(bnd, _f32p), mp, C.byref(params), _p(obs, _f32p),
                                    _p(err, _f32p), _p(dep, _f32p), _p(lab, _i16p)))
     return obs, err, dep, lab
+
+
+def bf_match(desc_query, desc_train, ratio=0.6, device=0):
+    """Tracking::BfMatch on the GPU (src/Tracking.cc:1747-1766; include/lccrf.h section 4):
+    train index per query or -1, and the number of matches."""
+    q = np.ascontiguousarray(desc_query, np.uint8).reshape(-1, 32)
+    t = np.ascontiguousarray(desc_train, np.uint8).reshape(-1, 32)
+    out = np.empty(q.shape[0], np.int32)
+    nm = np.zeros(1, np.int32)
+    _check(lib().lccrf_bf_match(int(device), q.shape[0], q.ctypes.data, t.shape[0], t.ctypes.data, float(ratio),
+                                _p(out, _i32p), _p(nm, _i32p)))
+    return out, int(nm[0])

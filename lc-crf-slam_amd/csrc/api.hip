@@ -1001,6 +1001,21 @@ int lccrf_unary_build(int device_id, int n_points, const float *Xw, const int32_
     return LCCRF_OK;
 }
 
+int lccrf_bf_match(int device_id, int n_query, const uint8_t *desc_query, int n_train, const uint8_t *desc_train,
+                   double ratio, int32_t *train_of_query_out, int32_t *n_matches_out)
+{
+    if (n_query < 0 || n_train < 0) return fail(LCCRF_E_INVALID, "negative size");
+    if (n_train >= (1 << 22)) return fail(LCCRF_E_CAPACITY, "at most %d train descriptors", (1 << 22) - 1);
+    if ((n_query && (!desc_query || !train_of_query_out)) || (n_train && !desc_train))
+        return fail(LCCRF_E_INVALID, "NULL descriptor / output array");
+    if (!(ratio >= 0.0)) return fail(LCCRF_E_INVALID, "ratio must be >= 0");
+    int rc = use_device(device_id);
+    if (rc) return rc;
+    hipError_t e = run_bf_match(device_id, n_query, desc_query, n_train, desc_train, ratio, train_of_query_out, n_matches_out);
+    if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? LCCRF_E_NOMEM : LCCRF_E_HIP, "bf_match: %s", hipGetErrorString(e));
+    return LCCRF_OK;
+}
+
 int lccrf_batch_last_timing(lccrf_batch_handle b, float *inference_ms, float *build_ms)
 {
     CHECK_H(b);

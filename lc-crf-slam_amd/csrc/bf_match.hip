@@ -1,0 +1,135 @@
+// bf_match.hip -- Tracking::BfMatch (src/Tracking.cc:1747-1766): brute-force Hamming 2-nearest-
+// neighbour matching of two frames' ORB descriptors with the 0.6 ratio test.
+//
+// The reference calls cv::BFMatcher(NORM_HAMMING).knnMatch(query, train, k = 2) and keeps query q
+// when `match[0].distance < match[1].distance * 0.6` (float distance against a double product).
+// OpenCV is absent from /root/reference (third-party, 3.x per CMakeLists.txt:31); its published
+// behaviour is restated: cv::batchDistance keeps, per query, the K smallest distances in ascending
+// order and inserts a candidate only where it is strictly smaller, scanning the train set in index
+// order -- i.e. the two smallest (distance, train index) pairs in lexicographic order.  Integer-only
+// apart from the one double comparison, so results are exact.  PARITY UNPINNED against a real OpenCV
+// build; checked against the oracle's scalar restatement (oracle/lccrf_oracle.c: orc_bf_match).
+//
+// Layout: 4 lanes per query, each scanning a quarter of the train descriptors staged in LDS in
+// tiles; candidates are (distance << 22 | train index) keys, so "lexicographically smaller" is one
+// unsigned compare and the four partial top-2 lists merge with two shuffles.
+#include "engine.h"
+
+#include <mutex>
+
+namespace lccrf {
+
+namespace {
+
+constexpr int kQPB = 64;                  // queries per block (x 4 lanes)
+constexpr int kTile = 1024;               // train descriptors per LDS tile (32 KB)
+constexpr unsigned kNone = 0xffffffffu;
+
+__device__ __forceinline__ void top2_insert(unsigned key, unsigned &k0, unsigned &k1)
+{
+    if (key < k0) { k1 = k0; k0 = key; }
+    else if (key < k1) k1 = key;
+}
+
+__global__ void __launch_bounds__(kQPB * 4) k_bf_match(const uint4 *__restrict__ query, int n_query,
+                                                        const uint4 *__restrict__ train, int n_train, double ratio,
+                                                        int *__restrict__ out, int *__restrict__ n_matches)
+{
+    __shared__ uint4 tile[kTile * 2];
+    const int tid = threadIdx.x, sub = tid & 3;
+    const int q = blockIdx.x * kQPB + (tid >> 2);
+    uint4 qa = make_uint4(0, 0, 0, 0), qb = qa;
+    if (q < n_query) { qa = query[2 * (size_t)q]; qb = query[2 * (size_t)q + 1]; }
+    unsigned k0 = kNone, k1 = kNone;
+    for (int t0 = 0; t0 < n_train; t0 += kTile) {
+        const int nt = min(kTile, n_train - t0);
+        __syncthreads();
+        for (int i = tid; i < 2 * nt; i += kQPB * 4) tile[i] = train[2 * (size_t)t0 + i];
+        __syncthreads();
+        for (int t = sub; t < nt; t += 4) {
+            const uint4 a = tile[2 * t], b = tile[2 * t + 1];
+            const int d = __popc(qa.x ^ a.x) + __popc(qa.y ^ a.y) + __popc(qa.z ^ a.z) + __popc(qa.w ^ a.w) +
+                          __popc(qb.x ^ b.x) + __popc(qb.y ^ b.y) + __popc(qb.z ^ b.z) + __popc(qb.w ^ b.w);
+            top2_insert(((unsigned)d << 22) | (unsigned)(t0 + t), k0, k1);
+        }
+    }
+    // merge the four lanes of a query (xor 1, xor 2)
+#pragma unroll
+    for (int o = 1; o <= 2; o <<= 1) {
+        const unsigned p0 = (unsigned)__shfl_xor((int)k0, o), p1 = (unsigned)__shfl_xor((int)k1, o);
+        top2_insert(p0, k0, k1);
+        top2_insert(p1, k0, k1);
+    }
+    if (q < n_query && sub == 0) {
+        int m = -1;
+        if (k1 != kNone) {                                // match.size() == 2
+            const double d0 = (double)(float)(k0 >> 22), d1 = (double)(float)(k1 >> 22);
+            if (d0 < d1 * ratio) m = (int)(k0 & 0x3fffffu);   // Tracking.cc:1755
+        }
+        out[q] = m;
+        if (m >= 0) atomicAdd(n_matches, 1);
+    }
+}
+
+struct Scratch {
+    std::mutex m;
+    void *q = nullptr, *t = nullptr;
+    int *out = nullptr;
+    size_t cq = 0, ct = 0, co = 0;
+    int device = -1;
+    hipStream_t stream = nullptr;
+} g_bf;
+
+hipError_t grow(void **p, size_t *cap, size_t bytes)
+{
+    if (*cap >= bytes) return hipSuccess;
+    if (*p) (void)hipFree(*p);
+    *p = nullptr;
+    *cap = 0;
+    const hipError_t e = hipMalloc(p, bytes + bytes / 2 + 256);
+    if (e == hipSuccess) *cap = bytes + bytes / 2 + 256;
+    return e;
+}
+
+}  // namespace
+
+hipError_t run_bf_match(int device_id, int n_query, const uint8_t *desc_query, int n_train, const uint8_t *desc_train,
+                        double ratio, int32_t *train_of_query_out, int32_t *n_matches_out)
+{
+    std::lock_guard<std::mutex> g(g_bf.m);
+    hipError_t e;
+    if (g_bf.device != device_id) {                       // scratch belongs to one device at a time
+        if (g_bf.q) (void)hipFree(g_bf.q);
+        if (g_bf.t) (void)hipFree(g_bf.t);
+        if (g_bf.out) (void)hipFree(g_bf.out);
+        if (g_bf.stream) (void)hipStreamDestroy(g_bf.stream);
+        g_bf.q = g_bf.t = nullptr;
+        g_bf.out = nullptr;
+        g_bf.cq = g_bf.ct = g_bf.co = 0;
+        g_bf.stream = nullptr;
+        g_bf.device = device_id;
+    }
+    if (!g_bf.stream && (e = hipStreamCreateWithFlags(&g_bf.stream, hipStreamNonBlocking)) != hipSuccess) return e;
+    hipStream_t s = g_bf.stream;
+    const size_t bq = (size_t)n_query * 32, bt = (size_t)n_train * 32, bo = ((size_t)n_query + 1) * sizeof(int);
+    if ((e = grow(&g_bf.q, &g_bf.cq, bq + 32)) != hipSuccess) return e;
+    if ((e = grow(&g_bf.t, &g_bf.ct, bt + 32)) != hipSuccess) return e;
+    if ((e = grow(reinterpret_cast<void **>(&g_bf.out), &g_bf.co, bo)) != hipSuccess) return e;
+    if (bq && (e = hipMemcpyAsync(g_bf.q, desc_query, bq, hipMemcpyHostToDevice, s)) != hipSuccess) return e;
+    if (bt && (e = hipMemcpyAsync(g_bf.t, desc_train, bt, hipMemcpyHostToDevice, s)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(g_bf.out + n_query, 0, sizeof(int), s)) != hipSuccess) return e;
+    if (n_query > 0) {
+        k_bf_match<<<dim3((n_query + kQPB - 1) / kQPB), dim3(kQPB * 4), 0, s>>>(
+            reinterpret_cast<const uint4 *>(g_bf.q), n_query, reinterpret_cast<const uint4 *>(g_bf.t), n_train, ratio,
+            g_bf.out, g_bf.out + n_query);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+        if ((e = hipMemcpyAsync(train_of_query_out, g_bf.out, (size_t)n_query * sizeof(int), hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
+    }
+    int nm = 0;
+    if ((e = hipMemcpyAsync(&nm, g_bf.out + n_query, sizeof(int), hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
+    if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;
+    if (n_matches_out) *n_matches_out = nm;
+    return hipSuccess;
+}
+
+}  // namespace lccrf

@@ -97,4 +97,8 @@ hipError_t run_unary_build(int device_id, int n_points, const float *Xw, const i
                            const float *kf_bounds, const double *match_prob, const lccrf_crf_params *params,
                            float *observs_out, float *error_out, float *depth_out, int16_t *label_out);
 
+// ---- BfMatch (src/Tracking.cc:1747-1766), csrc/bf_match.hip -------------------------------
+hipError_t run_bf_match(int device_id, int n_query, const uint8_t *desc_query, int n_train, const uint8_t *desc_train,
+                        double ratio, int32_t *train_of_query_out, int32_t *n_matches_out);
+
 }  // namespace lccrf

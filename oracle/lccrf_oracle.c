@@ -629,3 +629,30 @@ void orc_unary_build(int n_points, const float *Xw, const int32_t *obs_ptr, cons
         free(poses); free(intr); free(bnd);
     }
 }
+
+/* Tracking::BfMatch, ref: src/Tracking.cc:1747-1766.  cv::BFMatcher(NORM_HAMMING).knnMatch(k = 2) is a
+ * third-party dependency absent from /root/reference (OpenCV 3.x): restated from its published
+ * behaviour -- cv::batchDistance scans the train set in index order and inserts a candidate into the
+ * ascending top-K list only where it is strictly smaller, so ties keep the lower train index first. */
+void orc_bf_match(int n_query, const uint8_t *desc_query, int n_train, const uint8_t *desc_train, double ratio,
+                  int32_t *train_of_query, int32_t *n_matches)
+{
+    int nm = 0;
+    for (int q = 0; q < n_query; q++) {
+        int d0 = INT_MAX, d1 = INT_MAX, i0 = -1, i1 = -1;
+        for (int t = 0; t < n_train; t++) {
+            int d = 0;
+            for (int b = 0; b < 32; b++) d += __builtin_popcount((unsigned)(desc_query[32 * (size_t)q + b] ^ desc_train[32 * (size_t)t + b]));
+            if (d < d1) {                                 /* insert before the first strictly greater element */
+                if (d < d0) { d1 = d0; i1 = i0; d0 = d; i0 = t; }
+                else { d1 = d; i1 = t; }
+            }
+        }
+        (void)i1;
+        int m = -1;
+        if (n_train >= 2 && (double)(float)d0 < (double)(float)d1 * ratio) m = i0;    /* :1755, match.size() == 2 */
+        train_of_query[q] = m;
+        nm += m >= 0;
+    }
+    if (n_matches) *n_matches = nm;
+}

@@ -15,8 +15,8 @@
  *     tests/golden/, and reproduces the reference's own known-answer image
  *     Thirdparty/DenseCRF/examples/res1_cpu.ppm byte for byte
  *     (tests/test_oracle_golden.py).
- *   - rows a2, a3 (Tracking::ComputeMapPointErrAndObserv, RroughClassify):
- *     PARITY UNPINNED.  src/Tracking.cc needs OpenCV/Eigen/g2o, which this
+ *   - rows a2, a3 (Tracking::ComputeMapPointErrAndObserv, RroughClassify) and
+ *     Tracking::BfMatch: PARITY UNPINNED.  src/Tracking.cc needs OpenCV/Eigen/g2o, which this
  *     image lacks, and the reference holds no test or fixture for them; the
  *     restatement follows Tracking.cc:1803-1839 and :1961-2013 literally and
  *     is checked only against hand-derived known answers.
@@ -120,6 +120,10 @@ void orc_unary_build(int n_points, const float *Xw, const int32_t *obs_ptr, cons
                      const double *obs_kp, const float *kf_pose, const float *kf_intr, const float *kf_bounds,
                      const double *match_prob, const orc_crf_params *p, float *observs, float *error,
                      float *depth, int16_t *label);
+
+/* Tracking.cc:1747-1766 (BfMatch): train index per query or -1; OpenCV's knnMatch tie rule restated. */
+void orc_bf_match(int n_query, const uint8_t *desc_query, int n_train, const uint8_t *desc_train, double ratio,
+                  int32_t *train_of_query, int32_t *n_matches);
 
 #ifdef __cplusplus
 }

@@ -98,6 +98,7 @@ def oracle_lib():
             C.POINTER(C.c_int), _f32p, _f32p]
         lib.orc_unary_build.argtypes = [C.c_int, _f32p, _i32p, _i32p, C.POINTER(C.c_double), _f32p, _f32p, _f32p,
                                         C.POINTER(C.c_double), C.POINTER(CrfParams), _f32p, _f32p, _f32p, _i16p]
+        lib.orc_bf_match.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_double, _i32p, _i32p]
         _olib = lib
     return _olib
 
@@ -392,3 +393,14 @@ def oracle_unary_build(Xw, obs_ptr, obs_kf, obs_kp, kf_pose, kf_intr, kf_bounds,
                         _ptr(bnd, _f32p), mp, C.byref(params), _ptr(obs, _f32p), _ptr(err, _f32p),
                         _ptr(dep, _f32p), _ptr(lab, _i16p))
     return obs, err, dep, lab
+
+
+def oracle_bf_match(desc_query, desc_train, ratio=0.6):
+    """Tracking::BfMatch (oracle): train index per query or -1, and the number of matches."""
+    lib = oracle_lib()
+    q = np.ascontiguousarray(desc_query, np.uint8).reshape(-1, 32)
+    t = np.ascontiguousarray(desc_train, np.uint8).reshape(-1, 32)
+    out = np.empty(q.shape[0], np.int32)
+    nm = np.zeros(1, np.int32)
+    lib.orc_bf_match(q.shape[0], q.ctypes.data, t.shape[0], t.ctypes.data, float(ratio), _ptr(out, _i32p), _ptr(nm, _i32p))
+    return out, int(nm[0])
