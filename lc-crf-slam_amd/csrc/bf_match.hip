@@ -15,6 +15,7 @@
 // unsigned compare and the four partial top-2 lists merge with two shuffles.
 #include "engine.h"
 
+#include <cstring>
 #include <mutex>
 
 namespace lccrf {
@@ -71,25 +72,15 @@ __global__ void __launch_bounds__(kQPB * 4) k_bf_match(const uint4 *__restrict__
     }
 }
 
+// one pinned host arena (query | train | results | count) and one device buffer for the descriptors:
+// one upload command per call, results written by the kernel straight into pinned host memory
 struct Scratch {
     std::mutex m;
-    void *q = nullptr, *t = nullptr;
-    int *out = nullptr;
-    size_t cq = 0, ct = 0, co = 0;
+    unsigned char *host = nullptr, *dev = nullptr;
+    size_t host_cap = 0, dev_cap = 0;
     int device = -1;
     hipStream_t stream = nullptr;
 } g_bf;
-
-hipError_t grow(void **p, size_t *cap, size_t bytes)
-{
-    if (*cap >= bytes) return hipSuccess;
-    if (*p) (void)hipFree(*p);
-    *p = nullptr;
-    *cap = 0;
-    const hipError_t e = hipMalloc(p, bytes + bytes / 2 + 256);
-    if (e == hipSuccess) *cap = bytes + bytes / 2 + 256;
-    return e;
-}
 
 }  // namespace
 
@@ -98,37 +89,47 @@ hipError_t run_bf_match(int device_id, int n_query, const uint8_t *desc_query, i
 {
     std::lock_guard<std::mutex> g(g_bf.m);
     hipError_t e;
-    if (g_bf.device != device_id) {                       // scratch belongs to one device at a time
-        if (g_bf.q) (void)hipFree(g_bf.q);
-        if (g_bf.t) (void)hipFree(g_bf.t);
-        if (g_bf.out) (void)hipFree(g_bf.out);
+    if (g_bf.device != device_id) {                       // the staging belongs to one device at a time
+        if (g_bf.host) (void)hipHostFree(g_bf.host);
+        if (g_bf.dev) (void)hipFree(g_bf.dev);
         if (g_bf.stream) (void)hipStreamDestroy(g_bf.stream);
-        g_bf.q = g_bf.t = nullptr;
-        g_bf.out = nullptr;
-        g_bf.cq = g_bf.ct = g_bf.co = 0;
+        g_bf.host = g_bf.dev = nullptr;
+        g_bf.host_cap = g_bf.dev_cap = 0;
         g_bf.stream = nullptr;
         g_bf.device = device_id;
     }
     if (!g_bf.stream && (e = hipStreamCreateWithFlags(&g_bf.stream, hipStreamNonBlocking)) != hipSuccess) return e;
     hipStream_t s = g_bf.stream;
-    const size_t bq = (size_t)n_query * 32, bt = (size_t)n_train * 32, bo = ((size_t)n_query + 1) * sizeof(int);
-    if ((e = grow(&g_bf.q, &g_bf.cq, bq + 32)) != hipSuccess) return e;
-    if ((e = grow(&g_bf.t, &g_bf.ct, bt + 32)) != hipSuccess) return e;
-    if ((e = grow(reinterpret_cast<void **>(&g_bf.out), &g_bf.co, bo)) != hipSuccess) return e;
-    if (bq && (e = hipMemcpyAsync(g_bf.q, desc_query, bq, hipMemcpyHostToDevice, s)) != hipSuccess) return e;
-    if (bt && (e = hipMemcpyAsync(g_bf.t, desc_train, bt, hipMemcpyHostToDevice, s)) != hipSuccess) return e;
-    if ((e = hipMemsetAsync(g_bf.out + n_query, 0, sizeof(int), s)) != hipSuccess) return e;
-    if (n_query > 0) {
-        k_bf_match<<<dim3((n_query + kQPB - 1) / kQPB), dim3(kQPB * 4), 0, s>>>(
-            reinterpret_cast<const uint4 *>(g_bf.q), n_query, reinterpret_cast<const uint4 *>(g_bf.t), n_train, ratio,
-            g_bf.out, g_bf.out + n_query);
-        if ((e = hipGetLastError()) != hipSuccess) return e;
-        if ((e = hipMemcpyAsync(train_of_query_out, g_bf.out, (size_t)n_query * sizeof(int), hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
+    if (n_matches_out) *n_matches_out = 0;
+    if (n_query <= 0) return hipSuccess;
+    const size_t bq = (size_t)n_query * 32, bt = (size_t)n_train * 32, bo = ((size_t)n_query + 2) * sizeof(int);
+    const size_t total_in = bq + bt, total = total_in + bo;
+    if (g_bf.host_cap < total) {
+        if (g_bf.host) (void)hipHostFree(g_bf.host);
+        g_bf.host = nullptr;
+        g_bf.host_cap = 0;
+        if ((e = hipHostMalloc(reinterpret_cast<void **>(&g_bf.host), total + total / 2 + 4096, hipHostMallocDefault)) != hipSuccess) return e;
+        g_bf.host_cap = total + total / 2 + 4096;
     }
-    int nm = 0;
-    if ((e = hipMemcpyAsync(&nm, g_bf.out + n_query, sizeof(int), hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
+    if (g_bf.dev_cap < total_in + 64) {
+        if (g_bf.dev) (void)hipFree(g_bf.dev);
+        g_bf.dev = nullptr;
+        g_bf.dev_cap = 0;
+        if ((e = hipMalloc(reinterpret_cast<void **>(&g_bf.dev), total_in + total_in / 2 + 4096)) != hipSuccess) return e;
+        g_bf.dev_cap = total_in + total_in / 2 + 4096;
+    }
+    memcpy(g_bf.host, desc_query, bq);
+    if (bt) memcpy(g_bf.host + bq, desc_train, bt);
+    int *out = reinterpret_cast<int *>(g_bf.host + total_in);
+    out[n_query] = 0;                                     // the match counter (host write, visible to the kernel launched below)
+    if ((e = hipMemcpyAsync(g_bf.dev, g_bf.host, total_in, hipMemcpyHostToDevice, s)) != hipSuccess) return e;
+    k_bf_match<<<dim3((n_query + kQPB - 1) / kQPB), dim3(kQPB * 4), 0, s>>>(
+        reinterpret_cast<const uint4 *>(g_bf.dev), n_query, reinterpret_cast<const uint4 *>(g_bf.dev + bq), n_train, ratio,
+        out, out + n_query);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
     if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;
-    if (n_matches_out) *n_matches_out = nm;
+    memcpy(train_of_query_out, out, (size_t)n_query * sizeof(int));
+    if (n_matches_out) *n_matches_out = out[n_query];
     return hipSuccess;
 }
 

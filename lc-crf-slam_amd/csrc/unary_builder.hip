@@ -21,6 +21,7 @@
 // exactly on the threshold.
 #include "engine.h"
 
+#include <cstring>
 #include <mutex>
 
 namespace lccrf {
@@ -95,24 +96,26 @@ __global__ void __launch_bounds__(256) k_unary_build(UnaryArgs a)
     a.label[i] = n_obs > 0 ? lab : (int16_t)-1;           // the caller drops points without observations, :1858
 }
 
-// grow-only device scratch per device, shared by all calls (guarded by a mutex)
+// Grow-only staging shared by all calls (guarded by a mutex): ONE pinned host arena that holds the
+// packed inputs followed by the outputs, ONE device buffer for the inputs.  A call costs one
+// host-side pack, one upload command, one kernel that writes its results straight into the pinned
+// arena, one stream synchronise (each separate small copy would add ~10 us of stream time).
 struct Scratch {
     std::mutex m;
-    void *buf[16] = {nullptr};
-    size_t cap[16] = {0};
+    unsigned char *host = nullptr, *dev = nullptr;
+    size_t host_cap = 0, dev_cap = 0;
     int device = -1;
     hipStream_t stream = nullptr;
 } g_scratch;
 
-hipError_t ensure(int slot, size_t bytes)
+void release_scratch()
 {
-    if (g_scratch.cap[slot] >= bytes) return hipSuccess;
-    if (g_scratch.buf[slot]) (void)hipFree(g_scratch.buf[slot]);
-    g_scratch.cap[slot] = 0;
-    const size_t want = bytes + bytes / 2 + 256;
-    hipError_t e = hipMalloc(&g_scratch.buf[slot], want);
-    if (e == hipSuccess) g_scratch.cap[slot] = want;
-    return e;
+    if (g_scratch.host) (void)hipHostFree(g_scratch.host);
+    if (g_scratch.dev) (void)hipFree(g_scratch.dev);
+    if (g_scratch.stream) (void)hipStreamDestroy(g_scratch.stream);
+    g_scratch.host = g_scratch.dev = nullptr;
+    g_scratch.host_cap = g_scratch.dev_cap = 0;
+    g_scratch.stream = nullptr;
 }
 
 }  // namespace
@@ -125,52 +128,63 @@ hipError_t run_unary_build(int device_id, int n_points, const float *Xw, const i
 {
     std::lock_guard<std::mutex> g(g_scratch.m);
     hipError_t e;
-    if (g_scratch.device != device_id) {                  // scratch belongs to one device at a time
-        for (int i = 0; i < 16; ++i) {
-            if (g_scratch.buf[i]) (void)hipFree(g_scratch.buf[i]);
-            g_scratch.buf[i] = nullptr;
-            g_scratch.cap[i] = 0;
-        }
-        if (g_scratch.stream) (void)hipStreamDestroy(g_scratch.stream);
-        g_scratch.stream = nullptr;
+    if (g_scratch.device != device_id) {                  // the staging belongs to one device at a time
+        release_scratch();
         g_scratch.device = device_id;
     }
     if (!g_scratch.stream && (e = hipStreamCreateWithFlags(&g_scratch.stream, hipStreamNonBlocking)) != hipSuccess) return e;
     hipStream_t s = g_scratch.stream;
-    const size_t n = (size_t)n_points, n_obs = n ? (size_t)obs_ptr[n_points] : 0;
-    const size_t sz[12] = {n * 3 * sizeof(float), (n + 1) * sizeof(int), n_obs * sizeof(int), n_obs * 2 * sizeof(double),
-                           (size_t)n_kf * 12 * sizeof(float), (size_t)n_kf * 4 * sizeof(float),
-                           (size_t)n_kf * 4 * sizeof(float), match_prob ? n * sizeof(double) : 0,
-                           n * sizeof(float), n * sizeof(float), n * sizeof(float), n * sizeof(int16_t)};
-    const void *src[8] = {Xw, obs_ptr, obs_kf, obs_kp, kf_pose, kf_intr, kf_bounds, match_prob};
-    for (int i = 0; i < 12; ++i)
-        if ((e = ensure(i, sz[i] + 16)) != hipSuccess) return e;
+    if (n_points <= 0) return hipSuccess;
+    const size_t n = (size_t)n_points, n_obs = (size_t)obs_ptr[n_points];
+    // input blocks (8-byte aligned offsets), then output blocks
+    const size_t in_sz[8] = {n_obs * 2 * sizeof(double), match_prob ? n * sizeof(double) : 0, n * 3 * sizeof(float),
+                             (n + 1) * sizeof(int), n_obs * sizeof(int), (size_t)n_kf * 12 * sizeof(float),
+                             (size_t)n_kf * 4 * sizeof(float), (size_t)n_kf * 4 * sizeof(float)};
+    const void *in_src[8] = {obs_kp, match_prob, Xw, obs_ptr, obs_kf, kf_pose, kf_intr, kf_bounds};
+    size_t in_off[8], total_in = 0;
+    for (int i = 0; i < 8; ++i) { in_off[i] = total_in; total_in += (in_sz[i] + 7) & ~(size_t)7; }
+    const size_t out_sz[4] = {n * sizeof(float), n * sizeof(float), n * sizeof(float), n * sizeof(int16_t)};
+    size_t out_off[4], total = total_in;
+    for (int i = 0; i < 4; ++i) { out_off[i] = total; total += (out_sz[i] + 7) & ~(size_t)7; }
+    if (g_scratch.host_cap < total) {
+        if (g_scratch.host) (void)hipHostFree(g_scratch.host);
+        g_scratch.host = nullptr;
+        g_scratch.host_cap = 0;
+        if ((e = hipHostMalloc(reinterpret_cast<void **>(&g_scratch.host), total + total / 2 + 4096, hipHostMallocDefault)) != hipSuccess) return e;
+        g_scratch.host_cap = total + total / 2 + 4096;
+    }
+    if (g_scratch.dev_cap < total_in) {
+        if (g_scratch.dev) (void)hipFree(g_scratch.dev);
+        g_scratch.dev = nullptr;
+        g_scratch.dev_cap = 0;
+        if ((e = hipMalloc(reinterpret_cast<void **>(&g_scratch.dev), total_in + total_in / 2 + 4096)) != hipSuccess) return e;
+        g_scratch.dev_cap = total_in + total_in / 2 + 4096;
+    }
     for (int i = 0; i < 8; ++i)
-        if (sz[i] && (e = hipMemcpyAsync(g_scratch.buf[i], src[i], sz[i], hipMemcpyHostToDevice, s)) != hipSuccess) return e;
+        if (in_sz[i]) memcpy(g_scratch.host + in_off[i], in_src[i], in_sz[i]);
+    if ((e = hipMemcpyAsync(g_scratch.dev, g_scratch.host, total_in, hipMemcpyHostToDevice, s)) != hipSuccess) return e;
     UnaryArgs a;
     a.n_points = n_points;
     a.n_kf = n_kf;
-    a.Xw = (const float *)g_scratch.buf[0];
-    a.obs_ptr = (const int *)g_scratch.buf[1];
-    a.obs_kf = (const int *)g_scratch.buf[2];
-    a.obs_kp = (const double *)g_scratch.buf[3];
-    a.kf_pose = (const float *)g_scratch.buf[4];
-    a.kf_intr = (const float *)g_scratch.buf[5];
-    a.kf_bounds = (const float *)g_scratch.buf[6];
-    a.match_prob = match_prob ? (const double *)g_scratch.buf[7] : nullptr;
+    a.obs_kp = reinterpret_cast<const double *>(g_scratch.dev + in_off[0]);
+    a.match_prob = match_prob ? reinterpret_cast<const double *>(g_scratch.dev + in_off[1]) : nullptr;
+    a.Xw = reinterpret_cast<const float *>(g_scratch.dev + in_off[2]);
+    a.obs_ptr = reinterpret_cast<const int *>(g_scratch.dev + in_off[3]);
+    a.obs_kf = reinterpret_cast<const int *>(g_scratch.dev + in_off[4]);
+    a.kf_pose = reinterpret_cast<const float *>(g_scratch.dev + in_off[5]);
+    a.kf_intr = reinterpret_cast<const float *>(g_scratch.dev + in_off[6]);
+    a.kf_bounds = reinterpret_cast<const float *>(g_scratch.dev + in_off[7]);
     a.p = *params;
-    a.observs = (float *)g_scratch.buf[8];
-    a.error = (float *)g_scratch.buf[9];
-    a.depth = (float *)g_scratch.buf[10];
-    a.label = (int16_t *)g_scratch.buf[11];
-    if (n_points > 0) {
-        k_unary_build<<<dim3((n_points + 255) / 256), dim3(256), 0, s>>>(a);
-        if ((e = hipGetLastError()) != hipSuccess) return e;
-        void *dst[4] = {observs_out, error_out, depth_out, label_out};
-        for (int i = 0; i < 4; ++i)
-            if ((e = hipMemcpyAsync(dst[i], g_scratch.buf[8 + i], sz[8 + i], hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
-    }
-    return hipStreamSynchronize(s);
+    a.observs = reinterpret_cast<float *>(g_scratch.host + out_off[0]);      // pinned host memory: written by the kernel
+    a.error = reinterpret_cast<float *>(g_scratch.host + out_off[1]);
+    a.depth = reinterpret_cast<float *>(g_scratch.host + out_off[2]);
+    a.label = reinterpret_cast<int16_t *>(g_scratch.host + out_off[3]);
+    k_unary_build<<<dim3((n_points + 255) / 256), dim3(256), 0, s>>>(a);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;
+    void *dst[4] = {observs_out, error_out, depth_out, label_out};
+    for (int i = 0; i < 4; ++i) memcpy(dst[i], g_scratch.host + out_off[i], out_sz[i]);
+    return hipSuccess;
 }
 
 }  // namespace lccrf

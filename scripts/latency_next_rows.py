@@ -1,0 +1,21 @@
+import importlib, sys, time, os
+import numpy as np
+sys.path.insert(0, "/root/repo"); sys.path.insert(0, os.getcwd())
+pkg = importlib.import_module("lc-crf-slam_amd"); wl = importlib.import_module("lc-crf-slam_amd.workloads")
+sc = wl.map_point_scene(2000, 15, 4)
+args = (sc["Xw"], sc["obs_ptr"], sc["obs_kf"], sc["obs_kp"], sc["kf_pose"], sc["kf_intr"], sc["kf_bounds"])
+for _ in range(5): pkg.unary_build(*args)
+t = []
+for _ in range(50):
+    t0 = time.perf_counter(); pkg.unary_build(*args); t.append(time.perf_counter() - t0)
+print("unary_build N=2000, %d observations: median %.1f us" % (sc["obs_ptr"][-1], np.median(t) * 1e6))
+rng = np.random.default_rng(0)
+q = rng.integers(0, 256, (2000, 32), dtype=np.uint8); tr = rng.integers(0, 256, (2000, 32), dtype=np.uint8)
+for _ in range(5): pkg.bf_match(q, tr)
+t = []
+for _ in range(50):
+    t0 = time.perf_counter(); pkg.bf_match(q, tr); t.append(time.perf_counter() - t0)
+print("bf_match 2000 x 2000: median %.1f us" % (np.median(t) * 1e6))
+sys.path.insert(0, "oracle"); import pyoracle as po
+t0 = time.perf_counter(); po.oracle_bf_match(q, tr); print("oracle bf_match: %.1f ms" % ((time.perf_counter() - t0) * 1e3))
+t0 = time.perf_counter(); po.oracle_unary_build(*args); print("oracle unary_build: %.1f us" % ((time.perf_counter() - t0) * 1e6))
