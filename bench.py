@@ -262,7 +262,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(name, engine, F),
                          "kernel": "inference (start + %d mean-field iterations + map), HIP events" % n_iter,
                          "algorithmic_bytes_per_launch": bytes_launch, "launch_ms": inf_ms,
-                         "note": "SLAM-size working sets are LDS/L2-resident: latency-bound, not HBM-bound"
+                         "note": "SLAM-size working sets are LDS/register-resident: bound by the CU's LDS pipe and latency, not by HBM"
                                  if name != "c5" else "lattice values exceed LDS; L2/MALL-resident"},
             "build_ms_per_batch": build_ms,
             "frames_per_s_end_to_end": F * world / ((build_ms + inf_ms) * 1e-3),
