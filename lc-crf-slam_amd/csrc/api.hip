@@ -133,6 +133,13 @@ struct Engine {
     int engine_pref = 0, engine_used = 1;
     size_t fused_lds = 0;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   // build begin/end, inference begin/end
+    // Late-bound fused inference (object API): queued right behind the build, before the host has seen
+    // the lattice sizes; `late_status` (pinned) tells afterwards whether the frame fitted.
+    int *late_status = nullptr;
+    bool late_ok = false;              // set by the object API: single frame, automatic engine choice
+    bool late_pending = false;
+    int late_iter = 0, late_map = 0;
+    float late_relax = 1.0f;
     bool timed_build = false, timed_inf = false;
 
     int init(int device_id, int frames, int max_points, int n_labels)
@@ -157,6 +164,8 @@ struct Engine {
         if ((rc = mem.alloc_pinned(&tbl_host, 2 * L + 1))) return rc;
         if ((rc = mem.alloc_pinned(&V_host, (size_t)LCCRF_MAX_KERNELS * Fcap))) return rc;
         if ((rc = mem.alloc_pinned(&row_host, (size_t)LCCRF_MAX_KERNELS * Fcap))) return rc;
+        if ((rc = mem.alloc_pinned(&late_status, 1))) return rc;
+        *late_status = 0;
         crf.F = F;
         crf.maxN = maxN;
         crf.L = L;
@@ -256,6 +265,7 @@ struct Engine {
         crf.unary = unary_own;
         crf.n_points = npoints_own;
         unary_set = built = sizes_known = started = false;
+        late_pending = false;
         built_upto = 0;
         engine_pref = 0;
         engine_used = 1;
@@ -360,6 +370,7 @@ struct Engine {
     int start()
     {
         if (!unary_set) return fail(LCCRF_E_STATE, "unary energies not set");
+        { int rl = resolve_late(); if (rl) return rl; }
         launch_start(crf, stream);
         started = true;
         return LCCRF_OK;
@@ -368,7 +379,9 @@ struct Engine {
     int step(float relax)
     {
         if (!started) return fail(LCCRF_E_STATE, "stepInference before startInference");
-        int rc = learn_sizes();
+        int rc = resolve_late();
+        if (rc) return rc;
+        rc = learn_sizes();
         if (rc) return rc;
         launch_step_stream(crf, kdevs.data(), maxV.data(), relax, stream);
         return LCCRF_OK;
@@ -378,6 +391,28 @@ struct Engine {
     {
         if (n_iter < 0) return fail(LCCRF_E_INVALID, "n_iterations < 0");
         if (!unary_set) return fail(LCCRF_E_STATE, "unary energies not set");
+        int rc = resolve_late();
+        if (rc) return rc;
+        if (late_ok && !sizes_known && engine_pref == 0 && !kernels.empty() && fused_late_supported(crf, kdevs.data())) {
+            // The host would have to wait for the build just to size the fused kernel's LDS.  Let the
+            // kernel size it itself and find out at the next synchronisation whether the frame fitted.
+            if ((rc = flush_builds())) return rc;
+            *late_status = 0;
+            launch_inference_fused_late(crf, kdevs.data(), n_iter, with_map, relax, late_status, stream);
+            HIP_TRY(hipGetLastError());
+            late_pending = true;
+            late_iter = n_iter;
+            late_map = with_map;
+            late_relax = relax;
+            started = true;
+            engine_used = 2;
+            return LCCRF_OK;
+        }
+        return inference_sized(n_iter, with_map, relax);
+    }
+
+    int inference_sized(int n_iter, int with_map, float relax)
+    {
         int rc = learn_sizes();
         if (rc) return rc;
         if (engine_used == 2) {
@@ -390,6 +425,17 @@ struct Engine {
         }
         HIP_TRY(hipGetLastError());
         return LCCRF_OK;
+    }
+
+    // Before anything looks at (or continues from) the results of a late-bound inference.
+    int resolve_late()
+    {
+        if (!late_pending) return LCCRF_OK;
+        late_pending = false;
+        HIP_TRY(hipStreamSynchronize(stream));
+        if (*late_status == 0) return LCCRF_OK;
+        *late_status = 0;                                  // the frame did not fit one workgroup: run it sized
+        return inference_sized(late_iter, late_map, late_relax);
     }
 };
 
@@ -486,6 +532,8 @@ int lccrf_create(lccrf_handle *out, int device_id, int n_points, int n_labels)
     h->N = n_points;
     h->eng.activeN = n_points;
     h->eng.crf.map = h->map_pin;
+    static const bool no_late = getenv("LCCRF_NO_LATE") != nullptr;   // debugging aid: always size the fused kernel on the host
+    h->eng.late_ok = !no_late;
     h->label_stage_busy = false;    // a parked engine's stream is idle (recycle() synchronised it)
     h->eng.sync_views();
     *h->stage_n = n_points;
@@ -542,6 +590,7 @@ int lccrf_set_unary(lccrf_handle h, const float *unary)
     if (!unary && h->N) return fail(LCCRF_E_INVALID, "unary is NULL");
     Engine &e = h->eng;
     const size_t n = (size_t)h->N * e.L;
+    { int rl = e.resolve_late(); if (rl) return rl; }
     HIP_TRY(hipStreamSynchronize(e.stream));          // staging buffer may still be in flight
     if (n) {
         memcpy(h->stage_f32, unary, n * sizeof(float));
@@ -557,6 +606,7 @@ int lccrf_set_unary_from_label(lccrf_handle h, const int16_t *label, const float
     CHECK_H(h);
     if ((!label && h->N) || !conf) return fail(LCCRF_E_INVALID, "label/conf is NULL");
     Engine &e = h->eng;
+    { int rl = e.resolve_late(); if (rl) return rl; }
     if (e.L < 2) return fail(LCCRF_E_INVALID, "setUnaryEnergyFromLabel needs >= 2 labels");
     if (h->label_stage_busy) HIP_TRY(hipStreamSynchronize(e.stream));   // an earlier call's kernel may still read the staging buffer
     // No uploads: the 2L+1 energies travel as a kernel argument and the kernel reads the labels from
@@ -581,6 +631,7 @@ int lccrf_add_pairwise(lccrf_handle h, const float *features, int d, float w)
     CHECK_H(h);
     if (!features && h->N) return fail(LCCRF_E_INVALID, "features is NULL");
     Engine &e = h->eng;
+    { int rl = e.resolve_late(); if (rl) return rl; }
     int rc = e.add_kernel(d, w, true, true);
     if (rc) return rc;
     const int k = (int)e.kernels.size() - 1;
@@ -637,6 +688,7 @@ int lccrf_step_inference(lccrf_handle h, float relax)
 int lccrf_build_map(lccrf_handle h)
 {
     CHECK_H(h);
+    { int rl = h->eng.resolve_late(); if (rl) return rl; }
     launch_map(h->eng.crf, h->eng.stream);
     HIP_TRY(hipGetLastError());
     return LCCRF_OK;
@@ -653,6 +705,7 @@ int lccrf_get_map(lccrf_handle h, int16_t *map_out)
     CHECK_H(h);
     if (!map_out && h->N) return fail(LCCRF_E_INVALID, "map_out is NULL");
     Engine &e = h->eng;
+    { int rl = e.resolve_late(); if (rl) return rl; }
     HIP_TRY(hipStreamSynchronize(e.stream));
     if (h->N) memcpy(map_out, h->map_pin, (size_t)h->N * sizeof(int16_t));   // written there by the kernels
     return LCCRF_OK;
@@ -671,6 +724,7 @@ int lccrf_get_probability(lccrf_handle h, float *prob_out)
 {
     CHECK_H(h);
     if (!prob_out && h->N) return fail(LCCRF_E_INVALID, "prob_out is NULL");
+    { int rl = h->eng.resolve_late(); if (rl) return rl; }
     return copy_out_f32(h, h->eng.crf.Q, prob_out, (size_t)h->N * h->eng.L);
 }
 

@@ -90,6 +90,9 @@ bool fused_supported(const CrfDev &c, const KernelDev *kds, const int *maxV, con
                      size_t *lds_bytes);
 void launch_inference_fused(const CrfDev &c, const KernelDev *kds, const int *maxV, const int *maxRow,
                             int n_iter, int with_map, float relax, hipStream_t s);
+bool fused_late_supported(const CrfDev &c, const KernelDev *kds);
+void launch_inference_fused_late(const CrfDev &c, const KernelDev *kds, int n_iter, int with_map, float relax,
+                                 int *status, hipStream_t s);
 
 // ---- unary builder (the step before the CRF) ------------------------
 hipError_t run_unary_build(int device_id, int n_points, const float *Xw, const int32_t *obs_ptr, const int32_t *obs_kf,

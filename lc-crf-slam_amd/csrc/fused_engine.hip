@@ -54,6 +54,8 @@ struct FusedArgs {
     float relax;
     long long *timing;                    // debug: shader-clock stamps of one workgroup (LCCRF_FUSED_TIMING=<block index + 1>)
     int timing_block;
+    int late;                             // 1: the kernel sizes its own LDS from its frame's V / longest row (lay is ignored)
+    int *status;                          // late-bound launches: set to 1 (pinned host memory) when the frame does not fit
     int dbg;                              // LCCRF_FUSED_DBG: 1 skip short-row S, 2 skip chain S (timing only, wrong results); 4 poison LDS
 };
 
@@ -67,6 +69,54 @@ struct FusedArgs {
     do {                                                               \
         if (a.timing && blockIdx.x == a.timing_block && tid == 0) a.timing[n_stamp++] = clock64(); \
     } while (0)
+
+constexpr int kChainMinRow = 64;          // kernel 0 runs chain_rows when its longest splat row has at least this many products ...
+constexpr int kChainMaxV = kChainTop + 7 * 64;           // ... and it has at most this many vertices (one lane per (vertex,label) row)
+
+// LDS plan of one workgroup for frames of at most NA points whose K lattices (all 2-D) have at most
+// V[k] vertices and kernel 0's longest row has `row0` products.  Shared by the host (batch API: sizes
+// maximised over the frames) and the kernel itself (late-bound launches: each frame sizes its own).
+__host__ __device__ inline bool layout_core(int NA, int K, const int *V, int row0, FusedLayout *lay)
+{
+    constexpr int D1 = 3;
+    if (NA < 1 || NA > 4 * kNT || K < 1 || K > kMaxFusedK) return false;
+    for (int k = 0; k < K; ++k)
+        if (V[k] >= 65535) return false;
+    const int chain0 = row0 >= kChainMinRow && V[0] <= kChainMaxV && NA * D1 + kChainGap * V[0] + 64 < 65535;
+    for (int all = 1; all >= 0; --all) {                  // own product buffers, else one shared buffer
+        FusedLayout L{};
+        size_t o = 0;
+        auto take = [&](size_t bytes) { size_t r = o; o += (bytes + 15) & ~(size_t)15; return (int)r; };
+        L.prod_all = all;
+        L.chain0 = chain0;
+        (void)take(128);                                   // chain_rows wants the zero block at an address >= 128
+        L.zero = take(64);
+        size_t shared_prod = 0;
+        for (int k = 0; k < K; ++k) {
+            const int E = NA * D1;
+            // chain rows carry kChainGap extra slots each; every plane is a multiple of 64 floats
+            L.Ecap[k] = ((k == 0 && chain0 ? E + kChainGap * V[k] + 16 : E) + 63) & ~63;
+            L.Vcap[k] = V[k];
+            L.val[k][0] = take((size_t)(V[k] + 1) * sizeof(float2));
+            L.val[k][1] = take((size_t)(V[k] + 1) * sizeof(float2));
+            L.nbr[k] = take((size_t)D1 * V[k] * sizeof(unsigned));
+            L.row[k] = take((size_t)(V[k] + 2) * sizeof(unsigned short));
+            const size_t pb = (size_t)L.Ecap[k] * 2 * sizeof(float);
+            if (all) L.prod[k] = take(pb);
+            else shared_prod = pb > shared_prod ? pb : shared_prod;
+        }
+        if (!all) {
+            const int p = take(shared_prod);
+            for (int k = 0; k < K; ++k) L.prod[k] = p;
+        }
+        L.total = (int)o;
+        if (o <= kLdsLimit) {
+            *lay = L;
+            return true;
+        }
+    }
+    return false;
+}
 
 // ---- ordered row sums for kernels with long splat rows -----------------------------------
 // The appearance kernel of a SLAM frame puts ~2000 points on ~120 lattice vertices: a few rows
@@ -141,6 +191,7 @@ __device__ __forceinline__ float chain_rows(unsigned addr, unsigned end, unsigne
 //      point's place in the row, ascending point order -- found once per launch)
 //   S  row sums, strictly left to right (chain_rows for a long-row kernel 0: CH = 1)
 //   B  three Jacobi blur passes            X  slice + apply + softmax, all in registers
+//   CH = 0 / 1: kernel 0 short-row / chain, decided by the host;  CH = 2: decided here (late-bound layout)
 template <int PPT, int K, int CH>
 __global__ void __launch_bounds__(kNT) k_fused(CrfDev c, FusedArgs a)
 {
@@ -151,10 +202,6 @@ __global__ void __launch_bounds__(kNT) k_fused(CrfDev c, FusedArgs a)
     const int tid = threadIdx.x;
     const int N = c.n_points[f];
     STAMP();
-    if (a.dbg & 4) {                      // debugging aid: NaN-poison the LDS so that reads of unwritten LDS show up
-        for (int i = tid; i < a.lay.total / 4; i += kNT) reinterpret_cast<unsigned *>(smem)[i] = 0x7fc00000u + (unsigned)i;
-        __syncthreads();
-    }
 
     // ---- per-thread point state (registers) ------------------------------------------
     float2 un[PPT], q[PPT];
@@ -167,6 +214,18 @@ __global__ void __launch_bounds__(kNT) k_fused(CrfDev c, FusedArgs a)
     for (int k = 0; k < K; ++k) V[k] = a.kd[k].V[f];
 
     if (N <= 0) return;                   // nothing to infer (and nothing below may index an empty frame)
+    FusedLayout lay = a.lay;
+    if constexpr (CH == 2) {              // late-bound launch: this frame sizes its own LDS (the host has not seen V yet)
+        if (!layout_core(N, K, V, a.kd[0].rowmax[f], &lay)) {
+            if (tid == 0 && a.status) *a.status = 1;      // the host falls back to the streaming engine
+            return;
+        }
+    }
+    auto chain_k = [&](int k) -> bool { return CH == 2 ? (k == 0 && lay.chain0 != 0) : (((CH >> k) & 1) != 0); };
+    if (a.dbg & 4) {                      // debugging aid: NaN-poison the LDS so that reads of unwritten LDS show up
+        for (int i = tid; i < lay.total / 4; i += kNT) reinterpret_cast<unsigned *>(smem)[i] = 0x7fc00000u + (unsigned)i;
+        __syncthreads();
+    }
 
     // All global loads of the prologue are issued before anything waits on them: the lattice
     // tables first (their LDS stores come last), then the per-point records.  Indices are clamped
@@ -219,11 +278,11 @@ __global__ void __launch_bounds__(kNT) k_fused(CrfDev c, FusedArgs a)
     PSTAMP();
 
     // ---- per-frame lattice tables into LDS --------------------------------------------
-    int *hist = reinterpret_cast<int *>(smem + a.lay.prod[0]);            // chain ranking scratch: [64] counts, [64] bases
+    int *hist = reinterpret_cast<int *>(smem + lay.prod[0]);            // chain ranking scratch: [64] counts, [64] bases
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-        unsigned *nbr = reinterpret_cast<unsigned *>(smem + a.lay.nbr[k]);
-        unsigned short *row = reinterpret_cast<unsigned short *>(smem + a.lay.row[k]);
+        unsigned *nbr = reinterpret_cast<unsigned *>(smem + lay.nbr[k]);
+        unsigned short *row = reinterpret_cast<unsigned short *>(smem + lay.row[k]);
 #pragma unroll
         for (int r = 0; r < kNbrRounds; ++r) {
             const int idx = tid + r * kNT;
@@ -242,13 +301,13 @@ __global__ void __launch_bounds__(kNT) k_fused(CrfDev c, FusedArgs a)
         const int *gr = kd.rowptr + (size_t)f * (kd.Epad + 1);
         for (int v = tid + kRowRounds * kNT; v <= V[k]; v += kNT) row[v] = (unsigned short)gr[v];
     }
-    if (tid < 16) reinterpret_cast<float *>(smem + a.lay.zero)[tid] = 0.0f;
+    if (tid < 16) reinterpret_cast<float *>(smem + lay.zero)[tid] = 0.0f;
     if (CH && tid < 128) hist[tid] = 0;
     if (tid == 0) {
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-            reinterpret_cast<float2 *>(smem + a.lay.val[k][0])[0] = make_float2(0.f, 0.f);
-            reinterpret_cast<float2 *>(smem + a.lay.val[k][1])[0] = make_float2(0.f, 0.f);
+            reinterpret_cast<float2 *>(smem + lay.val[k][0])[0] = make_float2(0.f, 0.f);
+            reinterpret_cast<float2 *>(smem + lay.val[k][1])[0] = make_float2(0.f, 0.f);
         }
     }
 #pragma unroll
@@ -272,7 +331,7 @@ __global__ void __launch_bounds__(kNT) k_fused(CrfDev c, FusedArgs a)
     auto pst = [](int r0, int v) { return (r0 + kChainGap * v + 3) & ~3; };
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-        const unsigned short *row = reinterpret_cast<const unsigned short *>(smem + a.lay.row[k]);
+        const unsigned short *row = reinterpret_cast<const unsigned short *>(smem + lay.row[k]);
 #pragma unroll
         for (int s = 0; s < PPT; ++s) {
             if (tid + s * kNT < N) {
@@ -280,7 +339,7 @@ __global__ void __launch_bounds__(kNT) k_fused(CrfDev c, FusedArgs a)
 #pragma unroll
                 for (int j = 0; j < D1; ++j) {
                     sl[j] = pk[s][k][j] >> 16;
-                    if ((CH >> k) & 1) {
+                    if (chain_k(k)) {
                         const int v = (int)(pk[s][k][j] & 0xffffu) - 1;
                         const int r0 = row[v];
                         sl[j] = (unsigned)(pst(r0, v) + ((int)(pk[s][k][j] >> 16) - r0));
@@ -297,10 +356,10 @@ __global__ void __launch_bounds__(kNT) k_fused(CrfDev c, FusedArgs a)
     // which lane sums which row, never the order inside a row).
     unsigned ch_a = 0, ch_b = 0;          // row address | wavefront max units << 18 ;
                                           // 8-product units | (padded length is 8n+4) << 13 | pad slots << 14 | output index << 16
-    if constexpr (CH != 0) {
+    if (CH != 0 && chain_k(0)) {
         constexpr int k = 0;
-        const unsigned short *row = reinterpret_cast<const unsigned short *>(smem + a.lay.row[k]);
-        unsigned short *srt = reinterpret_cast<unsigned short *>(smem + a.lay.prod[k]) + 256;   // [V] vertex of rank r
+        const unsigned short *row = reinterpret_cast<const unsigned short *>(smem + lay.row[k]);
+        unsigned short *srt = reinterpret_cast<unsigned short *>(smem + lay.prod[k]) + 256;   // [V] vertex of rank r
         int key = 0, len = 0;
         if (tid < V[k]) {
             len = (int)row[tid + 1] - (int)row[tid];
@@ -333,7 +392,7 @@ __global__ void __launch_bounds__(kNT) k_fused(CrfDev c, FusedArgs a)
         if (r < V[k]) {
             const int v = srt[r];
             const int r0 = row[v], rl = (int)row[v + 1] - r0, len4 = (rl + 3) & ~3;
-            addr = (unsigned)(a.lay.prod[k] + 4 * (l * a.lay.Ecap[k] + pst(r0, v)));               // < 2^18
+            addr = (unsigned)(lay.prod[k] + 4 * (l * lay.Ecap[k] + pst(r0, v)));               // < 2^18
             nblk = (unsigned)((len4 + 7) >> 3);                                                    // 8-product units, < 2^13
             ch_b = nblk | ((unsigned)((len4 >> 2) & 1) << 13) | ((unsigned)(len4 - rl) << 14) |
                    ((unsigned)((v + 1) * 2 + l) << 16);
@@ -360,15 +419,15 @@ __global__ void __launch_bounds__(kNT) k_fused(CrfDev c, FusedArgs a)
         }
         // ---- splat = products (P) + ordered row sums (S) ------------------------------
         auto phase_P = [&](int k) {
-            float *p0 = reinterpret_cast<float *>(smem + a.lay.prod[k]);
-            float *p1 = p0 + a.lay.Ecap[k];
+            float *p0 = reinterpret_cast<float *>(smem + lay.prod[k]);
+            float *p1 = p0 + lay.Ecap[k];
             float2 *p2 = reinterpret_cast<float2 *>(p0);
 #pragma unroll
             for (int s = 0; s < PPT; ++s) {
                 const int i = tid + s * kNT;
                 if (i < N) {
                     const unsigned s0 = slp[s][k][0] & 0xffffu, s1 = slp[s][k][0] >> 16, s2 = slp[s][k][1];
-                    if ((CH >> k) & 1) {                                  // chain kernel: one plane per label
+                    if (chain_k(k)) {                                  // chain kernel: one plane per label
                         p0[s0] = bary[s][k][0] * q[s].x;
                         p1[s0] = bary[s][k][0] * q[s].y;
                         p0[s1] = bary[s][k][1] * q[s].x;
@@ -382,7 +441,7 @@ __global__ void __launch_bounds__(kNT) k_fused(CrfDev c, FusedArgs a)
                     }
                 }
             }
-            if ((CH >> k) & 1) {          // behind the row: +0 up to a multiple of 4, then eight +0 (the buffer may
+            if (chain_k(k)) {          // behind the row: +0 up to a multiple of 4, then eight +0 (the buffer may
                                           // have held another kernel's products)
                 if (ch_b >> 16) {
                     float *e = reinterpret_cast<float *>(smem + (ch_a & 0x3ffffu)) + ((ch_b & 0x1fffu) * 8u - ((ch_b >> 13) & 1u) * 4u);
@@ -396,8 +455,8 @@ __global__ void __launch_bounds__(kNT) k_fused(CrfDev c, FusedArgs a)
         // lanes [s_lo, kNT) share the short-row kernels; the wavefront that owns the chain
         // kernel's longest rows keeps out of them
         auto phase_S = [&](int k, int s_lo) {
-            float *val = reinterpret_cast<float *>(smem + a.lay.val[k][0]);
-            if ((CH >> k) & 1) {
+            float *val = reinterpret_cast<float *>(smem + lay.val[k][0]);
+            if (chain_k(k)) {
                 const int npairs = 1 + ((max(V[k] - kChainTop, 0) + 63) >> 6);
                 if ((tid >> 7) < npairs && !(a.dbg & 2)) {                                // whole wavefronts
                     PSTAMP();
@@ -412,9 +471,9 @@ __global__ void __launch_bounds__(kNT) k_fused(CrfDev c, FusedArgs a)
             // short rows: one lane per vertex sums both labels (products are stored label-interleaved),
             // 8 at a time with all loads issued before the first add; a lane past the end of its row
             // reads the zero block (x + 0 is exact, see chain_rows)
-            const float2 *pl = reinterpret_cast<const float2 *>(smem + a.lay.prod[k]);
-            const float2 *zero = reinterpret_cast<const float2 *>(smem + a.lay.zero);
-            const unsigned short *row = reinterpret_cast<const unsigned short *>(smem + a.lay.row[k]);
+            const float2 *pl = reinterpret_cast<const float2 *>(smem + lay.prod[k]);
+            const float2 *zero = reinterpret_cast<const float2 *>(smem + lay.zero);
+            const unsigned short *row = reinterpret_cast<const unsigned short *>(smem + lay.row[k]);
             if (tid < s_lo || (a.dbg & 1)) return;
             for (int v = tid - s_lo; v < V[k]; v += kNT - s_lo) {
                 const int t = row[v + 1];
@@ -429,12 +488,12 @@ __global__ void __launch_bounds__(kNT) k_fused(CrfDev c, FusedArgs a)
                 reinterpret_cast<float2 *>(val)[v + 1] = make_float2(a0, a1);
             }
         };
-        if (a.lay.prod_all) {
+        if (lay.prod_all) {
 #pragma unroll
             for (int k = 0; k < K; ++k) phase_P(k);
             __syncthreads();
             STAMP();
-            const int s_lo = (K > 1 && (CH & 1)) ? 128 : 0;
+            const int s_lo = (K > 1 && chain_k(0)) ? 128 : 0;
 #pragma unroll
             for (int k = 0; k < K; ++k) phase_S(k, s_lo);                 // the chain kernel is kernel 0: it starts first
             __syncthreads();
@@ -454,9 +513,9 @@ __global__ void __launch_bounds__(kNT) k_fused(CrfDev c, FusedArgs a)
         for (int j = 0; j < D1; ++j) {
 #pragma unroll
             for (int k = 0; k < K; ++k) {
-                const float2 *src = reinterpret_cast<const float2 *>(smem + a.lay.val[k][j & 1]);
-                float2 *dst = reinterpret_cast<float2 *>(smem + a.lay.val[k][(j & 1) ^ 1]);
-                const unsigned *nbr = reinterpret_cast<const unsigned *>(smem + a.lay.nbr[k]) + j * V[k];
+                const float2 *src = reinterpret_cast<const float2 *>(smem + lay.val[k][j & 1]);
+                float2 *dst = reinterpret_cast<float2 *>(smem + lay.val[k][(j & 1) ^ 1]);
+                const unsigned *nbr = reinterpret_cast<const unsigned *>(smem + lay.nbr[k]) + j * V[k];
                 for (int v = tid; v < V[k]; v += kNT) {
                     const unsigned n = nbr[v];
                     const float2 o = src[v + 1], x = src[n & 0xffffu], y = src[n >> 16];
@@ -479,7 +538,7 @@ __global__ void __launch_bounds__(kNT) k_fused(CrfDev c, FusedArgs a)
                 float nx[2] = {-un[s].x, -un[s].y};                       // stepInit, densecrf3d.h:154-158
 #pragma unroll
                 for (int k = 0; k < K; ++k) {
-                    const float2 *val = reinterpret_cast<const float2 *>(smem + a.lay.val[k][D1 & 1]);
+                    const float2 *val = reinterpret_cast<const float2 *>(smem + lay.val[k][D1 & 1]);
                     const float alpha = a.kd[k].alpha;
                     const float2 x0 = val[offp[s][k][0] & 0xffffu], x1 = val[offp[s][k][0] >> 16], x2 = val[offp[s][k][1]];
                     const float w0 = bary[s][k][0] * alpha, w1 = bary[s][k][1] * alpha, w2 = bary[s][k][2] * alpha;   // permutohedral_cpu.h:689
@@ -511,53 +570,13 @@ __global__ void __launch_bounds__(kNT) k_fused(CrfDev c, FusedArgs a)
     if (a.timing && blockIdx.x == a.timing_block && tid == 0) a.timing[63] = n_stamp;
 }
 
-constexpr int kChainMinRow = 64;          // kernel 0 runs chain_rows when its longest splat row has at least this many products ...
-constexpr int kChainMaxV = kChainTop + 7 * 64;           // ... and it has at most this many vertices (one lane per (vertex,label), ranking is O(V) per lane)
-
 bool make_layout(const CrfDev &c, const KernelDev *kds, const int *maxV, const int *maxRow, FusedLayout *lay)
 {
     if (c.L != 2 || c.K < 1 || c.K > kMaxFusedK) return false;
     const int NA = c.activeN > 0 ? c.activeN : c.maxN;   // size LDS and the points-per-lane variant by the frames' real size
-    if (NA < 1 || NA > 4 * kNT) return false;
-    for (int k = 0; k < c.K; ++k) {
-        if (kds[k].d != kds[0].d || kds[k].d != 2) return false;
-        if (maxV[k] >= 65535 || kds[k].Epad >= 65535) return false;     // u16 row pointers / neighbour ids / slots
-    }
-    const int chain0 = maxRow && maxRow[0] >= kChainMinRow && maxV[0] <= kChainMaxV &&
-                       NA * kds[0].D1 + kChainGap * maxV[0] + 64 < 65535;
-    for (int all = 1; all >= 0; --all) {                  // own product buffers, else one shared buffer
-        FusedLayout L{};
-        size_t o = 0;
-        auto take = [&](size_t bytes) { size_t r = o; o += (bytes + 15) & ~(size_t)15; return (int)r; };
-        L.prod_all = all;
-        L.chain0 = chain0;
-        (void)take(128);                                   // chain_rows wants the zero block at an address >= 128
-        L.zero = take(64);
-        size_t shared_prod = 0;
-        for (int k = 0; k < c.K; ++k) {
-            const int E = NA * kds[k].D1;
-            // chain rows carry kChainGap extra slots each; every plane is a multiple of 64 floats
-            L.Ecap[k] = ((k == 0 && chain0 ? E + kChainGap * maxV[k] + 16 : E) + 63) & ~63;
-            L.Vcap[k] = maxV[k];
-            L.val[k][0] = take((size_t)(maxV[k] + 1) * sizeof(float2));
-            L.val[k][1] = take((size_t)(maxV[k] + 1) * sizeof(float2));
-            L.nbr[k] = take((size_t)kds[k].D1 * maxV[k] * sizeof(unsigned));
-            L.row[k] = take((size_t)(maxV[k] + 2) * sizeof(unsigned short));
-            const size_t pb = (size_t)L.Ecap[k] * 2 * sizeof(float);
-            if (all) L.prod[k] = take(pb);
-            else shared_prod = pb > shared_prod ? pb : shared_prod;
-        }
-        if (!all) {
-            const int p = take(shared_prod);
-            for (int k = 0; k < c.K; ++k) L.prod[k] = p;
-        }
-        L.total = (int)o;
-        if (o <= kLdsLimit) {
-            *lay = L;
-            return true;
-        }
-    }
-    return false;
+    for (int k = 0; k < c.K; ++k)
+        if (kds[k].d != 2 || kds[k].Epad >= 65535) return false;       // u16 row pointers / neighbour ids / slots
+    return layout_core(NA, c.K, maxV, maxRow ? maxRow[0] : 0, lay);
 }
 
 template <int PPT, int K, int CH>
@@ -567,12 +586,17 @@ void launch_fused(const CrfDev &c, const FusedArgs &a, hipStream_t s)
     // per (function, device); cheap enough to repeat and safe with several devices in one process
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)kLdsLimit);
-    fn<<<dim3(c.F), dim3(kNT), a.lay.total, s>>>(c, a);
+    fn<<<dim3(c.F), dim3(kNT), a.late ? (int)kLdsLimit : a.lay.total, s>>>(c, a);
 }
 
 template <int PPT>
 void launch_fused_ppt(const CrfDev &c, const FusedArgs &a, hipStream_t s)
 {
+    if (a.late) {
+        if (c.K == 1) launch_fused<PPT, 1, 2>(c, a, s);
+        else launch_fused<PPT, 2, 2>(c, a, s);
+        return;
+    }
     if (c.K == 1) {
         if (a.lay.chain0) launch_fused<PPT, 1, 1>(c, a, s);
         else launch_fused<PPT, 1, 0>(c, a, s);
@@ -626,6 +650,38 @@ void launch_inference_fused(const CrfDev &c, const KernelDev *kds, const int *ma
         fprintf(stderr, "[lccrf fused timing] %lld stamps, deltas (shader clocks):", h[63]);
         for (int i = 1; i < h[63] && i < 63; ++i) fprintf(stderr, " %lld", h[i] - h[i - 1]);
         fprintf(stderr, "\n");
+    }
+}
+
+// Late-bound launch: no host knowledge of the lattice sizes is needed, so it can be queued right
+// behind the build.  `status` (pinned host memory, zeroed by the caller) reads 1 afterwards if
+// the frame did not fit one workgroup; the caller then runs the streaming engine.
+bool fused_late_supported(const CrfDev &c, const KernelDev *kds)
+{
+    const int NA = c.activeN > 0 ? c.activeN : c.maxN;
+    if (c.L != 2 || c.K < 1 || c.K > kMaxFusedK || NA < 1 || NA > 4 * kNT) return false;
+    for (int k = 0; k < c.K; ++k)
+        if (kds[k].d != 2 || kds[k].Epad >= 65535) return false;
+    return true;
+}
+
+void launch_inference_fused_late(const CrfDev &c, const KernelDev *kds, int n_iter, int with_map, float relax,
+                                 int *status, hipStream_t s)
+{
+    FusedArgs a{};
+    for (int k = 0; k < c.K; ++k) a.kd[k] = kds[k];
+    a.n_iter = n_iter;
+    a.with_map = with_map;
+    a.relax = relax;
+    a.late = 1;
+    a.status = status;
+    const int ppt = ((c.activeN > 0 ? c.activeN : c.maxN) + kNT - 1) / kNT;
+    switch (ppt) {
+    case 1: launch_fused_ppt<1>(c, a, s); break;
+    case 2: launch_fused_ppt<2>(c, a, s); break;
+    case 3: launch_fused_ppt<3>(c, a, s); break;
+    case 4: launch_fused_ppt<4>(c, a, s); break;
+    default: break;
     }
 }
 
