@@ -136,6 +136,11 @@ struct Engine {
     // Late-bound fused inference (object API): queued right behind the build, before the host has seen
     // the lattice sizes; `late_status` (pinned) tells afterwards whether the frame fitted.
     int *late_status = nullptr;
+    // setUnaryEnergyFromLabel is deferred: the labels wait in pinned memory and either the late-bound
+    // fused kernel derives the energies itself or ensure_unary() launches the small kernel.
+    bool unary_deferred = false;
+    const int16_t *deferred_label = nullptr;
+    UnaryTable deferred_tbl{};
     bool late_ok = false;              // set by the object API: single frame, automatic engine choice
     bool late_pending = false;
     int late_iter = 0, late_map = 0;
@@ -266,6 +271,7 @@ struct Engine {
         crf.n_points = npoints_own;
         unary_set = built = sizes_known = started = false;
         late_pending = false;
+        unary_deferred = false;
         built_upto = 0;
         engine_pref = 0;
         engine_used = 1;
@@ -367,10 +373,20 @@ struct Engine {
         return LCCRF_OK;
     }
 
+    int ensure_unary()
+    {
+        if (!unary_deferred) return LCCRF_OK;
+        unary_deferred = false;
+        launch_unary_from_label_tbl(crf, deferred_label, deferred_tbl, stream);
+        HIP_TRY(hipGetLastError());
+        return LCCRF_OK;
+    }
+
     int start()
     {
         if (!unary_set) return fail(LCCRF_E_STATE, "unary energies not set");
         { int rl = resolve_late(); if (rl) return rl; }
+        { int ru = ensure_unary(); if (ru) return ru; }
         launch_start(crf, stream);
         started = true;
         return LCCRF_OK;
@@ -398,7 +414,10 @@ struct Engine {
             // kernel size it itself and find out at the next synchronisation whether the frame fitted.
             if ((rc = flush_builds())) return rc;
             *late_status = 0;
-            launch_inference_fused_late(crf, kdevs.data(), n_iter, with_map, relax, late_status, stream);
+            const bool from_label = unary_deferred && L == 2;
+            if (!from_label && (rc = ensure_unary())) return rc;
+            launch_inference_fused_late(crf, kdevs.data(), n_iter, with_map, relax, late_status,
+                                        from_label ? deferred_label : nullptr, deferred_tbl.v, stream);
             HIP_TRY(hipGetLastError());
             late_pending = true;
             late_iter = n_iter;
@@ -413,7 +432,9 @@ struct Engine {
 
     int inference_sized(int n_iter, int with_map, float relax)
     {
-        int rc = learn_sizes();
+        int rc = ensure_unary();
+        if (rc) return rc;
+        rc = learn_sizes();
         if (rc) return rc;
         if (engine_used == 2) {
             launch_inference_fused(crf, kdevs.data(), maxV.data(), maxRow.data(), n_iter, with_map, relax, stream);
@@ -433,7 +454,10 @@ struct Engine {
         if (!late_pending) return LCCRF_OK;
         late_pending = false;
         HIP_TRY(hipStreamSynchronize(stream));
-        if (*late_status == 0) return LCCRF_OK;
+        if (*late_status == 0) {
+            unary_deferred = false;                        // the kernel stored the energies it derived
+            return LCCRF_OK;
+        }
         *late_status = 0;                                  // the frame did not fit one workgroup: run it sized
         return inference_sized(late_iter, late_map, late_relax);
     }
@@ -597,6 +621,7 @@ int lccrf_set_unary(lccrf_handle h, const float *unary)
         HIP_TRY(hipMemcpyAsync(e.unary_own, h->stage_f32, n * sizeof(float), hipMemcpyHostToDevice, e.stream));
     }
     e.crf.unary = e.unary_own;
+    e.unary_deferred = false;
     e.unary_set = true;
     return LCCRF_OK;
 }
@@ -619,8 +644,9 @@ int lccrf_set_unary_from_label(lccrf_handle h, const int16_t *label, const float
     }
     if (h->N) memcpy(h->stage_i16, label, (size_t)h->N * sizeof(int16_t));
     e.crf.unary = e.unary_own;
-    launch_unary_from_label_tbl(e.crf, h->stage_i16, tb, e.stream);
-    HIP_TRY(hipGetLastError());
+    e.unary_deferred = true;                              // launched (or folded into the fused kernel) by the first consumer
+    e.deferred_label = h->stage_i16;
+    e.deferred_tbl = tb;
     h->label_stage_busy = true;
     e.unary_set = true;
     return LCCRF_OK;
@@ -732,6 +758,8 @@ int lccrf_get_unary(lccrf_handle h, float *unary_out)
 {
     CHECK_H(h);
     if (!unary_out && h->N) return fail(LCCRF_E_INVALID, "unary_out is NULL");
+    { int rl = h->eng.resolve_late(); if (rl) return rl; }
+    { int ru = h->eng.ensure_unary(); if (ru) return ru; }
     return copy_out_f32(h, h->eng.crf.unary, unary_out, (size_t)h->N * h->eng.L);
 }
 

@@ -91,8 +91,10 @@ bool fused_supported(const CrfDev &c, const KernelDev *kds, const int *maxV, con
 void launch_inference_fused(const CrfDev &c, const KernelDev *kds, const int *maxV, const int *maxRow,
                             int n_iter, int with_map, float relax, hipStream_t s);
 bool fused_late_supported(const CrfDev &c, const KernelDev *kds);
+// label != nullptr (L = 2): the unary energies are derived in the kernel from the labels and the 5 table
+// entries {u, n0, n1, p0, p1} and stored to c.unary as a by-product
 void launch_inference_fused_late(const CrfDev &c, const KernelDev *kds, int n_iter, int with_map, float relax,
-                                 int *status, hipStream_t s);
+                                 int *status, const int16_t *label, const float *tbl5, hipStream_t s);
 
 // ---- unary builder (the step before the CRF) ------------------------
 hipError_t run_unary_build(int device_id, int n_points, const float *Xw, const int32_t *obs_ptr, const int32_t *obs_kf,

@@ -56,6 +56,8 @@ struct FusedArgs {
     int timing_block;
     int late;                             // 1: the kernel sizes its own LDS from its frame's V / longest row (lay is ignored)
     int *status;                          // late-bound launches: set to 1 (pinned host memory) when the frame does not fit
+    const int16_t *label;                 // non-null: unary energies come from these labels and `tbl` (setUnaryEnergyFromLabel,
+    float tbl[5];                         //   densecrf3d.h:100-130, L = 2) -- computed here and stored to c.unary, no separate launch
     int dbg;                              // LCCRF_FUSED_DBG: 1 skip short-row S, 2 skip chain S (timing only, wrong results); 4 poison LDS
 };
 
@@ -251,7 +253,15 @@ __global__ void __launch_bounds__(kNT) k_fused(CrfDev c, FusedArgs a)
 #pragma unroll
     for (int s = 0; s < PPT; ++s) {
         const int ic = min(tid + s * kNT, N - 1);
-        un[s] = reinterpret_cast<const float2 *>(c.unary)[(size_t)f * c.maxN + ic];
+        if (a.label) {                                    // densecrf3d.h:116-129 with L = 2, as k_unary_from_label
+            const int t = a.label[(size_t)f * c.maxN + ic];
+            const bool known = t >= 0 && t < 2;
+            un[s].x = !known ? a.tbl[0] : (t == 0 ? a.tbl[3] : a.tbl[1 + t]);
+            un[s].y = !known ? a.tbl[0] : (t == 1 ? a.tbl[4] : a.tbl[1 + t]);
+            if (tid + s * kNT < N) reinterpret_cast<float2 *>(c.unary)[(size_t)f * c.maxN + ic] = un[s];
+        } else {
+            un[s] = reinterpret_cast<const float2 *>(c.unary)[(size_t)f * c.maxN + ic];
+        }
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             const KernelDev &kd = a.kd[k];
@@ -666,9 +676,12 @@ bool fused_late_supported(const CrfDev &c, const KernelDev *kds)
 }
 
 void launch_inference_fused_late(const CrfDev &c, const KernelDev *kds, int n_iter, int with_map, float relax,
-                                 int *status, hipStream_t s)
+                                 int *status, const int16_t *label, const float *tbl5, hipStream_t s)
 {
     FusedArgs a{};
+    a.label = label;
+    if (label)
+        for (int i = 0; i < 5; ++i) a.tbl[i] = tbl5[i];
     for (int k = 0; k < c.K; ++k) a.kd[k] = kds[k];
     a.n_iter = n_iter;
     a.with_map = with_map;
