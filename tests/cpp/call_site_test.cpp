@@ -1,11 +1,15 @@
 // call_site_test.cpp -- the reference's call site (src/Tracking.cc:1919-1930) written against
 // the drop-in adapter include/lccrf_densecrf.hpp, checked against the oracle's C API.
 //
-//   call_site_test <inputs.bin>     inputs: int32 N, float obs[N], float err[N], float xy[2N], int16 label[N]
+//   call_site_test <inputs.bin> [repetitions]     repetitions > 0: also time the call site (median, us)
+//                                   inputs: int32 N, float obs[N], float err[N], float xy[2N], int16 label[N]
 //
 // Exit 0 and print "CALL-SITE OK ..." when labels are identical and Q is bit-identical.
 // Exit 3 when the library reports that no GPU is usable (the adapter throws -- no fallback).
+#include <algorithm>
+#include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -76,6 +80,27 @@ int main(int argc, char **argv)
                (bad_label || bad_q) ? "CALL-SITE MISMATCH" : "CALL-SITE OK", N, n_dyn, crf.latticeSize(0),
                crf.latticeSize(1), bad_label, !bad_q);
         orc_crf_destroy(o);
+        const int reps = argc > 2 ? atoi(argv[2]) : 0;
+        if (reps > 0 && !(bad_label || bad_q)) {            // latency of the call site as a C++ caller sees it
+            vector<double> us;
+            for (int r = 0; r < reps + 5; ++r) {
+                const auto t0 = chrono::steady_clock::now();
+                {
+                    DenseCRFHIP<M> c2(N);
+                    c2.setUnaryEnergyFromLabel(init_label.data(), mConf);
+                    c2.addPairwiseEnergy(PottsPotentialHIP<M, 2>::appearanceKernel(N, mW1, vobservs, verrors, mObservStdev, mRpjErrorStdev));
+                    c2.addPairwiseEnergy(PottsPotentialHIP<M, 2>::smoothKernel(N, mW2, vpoints, vcorrd2d, mPoint3dStdev, mPoint2dStdev));
+                    c2.inference(5, true);
+                    volatile short first = c2.getMap()[0];
+                    (void)first;
+                }
+                const auto t1 = chrono::steady_clock::now();
+                if (r >= 5) us.push_back(chrono::duration<double, micro>(t1 - t0).count());
+            }
+            sort(us.begin(), us.end());
+            printf("CALL-SITE LATENCY N=%d median %.1f us  min %.1f us  (%d frames, construct .. getMap .. destroy)\n", N,
+                   us[us.size() / 2], us[0], reps);
+        }
         return (bad_label || bad_q) ? 1 : 0;
     } catch (const std::exception &e) {
         printf("EXCEPTION: %s\n", e.what());
