@@ -4,19 +4,20 @@
 // Why: at SLAM sizes (N ~ 2000 keypoints, V ~ 1.2k lattice vertices) one iteration moves
 // < 0.5 MB; a launch-per-phase design is bound by launch gaps, not by memory (SURVEY.md
 // section 7).  Here the mean-field state lives on chip:
-//     LDS        Q[N][2], both ping-pong lattice value arrays of every kernel, the blur
-//                neighbour table, the CSR row pointers, and the per-entry splat products
-//     registers  everything a point needs for slice/apply/softmax (its d+1 vertex ids,
-//                weights bary*alpha, w*norm, its unary) -- loaded once per launch
-//     L2         the CSR (csr_w, csr_pt) streamed once per iteration, fully coalesced
+//     registers  per point (lane t owns points t, t+1024, ...): unary, Q, and per kernel the
+//                d+1 vertex ids, product slots, barycentric weights and w*norm -- loaded once
+//     LDS        lattice side only: the splat products of every kernel, both ping-pong value
+//                arrays, the blur neighbour table (u16 pairs) and the row pointers
+//     HBM        touched by the prologue (~150 KB of records per frame) and the final store
 //
 // Bit-exactness: the reference splats sequentially over points (permutohedral_cpu.h:653-661),
-// so a vertex's value is a left-to-right fp32 sum in ascending point order.  Phase P forms
-// all products w*Q in parallel (exact, order-free); phase S then adds each vertex's products
-// strictly left to right.  Nothing is re-associated, nothing is fused (-ffp-contract=off).
+// so a vertex's value is a left-to-right fp32 sum in ascending point order.  Phase P writes
+// every product bary*Q into its row at the place the build recorded for it (exact, order-free);
+// phase S then adds each row strictly left to right -- chain_rows for the long rows of the
+// appearance kernel.  Nothing is re-associated, nothing is fused (-ffp-contract=off).
 //
-// Specialised for L = 2 labels (the SLAM configuration, src/Tracking.cc:1919) and kernels of
-// equal dimension D; anything else runs on the streaming engine with identical results.
+// Specialised for L = 2 labels (the SLAM configuration, src/Tracking.cc:1919) and 2-D kernels;
+// anything else runs on the streaming engine with identical results.  DESIGN.md section 4.2.
 #include "engine.h"
 #include "device_math.h"
 
@@ -61,7 +62,6 @@ struct FusedArgs {
     int dbg;                              // LCCRF_FUSED_DBG: 1 skip short-row S, 2 skip chain S (timing only, wrong results); 4 poison LDS
 };
 
-#define PSTAMP() do { if (a.dbg & 8) STAMP(); } while (0)   /* prologue breakdown, LCCRF_FUSED_DBG=8 */
 // prologue breakdown: LCCRF_FUSED_DBG=8
 #define PSTAMP()                      \
     do {                              \
