@@ -1,0 +1,53 @@
+"""Compile-time guard for the two hand-tuned kernels (no GPU needed: hipcc cross-compiles gfx950).
+
+The fused engine's SLAM variants (1-2 points per lane) must not spill: scratch traffic inside the
+mean-field loop costs more than any optimisation in that file gains, and
+chain_rows' hand-written ring relies on v96..v127 being free around it.  The fused build must not
+spill vector registers either."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+
+def resource_usage(src):
+    cmd = [HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "--cuda-device-only",
+           "-I" + os.path.join(ROOT, "lc-crf-slam_amd", "csrc"), "-I" + os.path.join(ROOT, "include"),
+           "-Rpass-analysis=kernel-resource-usage", "-c", os.path.join(ROOT, "lc-crf-slam_amd", "csrc", src), "-o", os.devnull]
+    err = subprocess.run(cmd, capture_output=True, text=True, check=True).stderr
+    out, cur = {}, None
+    for line in err.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            cur = out.setdefault(m.group(1), {})
+            continue
+        m = re.search(r"remark:\s+(VGPRs|AGPRs|ScratchSize \[bytes/lane\]|VGPRs Spill|SGPRs Spill): (\d+)", line)
+        if m and cur is not None:
+            cur[m.group(1)] = int(m.group(2))
+    return out
+
+
+@pytest.mark.skipif(shutil.which(HIPCC) is None, reason="hipcc not installed")
+def test_fused_slam_variants_do_not_spill():
+    use = resource_usage("fused_engine.hip")
+    fused = {k: v for k, v in use.items() if "k_fused" in k}
+    assert len(fused) == 24                                   # PPT 1..4 x K 1..2 x {short rows, chain, late-bound}
+    for name, r in fused.items():
+        ppt = int(re.search(r"k_fusedILi(\d)E", name).group(1))
+        assert r["VGPRs"] + r.get("AGPRs", 0) <= 128, name     # 1024 lanes per workgroup
+        if ppt <= 2:
+            assert r["ScratchSize [bytes/lane]"] == 0 and r["VGPRs Spill"] == 0, (name, r)
+
+
+@pytest.mark.skipif(shutil.which(HIPCC) is None, reason="hipcc not installed")
+def test_fused_build_does_not_spill_vector_registers():
+    use = resource_usage("build_small.hip")
+    build = {k: v for k, v in use.items() if "k_build_small" in k}
+    assert len(build) == 3                                    # d = 1, 2, 3
+    for name, r in build.items():
+        assert r["VGPRs Spill"] == 0 and r["VGPRs"] <= 128, (name, r)
