@@ -336,3 +336,39 @@ def test_step_api_after_deferred_build(po, wl):
     h.step_inference()
     o.step_inference()
     assert cc.same_bits(o.probability(), h.probability())
+
+
+@pytest.mark.gpu
+def test_object_api_from_several_threads(po, wl):
+    """Handles are independent (own stream, own buffers; the parked-handle cache and the error string
+    are the only shared state): four threads running frames of different sizes concurrently must each
+    get the oracle's results.  ctypes releases the GIL during the calls, so the threads really overlap."""
+    import threading
+    sizes = [700, 1300, 2000, 2600]
+    pbs = [wl.slam_problem(n, seed=80 + i) for i, n in enumerate(sizes)]
+    want = []
+    for pb in pbs:
+        o = cc.setup(po.OracleCRF, pb)
+        o.inference_native(5, True)
+        want.append((o.probability().copy(), o.map().copy()))
+        o.close()
+    errors = []
+
+    def worker(t):
+        try:
+            for rep in range(40):
+                j = (t + rep) % len(pbs)
+                h = cc.setup(pkg.DenseCRFHIP, pbs[j])
+                h.inference(5, True)
+                if not (np.array_equal(h.map(), want[j][1]) and cc.same_bits(h.probability(), want[j][0])):
+                    errors.append((t, rep, j))
+                h.close()
+        except Exception as e:                                 # noqa: BLE001
+            errors.append((t, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors[:5]
