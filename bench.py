@@ -34,7 +34,7 @@ def pmc_traffic(name, engine, F):
     Counters cannot be collected inside this process, so this is the figure of the committed
     profile of the SAME command line; None when no matching profile exists."""
     import csv
-    tag = {("c2", 2, 1024): "r1_fused_c2"}.get((name, engine, F))
+    tag = {("c2", 2, 4096): "r1_fused_c2"}.get((name, engine, F))
     fn = os.path.join(ROOT, "profiles", tag or "", "pmc_summary.csv")
     if not tag or not os.path.exists(fn):
         return None
@@ -152,7 +152,7 @@ def main():
 
     name = args.workload
     N, n_iter, _, desc = WORKLOADS[name]
-    F = args.frames or (1 if name == "c5" else 1024)
+    F = args.frames or (1 if name == "c5" else 4096)   # frames in flight per GPU: 16 full waves of workgroups on 256 CUs, ~2.8 GB
     distinct = 1 if name == "c5" else min(F, 16)
     pbs, idx, feats, label, dims, weights = make_batch(wl, name, F, rank, distinct)
     L = 2
