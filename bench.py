@@ -188,7 +188,7 @@ def main():
         b.inference(n_iter, True)
     b.synchronize()
     if world > 1:                                   # untimed: RCCL sets its rings up on first use
-        sh.gather_labels(map_view, d_np)
+        sh.gather_labels(map_view, d_np, n_labels=L)
 
     kernel_ms = []
     barrier()
@@ -197,7 +197,7 @@ def main():
         b.inference(n_iter, True)
     b.synchronize()
     if world > 1:                                   # the one collective: final label gather (RCCL)
-        gathered, _ = sh.gather_labels(map_view, d_np)
+        gathered, _ = sh.gather_labels(map_view, d_np, n_labels=L)
     barrier()
     t1 = time.perf_counter()
     dt = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)

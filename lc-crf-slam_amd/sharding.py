@@ -7,9 +7,9 @@ at SLAM sizes), so a frame is never split.  The unit of distribution is the FRAM
 
 No inter-GPU traffic happens during lattice build or inference.  The only collective is the
 final label gather: every rank contributes its [frames_per_rank, max_points] int16 label
-block (padded; per-frame point counts travel alongside) in ONE all_gather.  RCCL has no
-16-bit integer type, so the block is viewed as bytes.  The payload is KB-scale per frame --
-latency-bound, so no ring/tree tuning and no bucketing: one call.
+block (padded; per-frame point counts travel alongside) in ONE all_gather, one bit per label
+for the binary SLAM CRF (one byte otherwise; RCCL has no 16-bit integer type).  The payload is
+a few hundred bytes per frame -- latency-bound, so no ring/tree tuning and no bucketing: one call.
 
 torch.distributed is plumbing here (backend "nccl" is RCCL on ROCm; "gloo" in CPU tests).
 """
@@ -27,26 +27,44 @@ def frames_per_rank(n_frames, world):
     return (n_frames + world - 1) // world
 
 
-def gather_labels(local_labels, local_counts, group=None):
+def gather_labels(local_labels, local_counts, group=None, n_labels=None):
     """All-gather the per-rank label blocks.
 
     local_labels : int16 [S, max_points]  (S = frames_per_rank slots, unused slots arbitrary)
     local_counts : int32 [S]              points per local frame, -1 for an unused slot
+    n_labels     : label count of the CRF if known.  The wire format is one byte per label
+                   (labels are < 64 < 128; RCCL has no 16-bit integer type anyway), and one BIT
+                   per label for the binary static/dynamic CRF of the SLAM path (n_labels == 2):
+                   250 bytes per 2000-keypoint frame.
     returns (labels [world, S, max_points] int16, counts [world, S] int32), on every rank.
+    Entries beyond a frame's point count are unspecified.
     """
     world = dist.get_world_size(group)
     S, P = local_labels.shape
-    lab_bytes = local_labels.contiguous().view(torch.uint8)              # RCCL: no int16
+    dev = local_labels.device
+    if n_labels == 2:
+        Pb = (P + 7) // 8
+        bits = torch.zeros((S, Pb * 8), dtype=torch.uint8, device=dev)
+        bits[:, :P] = (local_labels & 1).to(torch.uint8)
+        weights = (2 ** torch.arange(8, device=dev, dtype=torch.int32)).to(torch.uint8)       # 1, 2, ..., 128
+        wire = (bits.view(S, Pb, 8) * weights).sum(-1, dtype=torch.int32).to(torch.uint8)
+    else:
+        wire = local_labels.to(torch.int8).contiguous().view(torch.uint8)
     # outputs are the rank blocks concatenated along dim 0 (the layout both RCCL and gloo accept)
-    out_bytes = torch.empty((world * S, lab_bytes.shape[1]), dtype=torch.uint8, device=local_labels.device)
+    out = torch.empty((world * S, wire.shape[1]), dtype=torch.uint8, device=dev)
     counts = torch.empty((world * S,), dtype=torch.int32, device=local_counts.device)
     if world == 1:
-        out_bytes.copy_(lab_bytes)
+        out.copy_(wire)
         counts.copy_(local_counts)
     else:
-        dist.all_gather_into_tensor(out_bytes, lab_bytes, group=group)
+        dist.all_gather_into_tensor(out, wire.contiguous(), group=group)
         dist.all_gather_into_tensor(counts, local_counts.contiguous(), group=group)
-    return out_bytes.view(torch.int16).view(world, S, P), counts.view(world, S)
+    if n_labels == 2:
+        shifts = torch.arange(8, device=dev, dtype=torch.uint8)
+        labels = ((out.unsqueeze(-1) >> shifts) & 1).view(world * S, -1)[:, :P].to(torch.int16)
+    else:
+        labels = out.view(torch.int8).to(torch.int16)
+    return labels.reshape(world, S, P), counts.view(world, S)
 
 
 def unshard(labels, counts, n_frames):

@@ -39,8 +39,11 @@ def main():
         lab = labels_of(wl.slam_problem(sizes[f], seed=500 + f))
         local[s, :sizes[f]] = torch.from_numpy(lab)
         counts[s] = sizes[f]
-    labels, cnt = sh.gather_labels(local, counts)
+    labels, cnt = sh.gather_labels(local, counts)                     # one byte per label on the wire
     per_frame = sh.unshard(labels, cnt, n_frames)
+    labels2, cnt2 = sh.gather_labels(local, counts, n_labels=2)       # one bit per label (the SLAM CRF is binary)
+    for a, b in zip(per_frame, sh.unshard(labels2, cnt2, n_frames)):
+        assert torch.equal(a, b)
     np.savez(out_path + ".rank%d.npz" % rank, **{"f%d" % i: t.numpy() for i, t in enumerate(per_frame)})
     dist.barrier()
     dist.destroy_process_group()
