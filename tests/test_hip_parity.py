@@ -372,3 +372,37 @@ def test_object_api_from_several_threads(po, wl):
     for th in threads:
         th.join()
     assert not errors, errors[:5]
+
+
+@pytest.mark.gpu
+def test_batch_mixing_long_row_and_short_row_frames(po, wl):
+    """One batch, one launch: the chain decision is made once for the batch (longest row over all
+    frames), so frames with short rows ride the chain path of their long-row neighbours and vice versa."""
+    shapes = [("one_cell", 1800), (None, 2000), ("rows_of_8", 1999), ("two_clusters", 2048), (None, 7), ("one_cell", 64)]
+    pbs = [wl.slam_problem(n, seed=90 + i) if sh is None else _shaped_problem(wl, n, sh, seed=90 + i)
+           for i, (sh, n) in enumerate(shapes)]
+    F, maxn = len(pbs), max(pb["N"] for pb in pbs)
+    feats = [np.zeros((F, maxn, 2), np.float32) for _ in range(2)]
+    label = np.full((F, maxn), -1, np.int16)
+    for f, pb in enumerate(pbs):
+        n = pb["N"]
+        label[f, :n] = pb["label"]
+        for k in range(2):
+            feats[k][f, :n] = pb["kernels"][k][0]
+    for eng in (0, 1):
+        b = pkg.BatchCRF(F, maxn, 2, [2, 2], [10.0, 30.0])
+        b.set_engine(eng)
+        b.set_inputs_host([pb["N"] for pb in pbs], feats, label=label, conf=0.7)
+        b.build()
+        b.inference(5, True)
+        Q, M = b.probability(), b.map()
+        if eng == 0:
+            assert b.engine() == 2                         # everything fits one workgroup per frame
+        b.close()
+        for f, pb in enumerate(pbs):
+            o = cc.setup(po.OracleCRF, pb)
+            o.inference_native(5, True)
+            n = pb["N"]
+            assert cc.same_bits(Q[f, :n], o.probability()), (eng, f)
+            assert np.array_equal(M[f, :n], o.map()), (eng, f)
+            o.close()
