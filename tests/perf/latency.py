@@ -3,7 +3,7 @@
 what the call site src/Tracking.cc:1919-1930 would see per frame.  Run on the GPU box."""
 import importlib, os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 pkg = importlib.import_module("lc-crf-slam_amd")
 wl = importlib.import_module("lc-crf-slam_amd.workloads")

@@ -2,7 +2,7 @@
 # Single-frame latency of the call site as a C++ caller sees it (no Python in the loop): builds
 # tests/cpp/call_site_test.cpp against the in-tree libraries and times construct .. getMap .. destroy.
 set -e
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 mkdir -p gpurun_out
 g++ -std=c++14 -O2 -Iinclude tests/cpp/call_site_test.cpp -o gpurun_out/call_site_test \
     lc-crf-slam_amd/liblccrf_hip.so oracle/liblccrf_oracle.so \
