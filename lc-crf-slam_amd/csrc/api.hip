@@ -245,6 +245,7 @@ struct Engine {
         if ((rc = mem.alloc(&k.csr_pos, Fz * E))) return rc;
         if ((rc = mem.alloc(&k.pk, Fz * E))) return rc;
         if ((rc = mem.alloc(&k.nbr16, Fz * k.D1 * E))) return rc;
+        if ((rc = mem.alloc(&k.vperm, Fz * E))) return rc;
         if ((rc = mem.alloc(&k.norm, Fz * maxN))) return rc;
         if ((rc = mem.alloc(&k.val0, Fz * k.vstride))) return rc;
         if ((rc = mem.alloc(&k.val1, Fz * k.vstride))) return rc;

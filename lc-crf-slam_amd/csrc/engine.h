@@ -53,6 +53,9 @@ struct KernelDev {
     // compact copies for the fused engine's prologue (frames with Epad < 65535 only; undefined otherwise)
     unsigned *pk;         // [F][Epad]         (offset + 1) | csr_pos << 16 of every real entry
     unsigned *nbr16;      // [F][D1][Epad]     (n1 + 1) | (n2 + 1) << 16 per (axis, vertex), 0 = absent
+    int *vperm;           // [F][Epad]         vertex id -> the id the fused engine uses internally (pk / nbr16 / its lattice
+                          //                   values are in that numbering; a spatially coherent order makes the blur
+                          //                   gathers near-sequential in LDS).  Identity when no better order is known.
     int *V_host, *rowmax_host;   // [F] pinned host mirrors of V / rowmax written by the fused build (or null)
     float *norm;          // [F][maxN]         1/(K*1 + 1e-20)  (PottsPotential3D::norm_)
     float *val0, *val1;   // [F][vstride]      lattice values (see vbase)

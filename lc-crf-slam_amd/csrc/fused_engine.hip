@@ -41,6 +41,7 @@ struct FusedLayout {                      // byte offsets into dynamic LDS
     int val[kMaxFusedK][2];               // float2 [V_k+1]     slot 0 = absent neighbour = 0
     int nbr[kMaxFusedK];                  // u32    [D1][V_k]   (n1+1) | (n2+1)<<16
     int row[kMaxFusedK];                  // u16    [V_k+1]
+    int perm[kMaxFusedK];                 // u16    [V_k]       vertex -> index of its lattice values (KernelDev::vperm)
     int Ecap[kMaxFusedK];                 // floats per label plane of prod
     int Vcap[kMaxFusedK];
     int prod_all;                         // 1: every kernel has its own product buffer
@@ -103,6 +104,7 @@ __host__ __device__ inline bool layout_core(int NA, int K, const int *V, int row
             L.val[k][1] = take((size_t)(V[k] + 1) * sizeof(float2));
             L.nbr[k] = take((size_t)D1 * V[k] * sizeof(unsigned));
             L.row[k] = take((size_t)(V[k] + 2) * sizeof(unsigned short));
+            L.perm[k] = take((size_t)(V[k] + 2) * sizeof(unsigned short));
             const size_t pb = (size_t)L.Ecap[k] * 2 * sizeof(float);
             if (all) L.prod[k] = take(pb);
             else shared_prod = pb > shared_prod ? pb : shared_prod;
@@ -234,7 +236,7 @@ __global__ void __launch_bounds__(kNT) k_fused(CrfDev c, FusedArgs a)
     // instead of branched on, so that the loads stay back to back.
     constexpr int kNbrRounds = 4, kRowRounds = 2;         // covers V <= 1365 in registers; larger lattices finish in copy loops
     unsigned g_nbr[K][kNbrRounds];
-    int g_row[K][kRowRounds];
+    int g_row[K][kRowRounds], g_perm[K][kRowRounds];
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         const KernelDev &kd = a.kd[k];
@@ -247,7 +249,10 @@ __global__ void __launch_bounds__(kNT) k_fused(CrfDev c, FusedArgs a)
             g_nbr[k][r] = gn[(size_t)j * kd.Epad + (idx - j * V[k])];
         }
 #pragma unroll
-        for (int r = 0; r < kRowRounds; ++r) g_row[k][r] = gr[min(tid + r * kNT, V[k])];
+        for (int r = 0; r < kRowRounds; ++r) {
+            g_row[k][r] = gr[min(tid + r * kNT, V[k])];
+            g_perm[k][r] = kd.vperm[(size_t)f * kd.Epad + min(tid + r * kNT, V[k] - 1)];
+        }
     }
     unsigned pk[PPT][K][D1];              // (vertex id + 1) | place in the row << 16
 #pragma unroll
@@ -298,9 +303,12 @@ __global__ void __launch_bounds__(kNT) k_fused(CrfDev c, FusedArgs a)
             const int idx = tid + r * kNT;
             if (idx < D1 * V[k]) nbr[idx] = g_nbr[k][r];
         }
+        unsigned short *perm = reinterpret_cast<unsigned short *>(smem + lay.perm[k]);
 #pragma unroll
-        for (int r = 0; r < kRowRounds; ++r)
+        for (int r = 0; r < kRowRounds; ++r) {
             if (tid + r * kNT <= V[k]) row[tid + r * kNT] = (unsigned short)g_row[k][r];
+            if (tid + r * kNT < V[k]) perm[tid + r * kNT] = (unsigned short)g_perm[k][r];
+        }
         // lattices with more vertices than the register rounds cover (sparse frames): plain copy loops
         const KernelDev &kd = a.kd[k];
         const unsigned *gn = kd.nbr16 + (size_t)f * D1 * kd.Epad;
@@ -310,6 +318,7 @@ __global__ void __launch_bounds__(kNT) k_fused(CrfDev c, FusedArgs a)
         }
         const int *gr = kd.rowptr + (size_t)f * (kd.Epad + 1);
         for (int v = tid + kRowRounds * kNT; v <= V[k]; v += kNT) row[v] = (unsigned short)gr[v];
+        for (int v = tid + kRowRounds * kNT; v < V[k]; v += kNT) perm[v] = (unsigned short)kd.vperm[(size_t)f * kd.Epad + v];
     }
     if (tid < 16) reinterpret_cast<float *>(smem + lay.zero)[tid] = 0.0f;
     if (CH && tid < 128) hist[tid] = 0;
@@ -405,7 +414,7 @@ __global__ void __launch_bounds__(kNT) k_fused(CrfDev c, FusedArgs a)
             addr = (unsigned)(lay.prod[k] + 4 * (l * lay.Ecap[k] + pst(r0, v)));               // < 2^18
             nblk = (unsigned)((len4 + 7) >> 3);                                                    // 8-product units, < 2^13
             ch_b = nblk | ((unsigned)((len4 >> 2) & 1) << 13) | ((unsigned)(len4 - rl) << 14) |
-                   ((unsigned)((v + 1) * 2 + l) << 16);
+                   ((unsigned)(((int)reinterpret_cast<const unsigned short *>(smem + lay.perm[k])[v] + 1) * 2 + l) << 16);
         }
         unsigned m = nblk;
 #pragma unroll
@@ -484,6 +493,7 @@ __global__ void __launch_bounds__(kNT) k_fused(CrfDev c, FusedArgs a)
             const float2 *pl = reinterpret_cast<const float2 *>(smem + lay.prod[k]);
             const float2 *zero = reinterpret_cast<const float2 *>(smem + lay.zero);
             const unsigned short *row = reinterpret_cast<const unsigned short *>(smem + lay.row[k]);
+            const unsigned short *perm = reinterpret_cast<const unsigned short *>(smem + lay.perm[k]);
             if (tid < s_lo || (a.dbg & 1)) return;
             for (int v = tid - s_lo; v < V[k]; v += kNT - s_lo) {
                 const int t = row[v + 1];
@@ -495,7 +505,7 @@ __global__ void __launch_bounds__(kNT) k_fused(CrfDev c, FusedArgs a)
 #pragma unroll
                     for (int u = 0; u < 8; ++u) { a0 += x[u].x; a1 += x[u].y; }   // strictly left to right
                 }
-                reinterpret_cast<float2 *>(val)[v + 1] = make_float2(a0, a1);
+                reinterpret_cast<float2 *>(val)[(int)perm[v] + 1] = make_float2(a0, a1);
             }
         };
         if (lay.prod_all) {

@@ -158,7 +158,10 @@ __global__ void __launch_bounds__(kBlock) k_offsets(KernelDev kd, const int *__r
     const int r = kd.slot[(size_t)f * kd.cap + kd.slot_of[fe + e]];
     const int id = prefix[r];
     kd.offset[fe + e] = id;
-    if (r == e) kd.rep[fe + id] = e;
+    if (r == e) {
+        kd.rep[fe + id] = e;
+        kd.vperm[fe + id] = id;                            // the streaming build keeps the reference numbering
+    }
 }
 
 template <int D>
