@@ -7,42 +7,37 @@ One "step" = one pass of the hot path over one batch: DenseCRF::inference(n_iter
 (densecrf_base.h:65-73: startInference + n_iter x stepInference + buildMap) for F independent
 frames resident in HBM, through the C-ABI (lccrf_batch_inference).  Lattice construction +
 normalisation (the PottsPotential3D ctor) is done once per batch before the timed region and
-reported separately (build_ms, frames_per_s_end_to_end), as SURVEY.md section 8(d) defines
-the metric.  Frames are independent, so N GPUs shard frames (weak scaling, F per rank); the
-only collective is the final label gather (RCCL all_gather), inside the timed region.
+reported separately (build_ms, frames_per_s_end_to_end), as SURVEY.md section 8(d) defines the
+metric.  Frames are independent, so N GPUs shard frames (weak scaling, F per rank); the only
+collective is the label gather -- ONE RCCL all_gather of the bit-packed labels per step, inside
+the timed region.
 
-Prints ONE JSON line on rank 0.
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself (child
+processes under torch.distributed.run, started before this process touches torch or the GPU).
+
+Prints ONE JSON line on rank 0.  Besides the contract's keys it carries
+  roofline          the dominant kernel against the roof that actually binds it (LDS for the
+                    one-workgroup-per-frame engine, HBM for the streaming engine), frac <= 1
+  c5                the HBM-roofline configuration (100k points, 6-D kernel) timed in the same run
+  single_frame_latency_us   the plug-in surface as the tracker uses it: one frame, host to host
+  cpu_baseline      the reference's own CPU path on this box's cores (1 pinned core, and all cores)
 """
 import argparse
 import importlib
 import json
 import os
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-
-
-def pmc_traffic(name, engine, F):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
-    (profiles/<tag>/pmc_summary.csv: FETCH_SIZE doubled per the gfx950 correction, + WRITE_SIZE).
-    Counters cannot be collected inside this process, so this is the figure of the committed
-    profile of the SAME command line; None when no matching profile exists."""
-    import csv
-    tag = {("c2", 2, 4096): "r1_fused_c2"}.get((name, engine, F))
-    fn = os.path.join(ROOT, "profiles", tag or "", "pmc_summary.csv")
-    if not tag or not os.path.exists(fn):
-        return None
-    tot = 0.0
-    for r in csv.DictReader(open(fn)):
-        if "k_fused" in r["kernel"]:
-            tot += float(r["bytes_corrected"])
-    return tot or None
+# MI355X_MICROARCH.md: HBM3E 8 TB/s spec; LDS bytes per clock per CU by instruction; 256 CUs at 2.4 GHz
+HBM_PEAK_GBS = 8000.0
+N_CU, CLK_HZ = 256, 2.4e9
+LDS_RATE = {"read_b64": 256.0, "read_b128": 256.0, "read_b32": 128.0, "read_u16": 64.0,
+            "write_b32": 64.0, "write_b64": 85.0}
 
 WORKLOADS = {
     # name: (N, n_iter, obs_cap, description)
@@ -62,6 +57,32 @@ def algorithmic_bytes_per_iter(N, L, dims, Vs):
     return b
 
 
+def fused_lds_model(N, dims, Vs, chain0):
+    """LDS bytes one mean-field iteration of one frame moves in the fused engine, by instruction class
+    (DESIGN.md section 4.5 states the same table).  L = 2, every kernel 2-D:
+      P     every point stores 3 products x 2 labels per kernel (chain kernel: 6 ds_write_b32, others 3 ds_write_b64)
+      S     every product is read once (chain: ds_read_b128, short rows: ds_read_b64); per vertex two u16 row
+            pointers, one u16 slot index and one 8-byte value store
+      blur  3 passes x per vertex: neighbour pair (b32), centre + two neighbours (3 x b64), one b64 store
+      X     every point gathers 3 float2 values per kernel (ds_read_b64)
+    Returns (total bytes, minimum LDS-pipe clocks at the per-instruction peak rates)."""
+    by = {k: 0.0 for k in LDS_RATE}
+    for k, (d, V) in enumerate(zip(dims, Vs)):
+        E = 3.0 * N
+        chain = chain0 and k == 0
+        by["write_b32" if chain else "write_b64"] += 8.0 * E          # P
+        by["read_b128" if chain else "read_b64"] += 8.0 * E           # S: products
+        by["read_u16"] += 6.0 * V                                      # S: row[v], row[v+1], perm[v]
+        by["write_b64"] += 8.0 * V                                     # S: value store
+        by["read_b32"] += 3 * 4.0 * V                                  # blur: neighbour pairs
+        by["read_b64"] += 3 * 24.0 * V                                 # blur: centre + 2 neighbours
+        by["write_b64"] += 3 * 8.0 * V                                 # blur: store
+        by["read_b64"] += 8.0 * E                                      # X: gathers
+    total = sum(by.values())
+    clocks = sum(v / LDS_RATE[k] for k, v in by.items())
+    return total, clocks, by
+
+
 class CudaView:
     """Zero-copy torch view of a device buffer owned by the C library."""
 
@@ -72,6 +93,7 @@ class CudaView:
 
 def make_batch(wl, name, F, rank, distinct):
     """F frames for this rank: `distinct` different synthetic frames, tiled."""
+    import numpy as np
     N, n_iter, cap, _ = WORKLOADS[name]
     pbs = []
     for i in range(distinct):
@@ -86,10 +108,18 @@ def make_batch(wl, name, F, rank, distinct):
     return pbs, idx, feats, label, dims, weights
 
 
-def cpu_baseline(pbs, n_iter, budget_s=12.0):
-    """The reference CPU path on this box's host cores (1 core: the reference is
-    single-threaded).  oracle/_ref (the reference's own headers, prebuilt) if present,
-    else the oracle port.  Bounded sample, rank 0 only.  The checker, never the product."""
+# ---------------------------------------------------------------------------------------------
+# CPU baseline: the reference's own CPU path (oracle/_ref, prebuilt from the reference headers) or,
+# if that is absent, the oracle port -- the checker, timed; never the product.
+# ---------------------------------------------------------------------------------------------
+def _cpu_frames(pbs, n_iter, budget_s, core):
+    """Run whole frames (construct, unary, two PottsPotential ctors, inference, destroy) for budget_s
+    seconds on one pinned core.  Returns (frames, seconds in inference, seconds in total, kind)."""
+    if core is not None:
+        try:
+            os.sched_setaffinity(0, {core})
+        except OSError:
+            pass
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import pyoracle as po
     kind, cls = ("reference", po.RefCRF) if po.have_ref() else ("port", po.OracleCRF)
@@ -110,10 +140,190 @@ def cpu_baseline(pbs, n_iter, budget_s=12.0):
         t_inf += t2 - t1
         t_all += t2 - t0
         frames += 1
-    return dict(value=frames * n_iter / t_inf, unit="iters/s", cores=1, kind=kind,
-                sample="%d frames x %d iters of the same workload, inference only, %.1f s of CPU work; "
-                       "end-to-end incl. lattice build: %.1f frames/s" % (frames, n_iter, t_all, frames / t_all),
-                frames_per_s_end_to_end=frames / t_all)
+    return frames, t_inf, t_all, kind
+
+
+def _cpu_worker(args):
+    return _cpu_frames(*args)
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(pbs, n_iter, budget_one=10.0, budget_all=8.0):
+    """(i) one pinned core -- the reference path is single-threaded; (ii) all cores -- independent frames
+    on every core this process may use, the fair comparator of the frames-in-flight number."""
+    import multiprocessing as mp
+    cores = sorted(os.sched_getaffinity(0))
+    slim = [dict(N=pb["N"], L=pb["L"], label=pb["label"], conf=pb["conf"], kernels=pb["kernels"]) for pb in pbs[:4]]
+    saved = os.sched_getaffinity(0)
+    frames, t_inf, t_all, kind = _cpu_frames(slim, n_iter, budget_one, cores[-1])
+    os.sched_setaffinity(0, saved)
+    out = dict(value=frames * n_iter / t_inf, unit="iters/s", cores=1, kind=kind, pinned_core=cores[-1],
+               nproc=len(cores), cpu_model=cpu_model(),
+               sample="%d frames x %d iters of the same workload on one pinned core, inference only, %.1f s of CPU work; "
+                      "end-to-end incl. lattice build: %.1f frames/s" % (frames, n_iter, t_all, frames / t_all),
+               frames_per_s_end_to_end=frames / t_all)
+    try:
+        ctx = mp.get_context("spawn")             # fresh interpreters: nothing of this process (torch, HIP) is inherited
+        with ctx.Pool(len(cores)) as pool:
+            res = pool.map(_cpu_worker, [(slim, n_iter, budget_all, c) for c in cores])
+        out["all_cores"] = dict(cores=len(cores),
+                                value=sum(r[0] * n_iter / r[1] for r in res),       # iters/s, inference only
+                                frames_per_s_end_to_end=sum(r[0] / r[2] for r in res),
+                                sample="%d frames in %.0f s on %d pinned worker processes" % (sum(r[0] for r in res), budget_all, len(cores)))
+    except Exception as e:                        # the 1-core figure stands on its own
+        out["all_cores"] = dict(error=repr(e))
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+# extra records
+# ---------------------------------------------------------------------------------------------
+def single_frame_latency(pkg, pbs, n_iter, reps=240):
+    """The plug-in surface as Tracking::DynamicDetectionWithCRF uses it (src/Tracking.cc:1920-1930):
+    construct, setUnaryEnergyFromLabel, two kernels, inference(5, true), getMap, destroy -- host buffers in,
+    host buffers out, one frame at a time.  Median over `reps` frames, through the ctypes binding, for this
+    library and for the reference's CPU path."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pyoracle as po
+
+    def one(cls, pb, native):
+        t0 = time.perf_counter()
+        c = cls(pb["N"], pb["L"])
+        c.set_unary_from_label(pb["label"], pb["conf"])
+        for f, w in pb["kernels"]:
+            c.add_pairwise(f, w)
+        (c.inference_native if native else c.inference)(n_iter, True)
+        m = c.map()
+        c.close()
+        return (time.perf_counter() - t0) * 1e6, m
+
+    out = {"n_points": pbs[0]["N"], "n_iters": n_iter, "reps": reps,
+           "what": "construct + unary + 2 kernels (lattice + norm) + inference + getMap + destroy, host to host, via ctypes"}
+    ref_cls = po.RefCRF if po.have_ref() else po.OracleCRF
+    for key, cls, native in (("hip", pkg.DenseCRFHIP, False), ("cpu_reference", ref_cls, True)):
+        ts = []
+        for r in range(reps + 10):
+            t, m = one(cls, pbs[r % len(pbs)], native)
+            if r >= 10:
+                ts.append(t)
+        out[key] = float(np.median(ts))
+        out[key + "_p90"] = float(np.percentile(ts, 90))
+    out["cpu_reference_kind"] = "reference" if po.have_ref() else "port"
+    return out
+
+
+def c5_record(pkg, wl, torch, dev, steps=10):
+    """Config C5 (100 000 points, one 6-D kernel, V ~ 5.9e5, 20 iterations, one frame): the configuration whose
+    working set lives in HBM/L2, i.e. the one where the 8 TB/s roof is the applicable one."""
+    import numpy as np
+    N, n_iter, _, desc = WORKLOADS["c5"]
+    pb = wl.bilateral_problem(N, 1)
+    f = torch.from_numpy(pb["kernels"][0][0][None]).to(dev)
+    lab = torch.from_numpy(pb["label"][None]).to(dev)
+    npt = torch.full((1,), N, dtype=torch.int32, device=dev)
+    b = pkg.BatchCRF(1, N, 2, [6], [float(pb["kernels"][0][1])], device=dev.index)
+    b.bind_inputs_device(1, npt.data_ptr(), [f.data_ptr()], d_label=lab.data_ptr(), conf=pb["conf"])
+    b.build(); b.synchronize(); b.build(); b.synchronize()
+    build_ms = b.last_timing()["build_ms"]
+    V = float(b.lattice_sizes(0)[0])
+    for _ in range(2):
+        b.inference(n_iter, True)
+    b.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        b.inference(n_iter, True)
+    b.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    ms = []
+    for _ in range(5):
+        b.inference(n_iter, True)
+        ms.append(b.last_timing()["inference_ms"])
+    inf_ms = float(np.median(ms))
+    bytes_iter = algorithmic_bytes_per_iter(N, 2, [6], [V])
+    achieved = bytes_iter * n_iter / (inf_ms * 1e-3) / 1e9
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pyoracle as po
+    o = po.OracleCRF(N, 2)
+    o.set_unary_from_label(pb["label"], pb["conf"])
+    o.add_pairwise(*pb["kernels"][0])
+    o.inference_native(n_iter, True)
+    match = float((b.map()[0] == o.map()).mean())
+    dq = float(np.abs(b.probability()[0] - o.probability()).max())
+    o.close()
+    b.close()
+    return {"workload": desc, "value": n_iter / dt, "unit": "iters/s", "ms_per_inference": dt * 1e3,
+            "lattice_vertices": V, "build_ms": build_ms,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "algorithmic_bytes_per_iteration": bytes_iter,
+                         "inference_ms": inf_ms, "us_per_iteration": inf_ms * 1e3 / n_iter,
+                         "note": "algorithmic bytes (SURVEY 8d) / HIP-event time of the 20-iteration inference"},
+            "label_match_vs_cpu_reference": match, "max_abs_dQ_vs_cpu_reference": dq}
+
+
+def pmc_traffic(tag):
+    """HBM bytes per launch of the dominant kernel from a committed rocprofv3 --pmc profile of THIS command line
+    (profiles/<tag>/pmc_summary.csv: FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE).  Counters
+    cannot be collected inside this process; None unless such a profile is committed."""
+    import csv
+    fn = os.path.join(ROOT, "profiles", tag or "", "pmc_summary.csv")
+    if not tag or not os.path.exists(fn):
+        return None
+    tot = 0.0
+    for r in csv.DictReader(open(fn)):
+        if "k_fused" in r["kernel"] or "k_frame" in r["kernel"]:
+            tot += float(r["bytes_corrected"])
+    return tot or None
+
+
+# ---------------------------------------------------------------------------------------------
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N`: start the N ranks as CHILD processes.  Nothing in this (parent) process has
+    imported torch or touched HIP, and it only waits: no process that initialised the GPU ever execs."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    return subprocess.run(cmd, env=env).returncode
+
+
+def rehearse_cpu(args, world, rank):
+    """--rehearse-cpu: the rank plumbing (spawn, process group, per-step label gather, max-over-ranks timing)
+    with gloo on CPU tensors and NO compute -- a test of the launcher, prints no metric."""
+    import torch
+    import torch.distributed as dist
+    sh = importlib.import_module("lc-crf-slam_amd.sharding")
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        assert dist.get_world_size() == args.gpus
+    S, W = 8, 32
+    bits = torch.full((S, W), rank + 1, dtype=torch.int64)
+    out = None
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = sh.gather_label_bits(bits)
+    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    ok = all(bool((out[r] == r + 1).all()) for r in range(world))
+    if rank == 0:
+        print(json.dumps({"rehearsal": True, "n_gpus": world, "steps": args.steps, "gathers": args.steps, "gather_ok": ok}))
+    if world > 1:
+        dist.destroy_process_group()
+    return 0 if ok else 1
 
 
 def main():
@@ -126,14 +336,28 @@ def main():
     ap.add_argument("--engine", type=int, default=0, help="0 auto, 1 streaming, 2 fused")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the c5 and single-frame-latency records")
+    ap.add_argument("--distinct", type=int, default=64, help="distinct synthetic frames tiled into the batch")
+    ap.add_argument("--rehearse-cpu", action="store_true", help="launcher test: gloo, no GPU, no compute, no metric")
     args = ap.parse_args()
 
-    import torch
-    import torch.distributed as dist
-
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))          # before torch / HIP are touched
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: refusing to report a number for a different rank count"
+                         % (args.gpus, world))
+    if args.rehearse_cpu:
+        sys.exit(rehearse_cpu(args, world, rank))
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
     # Rehearsal knobs for a 1-GPU box (scripts/rehearse_multi.sh): every rank on one device and a
     # backend that tolerates that.  The driver's runs never set them.
     if "LCCRF_BENCH_DEVICE" in os.environ:
@@ -142,6 +366,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(os.environ.get("LCCRF_BENCH_BACKEND", "nccl"),   # "nccl" is RCCL on ROCm
                                 rank=rank, world_size=world)
+        assert dist.get_world_size() == args.gpus
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -149,11 +374,12 @@ def main():
 
     pkg = importlib.import_module("lc-crf-slam_amd")
     wl = importlib.import_module("lc-crf-slam_amd.workloads")
+    sh = importlib.import_module("lc-crf-slam_amd.sharding")
 
     name = args.workload
     N, n_iter, _, desc = WORKLOADS[name]
-    F = args.frames or (1 if name == "c5" else 4096)   # frames in flight per GPU: 16 full waves of workgroups on 256 CUs, ~2.8 GB
-    distinct = 1 if name == "c5" else min(F, 16)
+    F = args.frames or (1 if name == "c5" else 4096)   # frames in flight per GPU: 16 full waves of workgroups on 256 CUs
+    distinct = 1 if name == "c5" else min(F, args.distinct)
     pbs, idx, feats, label, dims, weights = make_batch(wl, name, F, rank, distinct)
     L = 2
 
@@ -173,31 +399,30 @@ def main():
     b.synchronize()
     build_ms = b.last_timing()["build_ms"]
     engine = b.engine()
-    Vs = [b.lattice_sizes(k).astype(np.float64).mean() for k in range(len(dims))]
+    Vs = [float(b.lattice_sizes(k).astype(np.float64).mean()) for k in range(len(dims))]
 
-    sh = importlib.import_module("lc-crf-slam_amd.sharding")
-    d_map_ptr, _ = b.device_buffers()
-    map_view = torch.as_tensor(CudaView(d_map_ptr, (F, N), "<i2"), device=dev)
+    bits_ptr, words = b.device_label_bits()
+    bits_view = torch.as_tensor(CudaView(bits_ptr, (F, words), "<i8"), device=dev)
+    gathered = torch.empty((world * F, words), dtype=torch.int64, device=dev)
+    # the library's kernels and the collective share torch's current stream: ordering without host round trips
+    stream = torch.cuda.current_stream(dev).cuda_stream
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        b.inference(n_iter, True)
-    b.synchronize()
-    if world > 1:                                   # untimed: RCCL sets its rings up on first use
-        sh.gather_labels(map_view, d_np, n_labels=L)
+    def step():
+        b.inference(n_iter, True, stream=stream)
+        if world > 1:                               # the one collective of the path: the label gather, every batch (RCCL)
+            sh.gather_label_bits(bits_view, out=gathered)
 
-    kernel_ms = []
+    for _ in range(args.warmup):                    # (RCCL sets its rings up on first use)
+        step()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        b.inference(n_iter, True)
-    b.synchronize()
-    if world > 1:                                   # the one collective: final label gather (RCCL)
-        gathered, _ = sh.gather_labels(map_view, d_np, n_labels=L)
+        step()
     barrier()
     t1 = time.perf_counter()
     dt = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
@@ -205,9 +430,16 @@ def main():
         dist.all_reduce(dt, op=dist.ReduceOp.MAX)
     dt = float(dt.item())
 
-    # HIP-event duration of the inference launch(es) on the library's own stream
+    gather_ok = None
+    if world > 1:                                   # every rank's slot of the gathered buffer holds that rank's labels
+        mine = sh.unpack_label_bits(gathered.view(world, F, words)[rank], N)
+        map_ptr, _ = b.device_buffers()
+        gather_ok = bool(torch.equal(mine, torch.as_tensor(CudaView(map_ptr, (F, N), "<i2"), device=dev)))
+
+    # HIP-event duration of the inference launch(es), on the stream they are launched on
+    kernel_ms = []
     for _ in range(5):
-        b.inference(n_iter, True)
+        b.inference(n_iter, True, stream=stream)
         kernel_ms.append(b.last_timing()["inference_ms"])
     inf_ms = float(np.median(kernel_ms))
 
@@ -239,8 +471,37 @@ def main():
         total_iters = float(F) * n_iter * args.steps * world
         value = total_iters / dt
         bytes_iter = algorithmic_bytes_per_iter(N, L, dims, Vs)
-        bytes_launch = bytes_iter * n_iter * F
-        achieved = bytes_launch / (inf_ms * 1e-3) / 1e9
+        alg_launch = bytes_iter * n_iter * F
+        launch_s = inf_ms * 1e-3
+        if engine == 2:
+            # The one-workgroup-per-frame engine keeps the mean-field state in registers and LDS: HBM carries the
+            # per-frame records once per launch.  Its roof is the CU's LDS pipe.
+            chain0 = True                                           # SLAM frames: the appearance kernel takes the chain path
+            lds_bytes, lds_clocks, by = fused_lds_model(N, dims, Vs, chain0)
+            lds_launch = lds_bytes * n_iter * F
+            t_floor = lds_clocks * n_iter * F / N_CU / CLK_HZ       # every CU streaming at the per-instruction peak
+            achieved = lds_launch / launch_s / 1e9
+            peak = lds_launch / t_floor / 1e9
+            traffic = pmc_traffic("r2_fused_c2" if (name, F) == ("c2", 4096) else None)
+            roof = {"bound": "lds", "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": achieved / peak,
+                    "traffic": traffic,
+                    "kernel": "inference launch (start + %d mean-field iterations + map), HIP events" % n_iter,
+                    "launch_ms": inf_ms, "lds_bytes_per_iteration_frame": lds_bytes,
+                    "lds_bytes_by_instruction": by,
+                    "peak_note": "instruction-mix-weighted LDS peak: bytes / sum(bytes_i / rate_i), rates per CU and clock "
+                                 "from MI355X_MICROARCH.md (ds_read_b64/b128 256, ds_read_b32 128, ds_write_b32 64, "
+                                 "ds_write_b64 85 B/clk), 256 CUs at 2.4 GHz",
+                    "hbm_counter_frac": (traffic / launch_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                    "traffic_source": "profiles/r2_fused_c2 (rocprofv3 --pmc of this command line)" if traffic else None,
+                    "algorithmic_hbm_bytes_per_launch": alg_launch,
+                    "note": "SURVEY 8(d)'s byte model counts arrays that this engine keeps in LDS/registers; against HBM "
+                            "the honest figure is hbm_counter_frac"}
+        else:
+            achieved = alg_launch / launch_s / 1e9
+            roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                    "kernel": "inference (start + %d mean-field iterations + map), HIP events" % n_iter,
+                    "algorithmic_bytes_per_launch": alg_launch, "launch_ms": inf_ms}
         out = {
             "metric": "CRF mean-field iters/sec",
             "value": value,
@@ -254,22 +515,27 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": desc, "frames_in_flight_per_gpu": F, "n_points": N, "n_iters": n_iter,
-                       "n_labels": L, "kernel_dims": dims, "mean_lattice_vertices": Vs,
+            "config": {"workload": desc, "frames_in_flight_per_gpu": F, "distinct_frames": distinct, "n_points": N,
+                       "n_iters": n_iter, "n_labels": L, "kernel_dims": dims, "mean_lattice_vertices": Vs,
                        "engine": {1: "streaming", 2: "fused"}.get(engine, str(engine)),
-                       "sharding": "frames over ranks, no data-path collective; final RCCL label all_gather"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(name, engine, F),
-                         "kernel": "inference (start + %d mean-field iterations + map), HIP events" % n_iter,
-                         "algorithmic_bytes_per_launch": bytes_launch, "launch_ms": inf_ms,
-                         "note": "SLAM-size working sets are LDS/register-resident: bound by the CU's LDS pipe and latency, not by HBM"
-                                 if name != "c5" else "lattice values exceed LDS; L2/MALL-resident"},
+                       "sharding": "frames over ranks, no data-path collective; one RCCL all_gather of the bit-packed "
+                                   "labels per step (%d bytes per rank)" % (F * words * 8)},
+            "roofline": roof,
             "build_ms_per_batch": build_ms,
             "frames_per_s_end_to_end": F * world / ((build_ms + inf_ms) * 1e-3),
-            "single_frame_latency_note": "see DESIGN.md; this line is batched throughput",
             "label_match_vs_cpu_reference": label_match,
             "max_abs_dQ_vs_cpu_reference": max_dq,
         }
+        if gather_ok is not None:
+            out["label_gather_ok"] = gather_ok
+        if world == 1 and not args.no_extras:
+            b.close()
+            del d_feats, d_label
+            torch.cuda.empty_cache()
+            if name != "c5":
+                out["c5"] = c5_record(pkg, wl, torch, dev)
+            lat_pbs = pbs[:8] if name != "c5" else [wl.slam_problem(2000, s) for s in range(1, 9)]
+            out["single_frame_latency_us"] = single_frame_latency(pkg, lat_pbs, 5 if name == "c5" else n_iter)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(pbs, n_iter)
         print(json.dumps(out))

@@ -156,6 +156,12 @@ int  lccrf_batch_get_probability_host(lccrf_batch_handle b, float *prob_out);
 int  lccrf_batch_get_lattice_sizes_host(lccrf_batch_handle b, int kernel, int32_t *n_vertices_out);
 int  lccrf_batch_get_norm_host(lccrf_batch_handle b, int kernel, float *norm_out);
 int  lccrf_batch_device_buffers(lccrf_batch_handle b, const int16_t **d_map, const float **d_prob);
+/* Binary CRFs (n_labels == 2, the SLAM configuration src/Tracking.cc:1919): the MAP labels of the last
+ * inference with_map as one BIT per point -- uint64 [n_frames][words_per_frame], point i = bit i%64 of
+ * word i/64, bits beyond a frame's n_points are 0.  Written by the same kernel that writes the int16
+ * labels; this is the payload of the multi-GPU label gather (250 bytes per
+ * 2000-keypoint frame instead of 4000; RCCL has no 16-bit integer type).                          */
+int  lccrf_batch_device_label_bits(lccrf_batch_handle b, const uint64_t **d_bits, int *words_per_frame);
 
 /* Engine selection for the inference loop (both give bit-identical results):
  *   0 = automatic, 1 = streaming kernels over HBM (any size), 2 = fused one-workgroup-

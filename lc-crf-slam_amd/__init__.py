@@ -17,7 +17,9 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblccrf_hip.so")
+# LCCRF_LIB selects another build of the same library (e.g. liblccrf_hip_instr.so from `make INSTRUMENT=1`,
+# used by scripts/gpu_stamps.sh); it must exist -- there is no fallback of any kind.
+LIB_PATH = os.environ.get("LCCRF_LIB") or os.path.join(_HERE, "liblccrf_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "lccrf.h")
 
 MAX_KERNELS = 8
@@ -104,6 +106,7 @@ def lib():
     L.lccrf_batch_get_lattice_sizes_host.argtypes = [vp, C.c_int, _i32p]
     L.lccrf_batch_get_norm_host.argtypes = [vp, C.c_int, _f32p]
     L.lccrf_batch_device_buffers.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
+    L.lccrf_batch_device_label_bits.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_int)]
     L.lccrf_batch_set_engine.argtypes = [vp, C.c_int]
     L.lccrf_batch_get_engine.argtypes = [vp, C.POINTER(C.c_int)]
     L.lccrf_batch_last_timing.argtypes = [vp, _f32p, _f32p]
@@ -333,6 +336,12 @@ class BatchCRF:
         m, q = C.c_void_p(), C.c_void_p()
         _check(lib().lccrf_batch_device_buffers(self.h, C.byref(m), C.byref(q)))
         return m.value, q.value
+
+    def device_label_bits(self):
+        """(device address, words per frame) of the bit-packed MAP labels (binary CRFs only)."""
+        p, w = C.c_void_p(), C.c_int(0)
+        _check(lib().lccrf_batch_device_label_bits(self.h, C.byref(p), C.byref(w)))
+        return p.value, w.value
 
     def last_timing(self):
         a, b = C.c_float(0), C.c_float(0)

@@ -133,6 +133,8 @@ struct Engine {
     int engine_pref = 0, engine_used = 1;
     size_t fused_lds = 0;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   // build begin/end, inference begin/end
+    hipEvent_t ev_order = nullptr;     // orders a caller-supplied stream against the engine's own (StreamScope)
+    int *npoints_bad = nullptr;        // pinned: set by the validation kernel when a bound n_points[f] is outside [0, maxN]
     // Late-bound fused inference (object API): queued right behind the build, before the host has seen
     // the lattice sizes; `late_status` (pinned) tells afterwards whether the frame fitted.
     int *late_status = nullptr;
@@ -157,6 +159,7 @@ struct Engine {
         HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
         mem.stream = stream;
         for (auto &e : ev) HIP_TRY(hipEventCreate(&e));
+        HIP_TRY(hipEventCreateWithFlags(&ev_order, hipEventDisableTiming));
         const size_t nl = (size_t)Fcap * maxN * L;
         int rc;
         if ((rc = mem.alloc(&npoints_own, Fcap))) return rc;
@@ -164,6 +167,8 @@ struct Engine {
         if ((rc = mem.alloc(&crf.Q, nl))) return rc;
         if ((rc = mem.alloc(&crf.next, nl))) return rc;
         if ((rc = mem.alloc(&crf.map, (size_t)Fcap * maxN))) return rc;
+        crf.bits_stride = (maxN + 63) / 64;
+        if (n_labels == 2 && (rc = mem.alloc(&crf.map_bits, (size_t)Fcap * std::max(crf.bits_stride, 1)))) return rc;
         if ((rc = mem.alloc(&label_own, (size_t)Fcap * maxN))) return rc;
         if ((rc = mem.alloc(&tbl, 2 * L + 1))) return rc;
         if ((rc = mem.alloc_pinned(&tbl_host, 2 * L + 1))) return rc;
@@ -171,6 +176,8 @@ struct Engine {
         if ((rc = mem.alloc_pinned(&row_host, (size_t)LCCRF_MAX_KERNELS * Fcap))) return rc;
         if ((rc = mem.alloc_pinned(&late_status, 1))) return rc;
         *late_status = 0;
+        if ((rc = mem.alloc_pinned(&npoints_bad, 1))) return rc;
+        *npoints_bad = 0;
         crf.F = F;
         crf.maxN = maxN;
         crf.L = L;
@@ -186,6 +193,7 @@ struct Engine {
         mem.release();
         for (auto &e : ev)
             if (e) (void)hipEventDestroy(e);
+        if (ev_order) (void)hipEventDestroy(ev_order);
         if (stream) (void)hipStreamDestroy(stream);
         stream = nullptr;
     }
@@ -343,6 +351,10 @@ struct Engine {
         if (rc0) return rc0;
         if (sizes_known) return LCCRF_OK;
         HIP_TRY(hipStreamSynchronize(stream));
+        if (*npoints_bad) {
+            *npoints_bad = 0;
+            return fail(LCCRF_E_CAPACITY, "a bound n_points[f] lies outside [0, max_points=%d] (the kernels clamped it)", maxN);
+        }
         for (size_t k = 0; k < kernels.size(); ++k) {
             int m = 0, r = 0;
             for (int f = 0; f < F; ++f) {
@@ -557,6 +569,7 @@ int lccrf_create(lccrf_handle *out, int device_id, int n_points, int n_labels)
     h->N = n_points;
     h->eng.activeN = n_points;
     h->eng.crf.map = h->map_pin;
+    h->eng.crf.map_bits = nullptr;                       // the packed copy is the batch API's gather payload only
     static const bool no_late = getenv("LCCRF_NO_LATE") != nullptr;   // debugging aid: always size the fused kernel on the host
     h->eng.late_ok = !no_late;
     h->label_stage_busy = false;    // a parked engine's stream is idle (recycle() synchronised it)
@@ -829,6 +842,8 @@ int lccrf_batch_create(lccrf_batch_handle *out, int device_id, const lccrf_batch
     b->desc = *desc;
     rc = b->eng.init(device_id, desc->max_frames, desc->max_points, desc->n_labels);
     for (int k = 0; k < desc->n_kernels && !rc; ++k) rc = b->eng.add_kernel(desc->feat_dims[k], desc->weights[k], true, false);
+    if (!rc && hipStreamSynchronize(b->eng.stream) != hipSuccess)      // every allocation is zeroed before the handle is handed out
+        rc = fail(LCCRF_E_HIP, "hipStreamSynchronize after allocation failed");
     if (rc) {
         b->eng.destroy();
         delete b;
@@ -907,7 +922,10 @@ int lccrf_batch_bind_inputs_device(lccrf_batch_handle b, int n_frames, const int
     if (rc) return rc;
     Engine &e = b->eng;
     e.activeN = 0;                                    // per-frame sizes live on the device: unknown here
-    e.crf.n_points = d_n_points;
+    // the kernels index every per-frame array with n_points[f]: work on a validated copy (clamped to
+    // [0, max_points]; an out-of-range entry raises LCCRF_E_CAPACITY at the next synchronisation point)
+    launch_validate_npoints(d_n_points, e.npoints_own, n_frames, e.maxN, e.npoints_bad, e.stream);
+    e.crf.n_points = e.npoints_own;
     if (d_unary) {
         e.crf.unary = const_cast<float *>(d_unary);   // read-only use
     } else {
@@ -926,17 +944,43 @@ int lccrf_batch_bind_inputs_device(lccrf_batch_handle b, int n_frames, const int
     return LCCRF_OK;
 }
 
-static hipStream_t pick_stream(lccrf_batch *b, void *stream) { return stream ? (hipStream_t)stream : b->eng.stream; }
+// Runs the body of a batch call on a caller-supplied stream.  The engine's own stream carries the
+// zeroing of fresh allocations (Arena::alloc) and the kernels of lccrf_batch_bind_inputs_device, and
+// nothing else orders a foreign stream against it: entering makes the caller's stream wait for
+// everything queued on the own stream so far, leaving makes the own stream (read-backs, later
+// calls) wait for the caller's.  The engine's stream is restored on every exit path.
+struct StreamScope {
+    Engine &e;
+    hipStream_t own, use;
+    StreamScope(Engine &eng, void *stream) : e(eng), own(eng.stream), use(stream ? (hipStream_t)stream : eng.stream) {}
+    int enter()
+    {
+        if (use != own) {
+            HIP_TRY(hipEventRecord(e.ev_order, own));
+            HIP_TRY(hipStreamWaitEvent(use, e.ev_order, 0));
+        }
+        e.stream = use;
+        return LCCRF_OK;
+    }
+    ~StreamScope()
+    {
+        e.stream = own;
+        if (use != own) {
+            (void)hipEventRecord(e.ev_order, use);
+            (void)hipStreamWaitEvent(own, e.ev_order, 0);
+        }
+    }
+};
 
 int lccrf_batch_build(lccrf_batch_handle b, void *stream)
 {
     CHECK_H(b);
     if (!b->inputs_set) return fail(LCCRF_E_STATE, "inputs not set");
     Engine &e = b->eng;
-    hipStream_t own = e.stream;
-    e.stream = pick_stream(b, stream);
+    StreamScope scope(e, stream);
+    int rc = scope.enter();
+    if (rc) return rc;
     HIP_TRY(hipEventRecord(e.ev[0], e.stream));
-    int rc = LCCRF_OK;
     if (!e.kernels.empty()) rc = e.build_kernels(0, (int)e.kernels.size());
     e.built_upto = (int)e.kernels.size();
     if (!rc) {
@@ -945,11 +989,7 @@ int lccrf_batch_build(lccrf_batch_handle b, void *stream)
     }
     e.timed_build = !rc;
     e.built = !rc;
-    if (e.stream != own) {                            // V read-back must land before learn_sizes() looks
-        (void)hipStreamSynchronize(e.stream);
-    }
-    e.stream = own;
-    return rc;
+    return rc;                                        // (learn_sizes() waits on the own stream, which ~StreamScope orders behind this one)
 }
 
 int lccrf_batch_inference(lccrf_batch_handle b, int n_iterations, int with_map, float relax, void *stream)
@@ -959,8 +999,8 @@ int lccrf_batch_inference(lccrf_batch_handle b, int n_iterations, int with_map, 
     if (!e.built) return fail(LCCRF_E_STATE, "lccrf_batch_build has not run for these inputs");
     int rc = e.learn_sizes();
     if (rc) return rc;
-    hipStream_t own = e.stream;
-    e.stream = pick_stream(b, stream);
+    StreamScope scope(e, stream);
+    if ((rc = scope.enter())) return rc;
     HIP_TRY(hipEventRecord(e.ev[2], e.stream));
     rc = e.inference(n_iterations, with_map, relax);
     if (!rc) {
@@ -968,7 +1008,6 @@ int lccrf_batch_inference(lccrf_batch_handle b, int n_iterations, int with_map, 
         if (er != hipSuccess) rc = fail(LCCRF_E_HIP, "hipEventRecord: %s", hipGetErrorString(er));
     }
     e.timed_inf = !rc;
-    e.stream = own;
     return rc;
 }
 
@@ -1027,6 +1066,16 @@ int lccrf_batch_device_buffers(lccrf_batch_handle b, const int16_t **d_map, cons
     CHECK_H(b);
     if (d_map) *d_map = b->eng.crf.map;
     if (d_prob) *d_prob = b->eng.crf.Q;
+    return LCCRF_OK;
+}
+
+int lccrf_batch_device_label_bits(lccrf_batch_handle b, const uint64_t **d_bits, int *words_per_frame)
+{
+    CHECK_H(b);
+    if (!d_bits || !words_per_frame) return fail(LCCRF_E_INVALID, "NULL output");
+    if (!b->eng.crf.map_bits) return fail(LCCRF_E_INVALID, "packed labels exist for binary CRFs (n_labels == 2) only");
+    *d_bits = reinterpret_cast<const uint64_t *>(b->eng.crf.map_bits);
+    *words_per_frame = b->eng.crf.bits_stride;
     return LCCRF_OK;
 }
 

@@ -23,10 +23,14 @@ namespace lccrf {
 
 namespace {
 
+#ifndef LCCRF_INSTRUMENT
+#define LCCRF_INSTRUMENT 0
+#endif
+constexpr bool kInstr = LCCRF_INSTRUMENT != 0;   // `make INSTRUMENT=1`: shader-clock stamps; the release library has none
 __device__ long long g_build_stamps[32];    // debug: shader-clock stamps of workgroup (0,0) (LCCRF_BUILD_TIMING=1)
 #define BSTAMP(i)                                                                              \
     do {                                                                                       \
-        if (stamps && blockIdx.x == 0 && (int)blockIdx.y == stamps - 1 && threadIdx.x == 0) g_build_stamps[i] = clock64(); \
+        if (kInstr && stamps && blockIdx.x == 0 && (int)blockIdx.y == stamps - 1 && threadIdx.x == 0) g_build_stamps[i] = clock64(); \
     } while (0)
 
 constexpr int kBT = 1024;
@@ -472,7 +476,7 @@ bool build_small_supported(const KernelDev *kds, int n, int NA)
 void launch_build_small(const KernelDev *kds, int n, int NA, const CrfDev &c, hipStream_t s)
 {
     const SmallPlan p = small_plan(kds[0], NA);          // same d and same capacities for all n
-    static const int want_stamps = getenv("LCCRF_BUILD_TIMING") ? std::max(atoi(getenv("LCCRF_BUILD_TIMING")), 1) : 0;   // 1 + kernel index
+    static const int want_stamps = (kInstr && getenv("LCCRF_BUILD_TIMING")) ? std::max(atoi(getenv("LCCRF_BUILD_TIMING")), 1) : 0;   // 1 + kernel index
     const dim3 grid(c.F, n);
     const KernelDev &k0 = kds[0], &k1 = kds[n - 1];
 #define BUILD_CASE(DD)                                                                                  \

@@ -70,6 +70,8 @@ struct CrfDev {
     float *Q;             // [F][maxN][L]   current_
     float *next;          // [F][maxN][L]   next_
     int16_t *map;         // [F][maxN]
+    unsigned long long *map_bits;   // [F][bits_stride] or null: the MAP labels of a binary CRF, one bit per point (bit i%64 of
+    int bits_stride;                //   word i/64) -- the wire format of the multi-GPU label gather; bits_stride = ceil(maxN/64)
 };
 
 // ---- streaming engine (any size; every array in HBM) ---------------------------------
@@ -83,6 +85,8 @@ void launch_start(const CrfDev &c, hipStream_t s);
 void launch_step_stream(const CrfDev &c, const KernelDev *kds, const int *maxV, float relax,
                         hipStream_t s);
 void launch_map(const CrfDev &c, hipStream_t s);
+// out[f] = clamp(in[f], 0, maxN); *bad (pinned host memory) is set to 1 if anything had to be clamped
+void launch_validate_npoints(const int *in, int *out, int F, int maxN, int *bad, hipStream_t s);
 
 // ---- fused build (SLAM sizes; one workgroup per (frame, kernel), hash table in LDS) ------
 bool build_small_supported(const KernelDev *kds, int n, int max_points);

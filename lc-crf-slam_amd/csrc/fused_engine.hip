@@ -63,14 +63,21 @@ struct FusedArgs {
     int dbg;                              // LCCRF_FUSED_DBG: 1 skip short-row S, 2 skip chain S (timing only, wrong results); 4 poison LDS
 };
 
-// prologue breakdown: LCCRF_FUSED_DBG=8
+// Instrumentation (shader-clock stamps, phase-skipping experiments) exists only in builds made with
+// `make INSTRUMENT=1` (-DLCCRF_INSTRUMENT=1): the release library reads no debug switch that could change a
+// result.  prologue breakdown: LCCRF_FUSED_DBG=8
+#ifndef LCCRF_INSTRUMENT
+#define LCCRF_INSTRUMENT 0
+#endif
+constexpr bool kInstr = LCCRF_INSTRUMENT != 0;
+#define DBG(bit) (kInstr && (a.dbg & (bit)))
 #define PSTAMP()                      \
     do {                              \
-        if (a.dbg & 8) STAMP();       \
+        if (DBG(8)) STAMP();          \
     } while (0)
 #define STAMP()                                                        \
     do {                                                               \
-        if (a.timing && blockIdx.x == a.timing_block && tid == 0) a.timing[n_stamp++] = clock64(); \
+        if (kInstr && a.timing && blockIdx.x == a.timing_block && tid == 0) a.timing[n_stamp++] = clock64(); \
     } while (0)
 
 constexpr int kChainMinRow = 64;          // kernel 0 runs chain_rows when its longest splat row has at least this many products ...
@@ -226,7 +233,7 @@ __global__ void __launch_bounds__(kNT) k_fused(CrfDev c, FusedArgs a)
         }
     }
     auto chain_k = [&](int k) -> bool { return CH == 2 ? (k == 0 && lay.chain0 != 0) : (((CH >> k) & 1) != 0); };
-    if (a.dbg & 4) {                      // debugging aid: NaN-poison the LDS so that reads of unwritten LDS show up
+    if (DBG(4)) {                      // debugging aid: NaN-poison the LDS so that reads of unwritten LDS show up
         for (int i = tid; i < lay.total / 4; i += kNT) reinterpret_cast<unsigned *>(smem)[i] = 0x7fc00000u + (unsigned)i;
         __syncthreads();
     }
@@ -477,7 +484,7 @@ __global__ void __launch_bounds__(kNT) k_fused(CrfDev c, FusedArgs a)
             float *val = reinterpret_cast<float *>(smem + lay.val[k][0]);
             if (chain_k(k)) {
                 const int npairs = 1 + ((max(V[k] - kChainTop, 0) + 63) >> 6);
-                if ((tid >> 7) < npairs && !(a.dbg & 2)) {                                // whole wavefronts
+                if ((tid >> 7) < npairs && !DBG(2)) {                                // whole wavefronts
                     PSTAMP();
                     const unsigned row_addr = ch_a & 0x3ffffu;
                     const float acc = chain_rows(row_addr, row_addr + ((ch_b & 0x1fffu) * 8u - ((ch_b >> 13) & 1u) * 4u) * 4u,
@@ -494,7 +501,7 @@ __global__ void __launch_bounds__(kNT) k_fused(CrfDev c, FusedArgs a)
             const float2 *zero = reinterpret_cast<const float2 *>(smem + lay.zero);
             const unsigned short *row = reinterpret_cast<const unsigned short *>(smem + lay.row[k]);
             const unsigned short *perm = reinterpret_cast<const unsigned short *>(smem + lay.perm[k]);
-            if (tid < s_lo || (a.dbg & 1)) return;
+            if (tid < s_lo || DBG(1)) return;
             for (int v = tid - s_lo; v < V[k]; v += kNT - s_lo) {
                 const int t = row[v + 1];
                 float a0 = 0.0f, a1 = 0.0f;
@@ -585,9 +592,13 @@ __global__ void __launch_bounds__(kNT) k_fused(CrfDev c, FusedArgs a)
             reinterpret_cast<float2 *>(c.Q)[(size_t)f * c.maxN + i] = q[s];
             if (a.with_map) c.map[(size_t)f * c.maxN + i] = (q[s].x < q[s].y) ? 1 : 0;   // densecrf3d.h:145
         }
+        if (a.with_map && c.map_bits && (i & ~63) < N) {                   // the same labels, one bit each (label gather payload)
+            const unsigned long long m = __ballot(i < N && q[s].x < q[s].y);
+            if ((tid & 63) == 0) c.map_bits[(size_t)f * c.bits_stride + (i >> 6)] = m;
+        }
     }
     STAMP();
-    if (a.timing && blockIdx.x == a.timing_block && tid == 0) a.timing[63] = n_stamp;
+    if (kInstr && a.timing && blockIdx.x == a.timing_block && tid == 0) a.timing[63] = n_stamp;
 }
 
 bool make_layout(const CrfDev &c, const KernelDev *kds, const int *maxV, const int *maxRow, FusedLayout *lay)
@@ -648,12 +659,12 @@ void launch_inference_fused(const CrfDev &c, const KernelDev *kds, const int *ma
     a.with_map = with_map;
     a.relax = relax;
     static long long *timing_buf = nullptr;
-    static const bool want_timing = getenv("LCCRF_FUSED_TIMING") != nullptr;
+    static const bool want_timing = kInstr && getenv("LCCRF_FUSED_TIMING") != nullptr;
     if (want_timing && !timing_buf) (void)hipMalloc(&timing_buf, 64 * sizeof(long long));
     a.timing = want_timing ? timing_buf : nullptr;
     a.timing_block = want_timing ? std::max(atoi(getenv("LCCRF_FUSED_TIMING")) - 1, 0) : 0;
     if (a.timing_block >= c.F) a.timing_block = 0;
-    static const int dbg = getenv("LCCRF_FUSED_DBG") ? atoi(getenv("LCCRF_FUSED_DBG")) : 0;
+    static const int dbg = (kInstr && getenv("LCCRF_FUSED_DBG")) ? atoi(getenv("LCCRF_FUSED_DBG")) : 0;
     a.dbg = dbg;
     const int ppt = ((c.activeN > 0 ? c.activeN : c.maxN) + kNT - 1) / kNT;
     switch (ppt) {

@@ -448,9 +448,27 @@ __global__ void __launch_bounds__(kBlock) k_map(CrfDev c)
 {
     const int f = blockIdx.y;
     const int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= c.n_points[f]) return;
-    const float *p = c.Q + ((size_t)f * c.maxN + i) * c.L;
-    c.map[(size_t)f * c.maxN + i] = (int16_t)argmax_row(p, c.L);
+    const int N = c.n_points[f];
+    int lab = 0;
+    if (i < N) {
+        const float *p = c.Q + ((size_t)f * c.maxN + i) * c.L;
+        lab = argmax_row(p, c.L);
+        c.map[(size_t)f * c.maxN + i] = (int16_t)lab;
+    }
+    if (c.map_bits && c.L == 2 && (i & ~63) < N) {           // one bit per label: the label gather's wire format
+        const unsigned long long m = __ballot(lab == 1);
+        if ((threadIdx.x & 63) == 0) c.map_bits[(size_t)f * c.bits_stride + (i >> 6)] = m;
+    }
+}
+
+__global__ void __launch_bounds__(kBlock) k_validate_npoints(const int *__restrict__ in, int *__restrict__ out, int F,
+                                                             int maxN, int *bad)
+{
+    const int f = blockIdx.x * kBlock + threadIdx.x;
+    if (f >= F) return;
+    const int n = in[f], c = min(max(n, 0), maxN);
+    out[f] = c;
+    if (c != n) *bad = 1;
 }
 
 template <int D>
@@ -572,6 +590,11 @@ void launch_step_stream(const CrfDev &c, const KernelDev *kds, const int *maxV, 
                                                                  k == 0 ? SLICE_APPLY_FIRST : SLICE_APPLY);
     }
     k_softmax<<<grid_for(c.maxN, c.F), kBlock, 0, s>>>(c, c.next, c.Q, 1.0f, relax);
+}
+
+void launch_validate_npoints(const int *in, int *out, int F, int maxN, int *bad, hipStream_t s)
+{
+    k_validate_npoints<<<(F + kBlock - 1) / kBlock, kBlock, 0, s>>>(in, out, F, maxN, bad);
 }
 
 void launch_map(const CrfDev &c, hipStream_t s)

@@ -67,6 +67,29 @@ def gather_labels(local_labels, local_counts, group=None, n_labels=None):
     return labels.reshape(world, S, P), counts.view(world, S)
 
 
+def gather_label_bits(local_bits, out=None, group=None):
+    """The per-step collective of the multi-GPU bench: ONE all_gather of the bit-packed labels the
+    inference kernel wrote itself (lccrf_batch_device_label_bits: int64 [S, words], point i = bit
+    i%64 of word i/64).  No packing kernels on the way: a 2000-keypoint frame is 32 words.
+    returns int64 [world, S, words] on every rank (`out`, if given, is reused)."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    S, W = local_bits.shape
+    if out is None:
+        out = torch.empty((world * S, W), dtype=local_bits.dtype, device=local_bits.device)
+    if world == 1:
+        out.copy_(local_bits)
+    else:
+        dist.all_gather_into_tensor(out, local_bits, group=group)
+    return out.view(world, S, W)
+
+
+def unpack_label_bits(bits, max_points):
+    """int64 [..., words] -> int16 [..., max_points] labels (0 / 1)."""
+    shifts = torch.arange(64, device=bits.device, dtype=torch.int64)
+    lab = (bits.unsqueeze(-1) >> shifts) & 1
+    return lab.reshape(*bits.shape[:-1], -1)[..., :max_points].to(torch.int16)
+
+
 def unshard(labels, counts, n_frames):
     """Back to global frame order: list of 1-D int16 tensors (trimmed to each frame's size)."""
     world = labels.shape[0]

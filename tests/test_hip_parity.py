@@ -406,3 +406,78 @@ def test_batch_mixing_long_row_and_short_row_frames(po, wl):
             assert cc.same_bits(Q[f, :n], o.probability()), (eng, f)
             assert np.array_equal(M[f, :n], o.map()), (eng, f)
             o.close()
+
+
+def test_batch_on_a_caller_stream_right_after_create(wl):
+    """build/inference on a foreign stream must be ordered behind the engine's own stream
+    (allocation memsets, the unary kernel of bind_inputs_device).  Fresh handles every round so that
+    the zeroing of several hundred MB of lattice arrays is still in flight when the build is queued."""
+    import torch
+    F, N = 96, 2000
+    pbs = [wl.slam_problem(N, seed=300 + (i % 3)) for i in range(F)]
+    feats = [np.stack([pb["kernels"][k][0] for pb in pbs]) for k in range(2)]
+    label = np.stack([pb["label"] for pb in pbs])
+    dev = torch.device("cuda", 0)
+    d_feats = [torch.from_numpy(f).to(dev) for f in feats]
+    d_label = torch.from_numpy(label).to(dev)
+    d_np = torch.full((F,), N, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    ref = None
+    for use_foreign in (False, True, True, True):
+        st = torch.cuda.Stream(device=dev) if use_foreign else None
+        b = pkg.BatchCRF(F, N, 2, [2, 2], [10.0, 30.0])
+        b.bind_inputs_device(F, d_np.data_ptr(), [t.data_ptr() for t in d_feats], d_label=d_label.data_ptr(), conf=0.7)
+        b.build(stream=st.cuda_stream if st else None)
+        b.inference(5, True, stream=st.cuda_stream if st else None)
+        Q, M = b.probability(), b.map()
+        b.close()
+        if ref is None:
+            ref = (Q, M)
+        else:
+            assert cc.same_bits(Q, ref[0]) and np.array_equal(M, ref[1])
+
+
+def test_bound_n_points_out_of_range_is_reported_not_followed(wl):
+    """a device-bound n_points[f] > max_points must not make the kernels run past the frame stride."""
+    import torch
+    F, N = 4, 500
+    pbs = [wl.slam_problem(N, seed=310 + i) for i in range(F)]
+    feats = [np.stack([pb["kernels"][k][0] for pb in pbs]) for k in range(2)]
+    label = np.stack([pb["label"] for pb in pbs])
+    dev = torch.device("cuda", 0)
+    d_feats = [torch.from_numpy(f).to(dev) for f in feats]
+    d_label = torch.from_numpy(label).to(dev)
+    d_np = torch.tensor([N, 10 * N, -3, N], dtype=torch.int32, device=dev)
+    b = pkg.BatchCRF(F, N, 2, [2, 2], [10.0, 30.0])
+    b.bind_inputs_device(F, d_np.data_ptr(), [t.data_ptr() for t in d_feats], d_label=d_label.data_ptr(), conf=0.7)
+    b.build()
+    with pytest.raises(pkg.LccrfError) as ei:
+        b.inference(5, True)
+    assert ei.value.code == -6
+    b.close()
+
+
+def test_hip_c5_full_size_matches_oracle(po, wl):
+    """BASELINE config 5 at FULL size: 100 000 points, one 6-D kernel (V ~ 5.9e5: hash capacity
+    2^21, 700k-entry scans, the multi-launch iteration), 20 iterations -- one frame through the object API and one
+    through the batch API against the oracle: lattice size, vertex ids, barycentrics, neighbour table, norm, Q, labels."""
+    pb = wl.bilateral_problem(100000, 1)
+    o = cc.setup(po.OracleCRF, pb)
+    o.inference_native(20, True)
+    ko = o.kernel(0)
+    h = cc.setup(pkg.DenseCRFHIP, pb)
+    h.inference(20, True)
+    kh = h.kernel(0)
+    assert kh["V"] == ko["V"] and kh["V"] > 500000
+    assert np.array_equal(kh["offset"], ko["offset"]) and np.array_equal(kh["nbr"], ko["nbr"])
+    assert cc.same_bits(kh["bary"], ko["bary"]) and cc.same_bits(kh["norm"], ko["norm"])
+    assert cc.same_bits(h.probability(), o.probability())
+    assert np.array_equal(h.map(), o.map())
+    h.close()
+    b = pkg.BatchCRF(1, pb["N"], 2, [6], [float(pb["kernels"][0][1])])
+    b.set_inputs_host([pb["N"]], [pb["kernels"][0][0][None]], label=pb["label"][None], conf=pb["conf"])
+    b.build()
+    b.inference(20, True)
+    assert cc.same_bits(b.probability()[0], o.probability()) and np.array_equal(b.map()[0], o.map())
+    assert int(b.lattice_sizes(0)[0]) == ko["V"]
+    b.close()
