@@ -148,6 +148,13 @@ int  lccrf_batch_build(lccrf_batch_handle b, void *stream);
 /* Per frame: DenseCRF::inference(n_iterations, with_map, relax), densecrf_base.h:65-73. */
 int  lccrf_batch_inference(lccrf_batch_handle b, int n_iterations, int with_map, float relax,
                            void *stream);
+/* Per frame, in ONE kernel launch: every PottsPotential3D ctor (lattice + norm, pairwise3d.h:20-28) followed by
+ * DenseCRF::inference(n_iterations, with_map, relax) (densecrf_base.h:65-73) -- the reference's whole per-frame
+ * sequence src/Tracking.cc:1920-1929.  Needs inputs only (no lccrf_batch_build); the lattices never reach
+ * HBM, so the parity probes (norm, lattice arrays) rebuild them on demand.  Frames the one-launch kernel
+ * cannot take (n_labels != 2, a kernel with d != 2, more than two kernels, > 4096 points, or lattices too
+ * large for one workgroup's LDS) run on the build + inference kernels instead: same results either way.   */
+int  lccrf_batch_run(lccrf_batch_handle b, int n_iterations, int with_map, float relax, void *stream);
 int  lccrf_batch_synchronize(lccrf_batch_handle b);
 
 /* Results: copy to host, or borrow the device buffers ([n_frames][max_points](xL)).     */
@@ -163,9 +170,10 @@ int  lccrf_batch_device_buffers(lccrf_batch_handle b, const int16_t **d_map, con
  * 2000-keypoint frame instead of 4000; RCCL has no 16-bit integer type).                          */
 int  lccrf_batch_device_label_bits(lccrf_batch_handle b, const uint64_t **d_bits, int *words_per_frame);
 
-/* Engine selection for the inference loop (both give bit-identical results):
+/* Engine selection for the inference loop (all give bit-identical results):
  *   0 = automatic, 1 = streaming kernels over HBM (any size), 2 = fused one-workgroup-
- *   per-frame kernel with the lattice values in LDS (SLAM sizes only).                  */
+ *   per-frame kernel with the lattice values in LDS (SLAM sizes only).  lccrf_batch_get_engine
+ *   also reports 3 = the one-launch-per-frame kernel of lccrf_batch_run.                */
 int  lccrf_batch_set_engine(lccrf_batch_handle b, int engine);
 int  lccrf_batch_get_engine(lccrf_batch_handle b, int *engine_in_use);
 

@@ -100,6 +100,7 @@ def lib():
     L.lccrf_batch_bind_inputs_device.argtypes = [vp, C.c_int, vp, vp, vp, _f32p, C.POINTER(vp)]
     L.lccrf_batch_build.argtypes = [vp, vp]
     L.lccrf_batch_inference.argtypes = [vp, C.c_int, C.c_int, C.c_float, vp]
+    L.lccrf_batch_run.argtypes = [vp, C.c_int, C.c_int, C.c_float, vp]
     L.lccrf_batch_synchronize.argtypes = [vp]
     L.lccrf_batch_get_map_host.argtypes = [vp, _i16p]
     L.lccrf_batch_get_probability_host.argtypes = [vp, _f32p]
@@ -300,6 +301,11 @@ class BatchCRF:
     def inference(self, n_iter, with_map=True, relax=1.0, stream=None):
         _check(lib().lccrf_batch_inference(self.h, int(n_iter), int(bool(with_map)), float(relax),
                                            C.c_void_p(stream) if stream else None))
+
+    def run(self, n_iter, with_map=True, relax=1.0, stream=None):
+        """Lattice build + normalisation + inference of every frame in one launch (lccrf_batch_run)."""
+        _check(lib().lccrf_batch_run(self.h, int(n_iter), int(bool(with_map)), float(relax),
+                                     C.c_void_p(stream) if stream else None))
 
     def synchronize(self):
         _check(lib().lccrf_batch_synchronize(self.h))

@@ -120,8 +120,6 @@ struct Engine {
     int *npoints_own = nullptr;
     float *unary_own = nullptr;
     int16_t *label_own = nullptr;
-    float *tbl = nullptr;              // device: {u, n[L], p[L]}
-    float *tbl_host = nullptr;         // pinned
     int *V_host = nullptr;             // pinned [K][Fcap]
     int *row_host = nullptr;           // pinned [K][Fcap]
     std::vector<KernelState> kernels;
@@ -170,8 +168,6 @@ struct Engine {
         crf.bits_stride = (maxN + 63) / 64;
         if (n_labels == 2 && (rc = mem.alloc(&crf.map_bits, (size_t)Fcap * std::max(crf.bits_stride, 1)))) return rc;
         if ((rc = mem.alloc(&label_own, (size_t)Fcap * maxN))) return rc;
-        if ((rc = mem.alloc(&tbl, 2 * L + 1))) return rc;
-        if ((rc = mem.alloc_pinned(&tbl_host, 2 * L + 1))) return rc;
         if ((rc = mem.alloc_pinned(&V_host, (size_t)LCCRF_MAX_KERNELS * Fcap))) return rc;
         if ((rc = mem.alloc_pinned(&row_host, (size_t)LCCRF_MAX_KERNELS * Fcap))) return rc;
         if ((rc = mem.alloc_pinned(&late_status, 1))) return rc;
@@ -253,7 +249,6 @@ struct Engine {
         if ((rc = mem.alloc(&k.csr_pos, Fz * E))) return rc;
         if ((rc = mem.alloc(&k.pk, Fz * E))) return rc;
         if ((rc = mem.alloc(&k.nbr16, Fz * k.D1 * E))) return rc;
-        if ((rc = mem.alloc(&k.vperm, Fz * E))) return rc;
         if ((rc = mem.alloc(&k.norm, Fz * maxN))) return rc;
         if ((rc = mem.alloc(&k.val0, Fz * k.vstride))) return rc;
         if ((rc = mem.alloc(&k.val1, Fz * k.vstride))) return rc;
@@ -373,17 +368,24 @@ struct Engine {
         return LCCRF_OK;
     }
 
-    int set_unary_from_label_tables(const float *conf)
+    // setUnaryEnergyFromLabel (densecrf3d.h:100-130) is deferred: the 2L+1 energies travel as a kernel
+    // argument and either the one-launch-per-frame kernel derives the unaries itself or ensure_unary()
+    // launches the small kernel when somebody needs the array.  `label` must stay readable until then.
+    void defer_unary_from_label(const int16_t *label, const float *conf)
     {
         // densecrf3d.h:109-115.  log(float) binds to the float overload at the reference's call
         // site (src/Tracking.cc:21-43 sees `using namespace std` from include/Tracking.h:55).
-        tbl_host[0] = -logf(1.0f / L);
+        UnaryTable tb;
+        tb.v[0] = -logf(1.0f / L);
         for (int i = 0; i < L; ++i) {
-            tbl_host[1 + i] = -logf((1.0f - conf[i]) / (L - 1));
-            tbl_host[1 + L + i] = -logf(conf[i]);
+            tb.v[1 + i] = -logf((1.0f - conf[i]) / (L - 1));
+            tb.v[1 + L + i] = -logf(conf[i]);
         }
-        HIP_TRY(hipMemcpyAsync(tbl, tbl_host, sizeof(float) * (2 * L + 1), hipMemcpyHostToDevice, stream));
-        return LCCRF_OK;
+        crf.unary = unary_own;
+        unary_deferred = true;
+        deferred_label = label;
+        deferred_tbl = tb;
+        unary_set = true;
     }
 
     int ensure_unary()
@@ -416,30 +418,53 @@ struct Engine {
         return LCCRF_OK;
     }
 
+    // Can the whole frame (lattices + normalisation + inference) run as ONE launch (frame_engine.hip)?
+    bool frame_ok() const
+    {
+        static const bool no_frame = getenv("LCCRF_NO_FRAME") != nullptr;   // cross-check switch: two-kernel path, same results
+        return !no_frame && engine_pref == 0 && !kernels.empty() && frame_supported(crf, kdevs.data());
+    }
+
+    // One launch per frame; whether every frame fitted the kernel's LDS plan is known at the next
+    // synchronisation point (resolve_late), which re-runs the batch on the two-kernel path if not.
+    int run_frame(int n_iter, int with_map, float relax)
+    {
+        *late_status = 0;
+        const bool from_label = unary_deferred && L == 2;
+        launch_frame(crf, kdevs.data(), n_iter, with_map, relax, late_status, from_label ? deferred_label : nullptr,
+                     deferred_tbl.v, stream);
+        HIP_TRY(hipGetLastError());
+        late_pending = true;
+        late_iter = n_iter;
+        late_map = with_map;
+        late_relax = relax;
+        started = true;
+        engine_used = 3;
+        return LCCRF_OK;
+    }
+
     int inference(int n_iter, int with_map, float relax)
     {
         if (n_iter < 0) return fail(LCCRF_E_INVALID, "n_iterations < 0");
         if (!unary_set) return fail(LCCRF_E_STATE, "unary energies not set");
         int rc = resolve_late();
         if (rc) return rc;
-        if (late_ok && !sizes_known && engine_pref == 0 && !kernels.empty() && fused_late_supported(crf, kdevs.data())) {
-            // The host would have to wait for the build just to size the fused kernel's LDS.  Let the
-            // kernel size it itself and find out at the next synchronisation whether the frame fitted.
-            if ((rc = flush_builds())) return rc;
-            *late_status = 0;
-            const bool from_label = unary_deferred && L == 2;
-            if (!from_label && (rc = ensure_unary())) return rc;
-            launch_inference_fused_late(crf, kdevs.data(), n_iter, with_map, relax, late_status,
-                                        from_label ? deferred_label : nullptr, deferred_tbl.v, stream);
-            HIP_TRY(hipGetLastError());
-            late_pending = true;
-            late_iter = n_iter;
-            late_map = with_map;
-            late_relax = relax;
-            started = true;
-            engine_used = 2;
-            return LCCRF_OK;
-        }
+        // Object API: nothing has been built yet (add_pairwise only stages features) -> do not build, run the
+        // frame in one launch.  If a probe already forced the lattices into HBM, iterate on those instead.
+        if (late_ok && frame_ok() && !(built_upto == (int)kernels.size() && sizes_known)) return run_frame(n_iter, with_map, relax);
+        return inference_sized(n_iter, with_map, relax);
+    }
+
+    // lccrf_batch_run: per frame the PottsPotential ctors + inference(n, with_map)
+    int run(int n_iter, int with_map, float relax)
+    {
+        if (n_iter < 0) return fail(LCCRF_E_INVALID, "n_iterations < 0");
+        if (!unary_set) return fail(LCCRF_E_STATE, "unary energies not set");
+        int rc = resolve_late();
+        if (rc) return rc;
+        if (frame_ok()) return run_frame(n_iter, with_map, relax);
+        built_upto = 0;                                   // two-kernel path: rebuild for the current inputs, then infer
+        sizes_known = false;
         return inference_sized(n_iter, with_map, relax);
     }
 
@@ -467,11 +492,10 @@ struct Engine {
         if (!late_pending) return LCCRF_OK;
         late_pending = false;
         HIP_TRY(hipStreamSynchronize(stream));
-        if (*late_status == 0) {
-            unary_deferred = false;                        // the kernel stored the energies it derived
-            return LCCRF_OK;
-        }
-        *late_status = 0;                                  // the frame did not fit one workgroup: run it sized
+        if (*late_status == 0) return LCCRF_OK;
+        *late_status = 0;                                  // a frame did not fit the one-launch kernel: two-kernel path
+        built_upto = 0;
+        sizes_known = false;
         return inference_sized(late_iter, late_map, late_relax);
     }
 };
@@ -650,19 +674,9 @@ int lccrf_set_unary_from_label(lccrf_handle h, const int16_t *label, const float
     if (h->label_stage_busy) HIP_TRY(hipStreamSynchronize(e.stream));   // an earlier call's kernel may still read the staging buffer
     // No uploads: the 2L+1 energies travel as a kernel argument and the kernel reads the labels from
     // pinned host memory (each tiny DMA command costs ~10 us of stream time; this path is latency-bound).
-    UnaryTable tb;                                        // densecrf3d.h:109-115, logf: see set_unary_from_label_tables
-    tb.v[0] = -logf(1.0f / e.L);
-    for (int i = 0; i < e.L; ++i) {
-        tb.v[1 + i] = -logf((1.0f - conf[i]) / (e.L - 1));
-        tb.v[1 + e.L + i] = -logf(conf[i]);
-    }
     if (h->N) memcpy(h->stage_i16, label, (size_t)h->N * sizeof(int16_t));
-    e.crf.unary = e.unary_own;
-    e.unary_deferred = true;                              // launched (or folded into the fused kernel) by the first consumer
-    e.deferred_label = h->stage_i16;
-    e.deferred_tbl = tb;
+    e.defer_unary_from_label(h->stage_i16, conf);         // launched (or folded into the frame kernel) by the first consumer
     h->label_stage_busy = true;
-    e.unary_set = true;
     return LCCRF_OK;
 }
 
@@ -867,10 +881,13 @@ static int batch_common_inputs(lccrf_batch *b, int n_frames, const float *conf, 
     if (n_frames < 1 || n_frames > e.Fcap) return fail(LCCRF_E_CAPACITY, "n_frames %d not in [1,%d]", n_frames, e.Fcap);
     if (have_unary == have_label) return fail(LCCRF_E_INVALID, "exactly one of unary / label must be given");
     if (have_label && (!conf || e.L < 2)) return fail(LCCRF_E_INVALID, "label input needs conf[n_labels] and >= 2 labels");
+    { int rl = e.resolve_late(); if (rl) return rl; }
     e.F = n_frames;
     e.sync_views();
     e.unary_set = false;
     e.built = false;
+    e.built_upto = 0;
+    e.sizes_known = false;
     e.started = false;
     return LCCRF_OK;
 }
@@ -895,10 +912,10 @@ int lccrf_batch_set_inputs_host(lccrf_batch_handle b, int n_frames, const int32_
     const size_t per = (size_t)e.maxN;
     if (unary) {
         HIP_TRY(hipMemcpy(e.unary_own, unary, sizeof(float) * n_frames * per * e.L, hipMemcpyHostToDevice));
+        e.unary_deferred = false;
     } else {
         HIP_TRY(hipMemcpy(e.label_own, label, sizeof(int16_t) * n_frames * per, hipMemcpyHostToDevice));
-        if ((rc = e.set_unary_from_label_tables(conf))) return rc;
-        launch_unary_from_label(e.crf, e.label_own, e.tbl, e.stream);
+        e.defer_unary_from_label(e.label_own, conf);
     }
     for (int k = 0; k < b->desc.n_kernels; ++k) {
         if (!features[k]) return fail(LCCRF_E_INVALID, "features[%d] is NULL", k);
@@ -928,10 +945,9 @@ int lccrf_batch_bind_inputs_device(lccrf_batch_handle b, int n_frames, const int
     e.crf.n_points = e.npoints_own;
     if (d_unary) {
         e.crf.unary = const_cast<float *>(d_unary);   // read-only use
+        e.unary_deferred = false;
     } else {
-        e.crf.unary = e.unary_own;
-        if ((rc = e.set_unary_from_label_tables(conf))) return rc;
-        launch_unary_from_label(e.crf, d_label, e.tbl, e.stream);
+        e.defer_unary_from_label(d_label, conf);
     }
     for (int k = 0; k < b->desc.n_kernels; ++k) {
         if (!d_features[k]) return fail(LCCRF_E_INVALID, "d_features[%d] is NULL", k);
@@ -1011,12 +1027,31 @@ int lccrf_batch_inference(lccrf_batch_handle b, int n_iterations, int with_map, 
     return rc;
 }
 
+int lccrf_batch_run(lccrf_batch_handle b, int n_iterations, int with_map, float relax, void *stream)
+{
+    CHECK_H(b);
+    if (!b->inputs_set) return fail(LCCRF_E_STATE, "inputs not set");
+    Engine &e = b->eng;
+    StreamScope scope(e, stream);
+    int rc = scope.enter();
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(e.ev[2], e.stream));
+    rc = e.run(n_iterations, with_map, relax);
+    if (!rc) {
+        hipError_t er = hipEventRecord(e.ev[3], e.stream);
+        if (er != hipSuccess) rc = fail(LCCRF_E_HIP, "hipEventRecord: %s", hipGetErrorString(er));
+    }
+    e.timed_inf = !rc;
+    e.built = e.built_upto == (int)e.kernels.size() && !e.kernels.empty();
+    return rc;
+}
+
 int lccrf_batch_synchronize(lccrf_batch_handle b)
 {
     CHECK_H(b);
     HIP_TRY(hipStreamSynchronize(b->eng.stream));
     HIP_TRY(hipDeviceSynchronize());
-    return LCCRF_OK;
+    return b->eng.resolve_late();
 }
 
 int lccrf_batch_get_map_host(lccrf_batch_handle b, int16_t *map_out)
@@ -1024,6 +1059,7 @@ int lccrf_batch_get_map_host(lccrf_batch_handle b, int16_t *map_out)
     CHECK_H(b);
     if (!map_out) return fail(LCCRF_E_INVALID, "map_out is NULL");
     Engine &e = b->eng;
+    { int rl = b->eng.resolve_late(); if (rl) return rl; }
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(map_out, e.crf.map, sizeof(int16_t) * (size_t)e.F * e.maxN, hipMemcpyDeviceToHost));
     return LCCRF_OK;
@@ -1034,6 +1070,7 @@ int lccrf_batch_get_probability_host(lccrf_batch_handle b, float *prob_out)
     CHECK_H(b);
     if (!prob_out) return fail(LCCRF_E_INVALID, "prob_out is NULL");
     Engine &e = b->eng;
+    { int rl = b->eng.resolve_late(); if (rl) return rl; }
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(prob_out, e.crf.Q, sizeof(float) * (size_t)e.F * e.maxN * e.L, hipMemcpyDeviceToHost));
     return LCCRF_OK;
@@ -1045,6 +1082,7 @@ int lccrf_batch_get_lattice_sizes_host(lccrf_batch_handle b, int kernel, int32_t
     CHECK_K(b, kernel);
     if (!n_vertices_out) return fail(LCCRF_E_INVALID, "n_vertices_out is NULL");
     Engine &e = b->eng;
+    { int rl = b->eng.resolve_late(); if (rl) return rl; }
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(n_vertices_out, e.kernels[kernel].dev.V, sizeof(int) * e.F, hipMemcpyDeviceToHost));
     return LCCRF_OK;
@@ -1056,6 +1094,8 @@ int lccrf_batch_get_norm_host(lccrf_batch_handle b, int kernel, float *norm_out)
     CHECK_K(b, kernel);
     if (!norm_out) return fail(LCCRF_E_INVALID, "norm_out is NULL");
     Engine &e = b->eng;
+    { int rl = b->eng.resolve_late(); if (rl) return rl; }
+    { int rf = b->eng.flush_builds(); if (rf) return rf; }   // lccrf_batch_run builds nothing in HBM
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(norm_out, e.kernels[kernel].dev.norm, sizeof(float) * (size_t)e.F * e.maxN, hipMemcpyDeviceToHost));
     return LCCRF_OK;
@@ -1092,6 +1132,7 @@ int lccrf_batch_get_engine(lccrf_batch_handle b, int *engine_in_use)
 {
     CHECK_H(b);
     if (!engine_in_use) return fail(LCCRF_E_INVALID, "engine_in_use is NULL");
+    { int rl = b->eng.resolve_late(); if (rl) return rl; }   // a one-launch run may have fallen back
     int rc = b->eng.built ? b->eng.learn_sizes() : LCCRF_OK;
     if (rc) return rc;
     *engine_in_use = b->eng.engine_used;
@@ -1152,6 +1193,7 @@ int lccrf_batch_last_timing(lccrf_batch_handle b, float *inference_ms, float *bu
 {
     CHECK_H(b);
     Engine &e = b->eng;
+    { int rl = b->eng.resolve_late(); if (rl) return rl; }
     HIP_TRY(hipDeviceSynchronize());
     if (build_ms) {
         *build_ms = 0.0f;

@@ -186,10 +186,7 @@ __global__ void __launch_bounds__(kBT) k_build_small(KernelDev kd0, KernelDev kd
         const int id = pfx[first];
         kd.offset[fe + e] = id;
         sof[e] = (unsigned short)id;                      // from here on sof[e] is the vertex id of entry e
-        if (first == e) {
-            rep_s[id] = (unsigned short)e;
-            kd.vperm[fe + id] = id;
-        }
+        if (first == e) rep_s[id] = (unsigned short)e;
     }
     lds_barrier();
     BSTAMP(4);

@@ -53,9 +53,6 @@ struct KernelDev {
     // compact copies for the fused engine's prologue (frames with Epad < 65535 only; undefined otherwise)
     unsigned *pk;         // [F][Epad]         (offset + 1) | csr_pos << 16 of every real entry
     unsigned *nbr16;      // [F][D1][Epad]     (n1 + 1) | (n2 + 1) << 16 per (axis, vertex), 0 = absent
-    int *vperm;           // [F][Epad]         vertex id -> the id the fused engine uses internally (pk / nbr16 / its lattice
-                          //                   values are in that numbering; a spatially coherent order makes the blur
-                          //                   gathers near-sequential in LDS).  Identity when no better order is known.
     int *V_host, *rowmax_host;   // [F] pinned host mirrors of V / rowmax written by the fused build (or null)
     float *norm;          // [F][maxN]         1/(K*1 + 1e-20)  (PottsPotential3D::norm_)
     float *val0, *val1;   // [F][vstride]      lattice values (see vbase)
@@ -77,8 +74,8 @@ struct CrfDev {
 // ---- streaming engine (any size; every array in HBM) ---------------------------------
 void launch_build_kernel(const KernelDev &kd, const CrfDev &c, int maxV_hint, hipStream_t s);
 void launch_norm(const KernelDev &kd, const CrfDev &c, int maxV, hipStream_t s);
-void launch_unary_from_label(const CrfDev &c, const int16_t *label, const float *tbl, hipStream_t s);
-// same, with the 2L+1 energies passed by value (no table upload; `label` may be pinned host memory)
+// unary[i][:] from labels (densecrf3d.h:116-129); the 2L+1 energies {u, n[L], p[L]} are passed by value (no table
+// upload; `label` may be device or pinned host memory)
 struct UnaryTable { float v[2 * LCCRF_MAX_LABELS + 1]; };
 void launch_unary_from_label_tbl(const CrfDev &c, const int16_t *label, const UnaryTable &tbl, hipStream_t s);
 void launch_start(const CrfDev &c, hipStream_t s);
@@ -97,11 +94,14 @@ bool fused_supported(const CrfDev &c, const KernelDev *kds, const int *maxV, con
                      size_t *lds_bytes);
 void launch_inference_fused(const CrfDev &c, const KernelDev *kds, const int *maxV, const int *maxRow,
                             int n_iter, int with_map, float relax, hipStream_t s);
-bool fused_late_supported(const CrfDev &c, const KernelDev *kds);
-// label != nullptr (L = 2): the unary energies are derived in the kernel from the labels and the 5 table
-// entries {u, n0, n1, p0, p1} and stored to c.unary as a by-product
-void launch_inference_fused_late(const CrfDev &c, const KernelDev *kds, int n_iter, int with_map, float relax,
-                                 int *status, const int16_t *label, const float *tbl5, hipStream_t s);
+
+// ---- frame engine (SLAM sizes; lattice build + normalisation + inference of a frame in ONE launch) ---------
+bool frame_supported(const CrfDev &c, const KernelDev *kds);
+// label != nullptr (L = 2): the unary energies are derived in the kernel from the labels and the 5 table entries
+// {u, n0, n1, p0, p1}; otherwise read from c.unary.  `status` (pinned host word, zeroed by the caller) reads 1
+// afterwards if some frame did not fit the kernel's LDS plan; the caller then runs the two-kernel path.
+void launch_frame(const CrfDev &c, const KernelDev *kds, int n_iter, int with_map, float relax, int *status,
+                  const int16_t *label, const float *tbl5, hipStream_t s);
 
 // ---- unary builder (the step before the CRF) ------------------------
 hipError_t run_unary_build(int device_id, int n_points, const float *Xw, const int32_t *obs_ptr, const int32_t *obs_kf,

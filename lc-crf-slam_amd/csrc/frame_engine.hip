@@ -1,0 +1,560 @@
+// frame_engine.hip -- one frame's WHOLE CRF as ONE kernel launch (SURVEY.md section 7's design stance):
+// one 1024-lane workgroup per frame builds both permutohedral lattices, normalises both kernels, runs
+// startInference, every mean-field iteration and buildMap.  HBM is touched twice: the frame's inputs
+// (features of every kernel + labels or unary energies, ~36 KB at N = 2000) are read once, Q and the MAP
+// labels (~20 KB) are written once.  Nothing else leaves the CU: the reference's per-frame sequence
+//     DenseCRF3D crf(N); crf.setUnaryEnergyFromLabel(..); crf.addPairwiseEnergy(appearanceKernel(..));
+//     crf.addPairwiseEnergy(smoothKernel(..)); crf.inference(5, true);            (src/Tracking.cc:1920-1929)
+// costs one launch.  L = 2 labels, 2-D kernels, K <= 2, N <= 4096 -- the SLAM configuration; anything else
+// (and any frame whose lattices do not fit the LDS plan below) runs on the two-kernel / streaming path with
+// identical results.
+//
+// Lattice construction here is NOT the streaming build's algorithm (stream_engine.hip / build_small.hip keep
+// the reference's vertex numbering because the parity probes compare offset_/blur_neighbors_ verbatim).  The
+// mean-field result does not depend on how vertices are numbered -- a vertex's value is a sum over its OWN
+// row in ascending point order, and blur neighbours are found by key -- so this kernel uses whatever
+// numbering is cheapest:
+//   keys in the table   a 2-D vertex key is two int16 = one 32-bit word: the LDS hash table stores the key
+//                       itself (ds_cmpst claims a slot or finds the key; no representative entry, no key
+//                       recomputation while probing), permutohedral_cpu.h:66-167,371-377
+//   ids by slot order   dense vertex ids = exclusive scan of "slot occupied" (no first-occurrence machinery)
+//   neighbours          one lane per vertex probes the same table for key +- 1, permutohedral_cpu.h:408-421
+//   row order           a product's place in its vertex's row must follow ascending point index (quirk Q6).
+//                       Short rows (the smoothness kernel, ~5 entries per vertex): entries are dropped into
+//                       their row in arrival order and every entry counts the smaller entry ids of its row
+//                       (one ds_read_b64 per 4 entries).  Long rows (the appearance kernel, ~50 entries per
+//                       vertex): a bitmap per vertex over the points; rank = prefix popcount.
+//   normalisation       pairwise3d.h:20-28 is one splat/blur/slice of all-ones: the loop's own phases run
+//                       once with Q = 1 before startInference (ordered row sums included).
+// What must match the reference exactly does: the point records (point_record<2>, quirks Q1-Q4, phantom
+// points of the last block of four included), the set of vertices (V is reported and tested against the
+// reference's M_), the order of every sum.  ref: permutohedral_cpu.h:241-424,634-699; densecrf_base.h:65-91.
+#include "engine.h"
+#include "device_math.h"
+#include "fused_loop.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+
+namespace lccrf {
+
+namespace {
+
+using namespace fl;
+
+constexpr unsigned kEmptyKey = 0x80008000u;       // (-32768, -32768): not a key any sane feature produces; a frame that does is sent to the fallback path
+constexpr int kHdr = 512;                          // [0,128) unused, [128,192) zero block, [192,512) scan scratch / flags
+
+struct FrameArgs {
+    const float *feat[kMaxFusedK];        // [F][maxN][2] features of kernel k (already divided by the stdev)
+    float w[kMaxFusedK];                  // kernel weights (PottsPotential3D::w_)
+    float scale[2], inv_dp1, alpha;       // d = 2 constants: permutohedral_cpu.h:249,282-285,681
+    int maxN;                             // per-frame stride of feat / label / unary / Q / map
+    const int16_t *label;                 // non-null: unary energies from labels and tbl (densecrf3d.h:100-130, L = 2)
+    float tbl[5];                         //   {u, n0, n1, p0, p1}
+    int n_iter, with_map;
+    float relax;
+    int hcap;                             // hash capacity (power of two >= 1024)
+    int lds_total;                        // dynamic LDS bytes of the launch
+    int *V_out[kMaxFusedK];               // [F] vertices per kernel (reference M_), or null
+    int *status;                          // pinned host word: set to 1 when a frame does not fit this kernel's LDS plan
+    long long *timing;                    // instrumented builds only
+    int timing_block;
+};
+
+struct Hdr {                              // lives at smem + 192
+    int wave_sum[16];
+    int fail;
+    int rowmax;
+};
+
+__device__ __forceinline__ unsigned hash32(unsigned key)
+{
+    unsigned h = key * 2654435761u;
+    h ^= h >> 15;
+    h *= 2246822519u;
+    h ^= h >> 13;
+    return h;
+}
+
+// Exclusive scan of one int per lane over the workgroup; returns the prefix, `total` the grand total.
+// Two barriers; wave_sum may be reused right after the call returns only behind another barrier.
+__device__ __forceinline__ int block_excl_scan(int x, int tid, int *wave_sum, int &total)
+{
+    const int lane = tid & 63, wave = tid >> 6;
+    int incl = x;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int y = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += y;
+    }
+    __syncthreads();                                      // a previous scan's readers are done with wave_sum
+    if (lane == 63) wave_sum[wave] = incl;
+    __syncthreads();
+    int wbase = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < kNT / 64; ++w) {
+        const int y = wave_sum[w];
+        if (w < wave) wbase += y;
+        tot += y;
+    }
+    total = tot;
+    return wbase + incl - x;
+}
+
+// key of the simplex corner with remainder `rem` of a point record, packed (x | y << 16)
+__device__ __forceinline__ unsigned corner_key(const int16_t (&r0)[2], const uint8_t (&rk)[2], int rem)
+{
+    const unsigned x = (unsigned short)vertex_coord<2>(r0[0], rk[0], rem);
+    const unsigned y = (unsigned short)vertex_coord<2>(r0[1], rk[1], rem);
+    return x | (y << 16);
+}
+
+template <int PPT, int K>
+__global__ void __launch_bounds__(kNT) k_frame(CrfDev c, FrameArgs a)
+{
+    constexpr int D1 = kD1;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int f = blockIdx.x, tid = threadIdx.x;
+    const int N = c.n_points[f];
+    Instr ins{a.timing, a.timing_block, 8, 0};
+    FL_STAMP();
+    if (N <= 0) {                                         // an empty frame has no lattice (V = 0) and nothing to infer
+        if (tid < K && a.V_out[tid]) a.V_out[tid][f] = 0;
+        return;
+    }
+    const int Npad = (N + 3) & ~3;                       // blocks of four, permutohedral_cpu.h:294 (quirk Q1)
+    Hdr *hdr = reinterpret_cast<Hdr *>(smem + 192);
+    const int hcap = a.hcap, per = hcap / kNT;
+    const unsigned mask = (unsigned)hcap - 1u;
+    const int hk_off = a.lds_total - hcap * 4, ido_off = hk_off - hcap * 2;
+    unsigned *hk = reinterpret_cast<unsigned *>(smem + hk_off);                  // hash table: the keys themselves
+    unsigned short *ido = reinterpret_cast<unsigned short *>(smem + ido_off);    // slot -> vertex id
+
+    // ---- inputs: every global load of the launch is issued here --------------------------------
+    PointRegs<PPT, K> pr;
+    float2 ft[PPT][K];
+#pragma unroll
+    for (int s = 0; s < PPT; ++s) {
+        const int ic = min(tid + s * kNT, N - 1);
+#pragma unroll
+        for (int k = 0; k < K; ++k) ft[s][k] = reinterpret_cast<const float2 *>(a.feat[k])[(size_t)f * a.maxN + ic];
+        if (a.label) {                                    // densecrf3d.h:116-129 with L = 2
+            const int t = a.label[(size_t)f * a.maxN + ic];
+            const bool known = t >= 0 && t < 2;
+            pr.un[s].x = !known ? a.tbl[0] : (t == 0 ? a.tbl[3] : a.tbl[1 + t]);
+            pr.un[s].y = !known ? a.tbl[0] : (t == 1 ? a.tbl[4] : a.tbl[1 + t]);
+        } else {
+            pr.un[s] = reinterpret_cast<const float2 *>(c.unary)[(size_t)f * c.maxN + ic];
+        }
+    }
+    if (tid < 16) reinterpret_cast<float *>(smem + 128)[tid] = 0.0f;
+    if (tid == 0) { hdr->fail = 0; hdr->rowmax = 0; }
+
+    FusedLayout lay{};
+    lay.zero = 128;
+    int V[K], row0max = 0;
+    unsigned pk[PPT][K][D1];              // (vertex id + 1) | place in the row << 16, as the HBM records of k_fused
+    int cursor = kHdr;
+
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        // ---- A: point records (elevate, round, rank, barycentric) and the keys of their three corners ----
+        unsigned key[PPT][D1];
+#pragma unroll
+        for (int s = 0; s < PPT; ++s) {
+            const int i = tid + s * kNT;
+            float feat[2] = {i < N ? ft[s][k].x : 0.0f, i < N ? ft[s][k].y : 0.0f};   // phantom lanes, :299
+            int16_t r0[2];
+            uint8_t rk[2];
+            float b[D1];
+            point_record<2>(feat, a.scale, a.inv_dp1, r0, rk, b);
+#pragma unroll
+            for (int j = 0; j < D1; ++j) {
+                pr.bary[s][k][j] = b[j];
+                key[s][j] = corner_key(r0, rk, j);
+            }
+        }
+        for (int u = tid; u < hcap; u += kNT) hk[u] = kEmptyKey;
+        __syncthreads();
+        FL_PSTAMP();
+
+        // ---- B: insert.  ds_cmpst either claims an empty slot for the key or returns the key that lives there ----
+        unsigned slot[PPT][2];            // slot0 | slot1 << 16, slot2
+#pragma unroll
+        for (int s = 0; s < PPT; ++s) {
+            unsigned sl[D1] = {0u, 0u, 0u};
+            if (tid + s * kNT < Npad) {
+#pragma unroll
+                for (int j = 0; j < D1; ++j) {
+                    const unsigned kk = key[s][j];
+                    unsigned h = hash32(kk) & mask;
+                    int probes = 0;
+                    for (;;) {
+                        const unsigned prev = atomicCAS(&hk[h], kEmptyKey, kk);
+                        if (prev == kEmptyKey || prev == kk) break;
+                        h = (h + 1u) & mask;
+                        if (++probes >= hcap) { hdr->fail = 1; break; }
+                    }
+                    if (kk == kEmptyKey) hdr->fail = 1;
+                    sl[j] = h;
+                }
+            }
+            slot[s][0] = sl[0] | (sl[1] << 16);
+            slot[s][1] = sl[2];
+        }
+        __syncthreads();
+        FL_PSTAMP();
+
+        // ---- C: dense vertex ids in slot order; carve this kernel's persistent tables -------------------
+        unsigned okey[16];                // this lane's `per` consecutive slots (per <= 16)
+        int nocc = 0;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            okey[u] = kEmptyKey;
+            if (u < per) {
+                okey[u] = hk[tid * per + u];
+                nocc += okey[u] != kEmptyKey;
+            }
+        }
+        int Vk;
+        int id = block_excl_scan(nocc, tid, hdr->wave_sum, Vk);
+        V[k] = Vk;
+        const int W = (Npad + 31) >> 5;                   // bitmap words per vertex
+        auto take = [&](int &o, int bytes) { const int r = o; o += (bytes + 15) & ~15; return r; };
+        lay.val[k][0] = take(cursor, (Vk + 1) * 8);
+        lay.val[k][1] = take(cursor, (Vk + 1) * 8);
+        lay.nbr[k] = take(cursor, D1 * Vk * 4);
+        lay.row[k] = take(cursor, (Vk + 2) * 2);
+        int vs = cursor;                                  // V-dependent scratch behind the persistent tables
+        const int vkey_off = take(vs, Vk * 4);
+        const int cnt_off = take(vs, (Vk + 1) * 4);       // short mode: arrival counters, then start | length of every row list
+        const int E = N * D1;
+        // long rows (few vertices, many entries each): rank by bitmap, if the bitmap fits
+        const bool bitmap = (long)E >= 16L * Vk && vs + 6 * Vk * W + 64 <= ido_off;
+        const int bm_off = vs, pre_off = bm_off + ((Vk * W * 4 + 15) & ~15);
+        const int list_off = vs;                          // short mode: u16 entry lists, rows padded to 4
+        const int list_cap = (E + 3 * Vk + 8) & ~7;
+        const int vs_end = bitmap ? pre_off + Vk * W * 2 : list_off + list_cap * 2;
+        if (vs_end > ido_off || Vk >= 65534 || hdr->fail) {                         // does not fit: leave the frame to the fallback path
+            if (tid == 0 && a.status) *a.status = 1;
+            return;                                       // uniform: every lane read the same V and the same flag
+        }
+        unsigned *vkey = reinterpret_cast<unsigned *>(smem + vkey_off);
+        unsigned *cnt = reinterpret_cast<unsigned *>(smem + cnt_off);
+        unsigned *bm = reinterpret_cast<unsigned *>(smem + bm_off);
+        unsigned short *pre = reinterpret_cast<unsigned short *>(smem + pre_off);
+        unsigned short *list = reinterpret_cast<unsigned short *>(smem + list_off);
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            if (u < per && okey[u] != kEmptyKey) {
+                ido[tid * per + u] = (unsigned short)id;
+                vkey[id] = okey[u];
+                ++id;
+            }
+        }
+        for (int v = tid; v <= Vk; v += kNT) cnt[v] = 0u;
+        if (bitmap) {
+            for (int u = tid; u < Vk * W; u += kNT) bm[u] = 0u;
+        } else {
+            unsigned long long *l8 = reinterpret_cast<unsigned long long *>(list);
+            for (int u = tid; u < list_cap / 4; u += kNT) l8[u] = ~0ull;           // pads compare greater than every entry
+        }
+        if (tid == 0) {
+            reinterpret_cast<float2 *>(smem + lay.val[k][0])[0] = make_float2(0.f, 0.f);
+            reinterpret_cast<float2 *>(smem + lay.val[k][1])[0] = make_float2(0.f, 0.f);
+            if (a.V_out[k]) a.V_out[k][f] = Vk;
+        }
+        __syncthreads();
+        FL_PSTAMP();
+
+        // ---- D: every entry learns its vertex and joins the vertex's row; blur neighbours per vertex ------
+        unsigned vid[PPT][D1], arr[PPT][D1];              // vertex id, arrival index inside the row (short mode)
+#pragma unroll
+        for (int s = 0; s < PPT; ++s) {
+            const int i = tid + s * kNT;
+#pragma unroll
+            for (int j = 0; j < D1; ++j) {
+                const unsigned h = j == 0 ? (slot[s][0] & 0xffffu) : (j == 1 ? slot[s][0] >> 16 : slot[s][1]);
+                vid[s][j] = i < Npad ? (unsigned)ido[h] : 0u;
+                arr[s][j] = 0u;
+                if (i < N) {                              // real points only: phantoms add vertices, not products
+                    if (bitmap) atomicOr(&bm[vid[s][j] * W + (i >> 5)], 1u << (i & 31));
+                    else arr[s][j] = atomicAdd(&cnt[vid[s][j]], 1u);
+                }
+            }
+        }
+        {
+            unsigned *nbr = reinterpret_cast<unsigned *>(smem + lay.nbr[k]);
+            for (int v = tid; v < Vk; v += kNT) {         // permutohedral_cpu.h:408-421 with d = 2
+                const unsigned kk = vkey[v];
+                const unsigned x = kk & 0xffffu, y = kk >> 16;
+#pragma unroll
+                for (int j = 0; j < D1; ++j) {
+                    unsigned res = 0u;
+#pragma unroll
+                    for (int side = 0; side < 2; ++side) {
+                        const unsigned step = side ? 1u : 0xffffu, jump = side ? 0xfffeu : 2u;       // n1 = key - 1 (axis: + d), n2 = key + 1 (axis: - d)
+                        const unsigned qx = (x + (j == 0 ? jump : step)) & 0xffffu, qy = (y + (j == 1 ? jump : step)) & 0xffffu;
+                        const unsigned q = qx | (qy << 16);
+                        unsigned h = hash32(q) & mask, found = 0u;
+                        for (int probes = 0; probes < hcap; ++probes) {
+                            const unsigned o = hk[h];
+                            if (o == kEmptyKey) break;
+                            if (o == q) { found = (unsigned)ido[h] + 1u; break; }
+                            h = (h + 1u) & mask;
+                        }
+                        res |= found << (16 * side);
+                    }
+                    nbr[j * Vk + v] = res;
+                }
+            }
+        }
+        __syncthreads();
+        FL_PSTAMP();
+
+        // ---- E: row lengths -> row starts (and, short mode, the start of every padded entry list) -------
+        if (bitmap) {                                     // one wavefront per vertex: prefix popcounts of its bitmap words
+            const int lane = tid & 63, wave = tid >> 6;
+            const int wpl = (W + 63) >> 6;                // words per lane (1 for N <= 2048, 2 up to 4096)
+            for (int v = wave; v < Vk; v += kNT / 64) {
+                int pc[2] = {0, 0}, sum = 0;
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int wd = lane * wpl + u;
+                    if (u < wpl && wd < W) pc[u] = __popc(bm[v * W + wd]);
+                    sum += pc[u];
+                }
+                int incl = sum;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const int t = __shfl_up(incl, o, 64);
+                    if (lane >= o) incl += t;
+                }
+                int run = incl - sum;
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int wd = lane * wpl + u;
+                    if (u < wpl && wd < W) pre[v * W + wd] = (unsigned short)run;
+                    run += pc[u];
+                }
+                if (lane == 63) cnt[v] = (unsigned)incl;
+            }
+            __syncthreads();
+        }
+        {
+            // packed scan: low half = products before the row, high half = padded list entries before it
+            const int vper = (Vk + 1 + kNT - 1) / kNT, v0 = tid * vper;
+            unsigned sum = 0u;
+            int mx = 0;
+            for (int u = 0; u < vper; ++u) {
+                const int v = v0 + u;
+                if (v < Vk) {
+                    const unsigned n = cnt[v];
+                    sum += n | (((n + 3u) & ~3u) << 16);
+                    mx = max(mx, (int)n);
+                }
+            }
+            int tot;
+            unsigned run = (unsigned)block_excl_scan((int)sum, tid, hdr->wave_sum, tot);
+            unsigned short *row = reinterpret_cast<unsigned short *>(smem + lay.row[k]);
+            for (int u = 0; u < vper; ++u) {
+                const int v = v0 + u;
+                if (v <= Vk) {
+                    const unsigned n = v < Vk ? cnt[v] : 0u;
+                    row[v] = (unsigned short)(run & 0xffffu);
+                    cnt[v] = (run >> 16) | (n << 16);      // list start | row length
+                    run += n | (((n + 3u) & ~3u) << 16);
+                }
+            }
+            if (k == 0) {                                 // longest row of kernel 0 decides the chain path
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o, 64));
+                if ((tid & 63) == 0 && mx > 0) atomicMax(&hdr->rowmax, mx);
+            }
+        }
+        __syncthreads();
+        FL_PSTAMP();
+
+        // ---- F/G: the place of every entry in its row = number of smaller entries of the same vertex ----
+        if (!bitmap) {
+#pragma unroll
+            for (int s = 0; s < PPT; ++s) {
+                const int i = tid + s * kNT;
+                if (i < N) {
+#pragma unroll
+                    for (int j = 0; j < D1; ++j) list[(cnt[vid[s][j]] & 0xffffu) + arr[s][j]] = (unsigned short)(i * D1 + j);
+                }
+            }
+            __syncthreads();
+        }
+        const unsigned short *row = reinterpret_cast<const unsigned short *>(smem + lay.row[k]);
+#pragma unroll
+        for (int s = 0; s < PPT; ++s) {
+            const int i = tid + s * kNT;
+#pragma unroll
+            for (int j = 0; j < D1; ++j) {
+                unsigned rank = 0u;
+                const unsigned v = vid[s][j];
+                if (i < N) {
+                    if (bitmap) {
+                        rank = (unsigned)pre[v * W + (i >> 5)] + (unsigned)__popc(bm[v * W + (i >> 5)] & ((1u << (i & 31)) - 1u));
+                    } else {
+                        const unsigned lc = cnt[v], e = (unsigned)(i * D1 + j);
+                        const uint2 *lp = reinterpret_cast<const uint2 *>(list + (lc & 0xffffu));
+                        const int n4 = (int)(((lc >> 16) + 3u) >> 2);
+                        for (int u = 0; u < n4; ++u) {
+                            const uint2 x = lp[u];
+                            rank += ((x.x & 0xffffu) < e) + ((x.x >> 16) < e) + ((x.y & 0xffffu) < e) + ((x.y >> 16) < e);
+                        }
+                    }
+                }
+                pk[s][k][j] = (v + 1u) | (((unsigned)row[v] + rank) << 16);
+            }
+        }
+        if (k == 0) row0max = hdr->rowmax;
+        __syncthreads();                                  // the next kernel's build (or the loop's product buffers) reuses the scratch
+        FL_PSTAMP();
+    }
+    FL_STAMP();
+
+    // ---- loop-phase LDS plan: product buffers behind the persistent tables ---------------------------
+    lay.chain0 = chain_wanted(N, V[0], row0max) ? 1 : 0;
+    {
+        bool ok = false;
+        for (int all = 1; all >= 0 && !ok; --all) {
+            int o = cursor, shared = 0;
+            for (int k = 0; k < K; ++k) {
+                lay.Ecap[k] = plane_floats(N, V[k], k == 0 && lay.chain0);
+                const int pb = lay.Ecap[k] * 8;
+                if (all) { lay.prod[k] = o; o += (pb + 15) & ~15; }
+                else shared = max(shared, pb);
+            }
+            if (!all) {
+                for (int k = 0; k < K; ++k) lay.prod[k] = o;
+                o += (shared + 15) & ~15;
+            }
+            lay.prod_all = all;
+            lay.total = o;
+            ok = o <= a.lds_total;
+        }
+        if (!ok) {
+            if (tid == 0 && a.status) *a.status = 1;
+            return;
+        }
+    }
+    place_products<PPT, K, 2>(smem, lay, N, tid, pk, pr);
+    ChainLane cl{0u, 0u};
+    if (lay.chain0) cl = chain_setup(smem, lay, V[0], tid);
+
+    // ---- normalisation: norm = 1 / (compute(ones) + 1e-20), pairwise3d.h:22-27 -- one pass of the loop's own
+    //      splat / blur / slice with Q = 1 for every kernel at once
+#pragma unroll
+    for (int s = 0; s < PPT; ++s) pr.q[s] = make_float2(1.0f, 1.0f);
+    splat_blur<PPT, K, 2>(smem, lay, V, N, tid, pr, cl, ins);
+#pragma unroll
+    for (int s = 0; s < PPT; ++s) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            pr.wn[s][k] = 0.0f;
+            if (tid + s * kNT < N) {
+                const float t = slice_point(smem, lay, pr, s, k, a.alpha).x;
+                pr.wn[s][k] = a.w[k] * (1.0f / (t + 1e-20f));             // pairwise3d.h:26-27,77
+            }
+        }
+    }
+    FL_STAMP();                                           // (no barrier: the next writer of val[.][1] is two barriers away)
+
+    start_inference(pr, N, tid);
+    float alpha[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) alpha[k] = a.alpha;
+    mean_field<PPT, K, 2>(smem, lay, V, N, tid, pr, cl, alpha, a.n_iter, a.relax, ins);
+    store_results(c, f, N, tid, pr, a.with_map);
+    FL_STAMP();
+    if (kInstr && a.timing && (int)blockIdx.x == a.timing_block && tid == 0) a.timing[63] = ins.n;
+}
+
+int frame_hcap(int NA)
+{
+    const int live = 3 * ((NA + 3) & ~3);
+    int h = 1024;
+    while (h < live && h < 8192) h <<= 1;
+    return h;
+}
+
+template <int PPT, int K>
+void launch_frame_ppt(const CrfDev &c, const FrameArgs &a, hipStream_t s)
+{
+    auto fn = k_frame<PPT, K>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit);
+    fn<<<dim3(c.F), dim3(kNT), a.lds_total, s>>>(c, a);
+}
+
+}  // namespace
+
+bool frame_supported(const CrfDev &c, const KernelDev *kds)
+{
+    const int NA = c.activeN > 0 ? c.activeN : c.maxN;
+    if (c.L != 2 || c.K < 1 || c.K > kMaxFusedK || NA < 1 || NA > 4 * kNT) return false;
+    for (int k = 0; k < c.K; ++k)
+        if (kds[k].d != 2) return false;
+    return true;
+}
+
+void launch_frame(const CrfDev &c, const KernelDev *kds, int n_iter, int with_map, float relax, int *status,
+                  const int16_t *label, const float *tbl5, hipStream_t s)
+{
+    FrameArgs a{};
+    for (int k = 0; k < c.K; ++k) {
+        a.feat[k] = kds[k].feat;
+        a.w[k] = kds[k].w;
+        a.V_out[k] = kds[k].V;
+    }
+    a.scale[0] = kds[0].scale[0];
+    a.scale[1] = kds[0].scale[1];
+    a.inv_dp1 = kds[0].inv_dp1;
+    a.alpha = kds[0].alpha;
+    a.maxN = c.maxN;
+    a.label = label;
+    if (label)
+        for (int i = 0; i < 5; ++i) a.tbl[i] = tbl5[i];
+    a.n_iter = n_iter;
+    a.with_map = with_map;
+    a.relax = relax;
+    const int NA = c.activeN > 0 ? c.activeN : c.maxN;
+    a.hcap = frame_hcap(NA);
+    a.lds_total = (int)kLdsLimit;
+    a.status = status;
+    static long long *timing_buf = nullptr;
+    static const bool want_timing = kInstr && getenv("LCCRF_FRAME_TIMING") != nullptr;
+    if (want_timing && !timing_buf) (void)hipMalloc(&timing_buf, 64 * sizeof(long long));
+    a.timing = want_timing ? timing_buf : nullptr;
+    a.timing_block = want_timing ? std::max(atoi(getenv("LCCRF_FRAME_TIMING")) - 1, 0) : 0;
+    if (a.timing_block >= c.F) a.timing_block = 0;
+    const int ppt = (NA + kNT - 1) / kNT;
+#define FRAME_CASE(P)                                          \
+    case P:                                                    \
+        if (c.K == 1) launch_frame_ppt<P, 1>(c, a, s);         \
+        else launch_frame_ppt<P, 2>(c, a, s);                  \
+        break;
+    switch (ppt) {
+        FRAME_CASE(1)
+        FRAME_CASE(2)
+        FRAME_CASE(3)
+        FRAME_CASE(4)
+    default: break;
+    }
+#undef FRAME_CASE
+    if (a.timing) {                       // instrumented builds: synchronous read-back of one workgroup's stamps
+        long long h[64];
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpy(h, a.timing, sizeof(h), hipMemcpyDeviceToHost);
+        fprintf(stderr, "[lccrf frame timing] %lld stamps, deltas (shader clocks):", h[63]);
+        for (int i = 1; i < h[63] && i < 63; ++i) fprintf(stderr, " %lld", h[i] - h[i - 1]);
+        fprintf(stderr, "\n");
+    }
+}
+
+}  // namespace lccrf

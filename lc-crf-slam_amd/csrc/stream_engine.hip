@@ -158,10 +158,7 @@ __global__ void __launch_bounds__(kBlock) k_offsets(KernelDev kd, const int *__r
     const int r = kd.slot[(size_t)f * kd.cap + kd.slot_of[fe + e]];
     const int id = prefix[r];
     kd.offset[fe + e] = id;
-    if (r == e) {
-        kd.rep[fe + id] = e;
-        kd.vperm[fe + id] = id;                            // the streaming build keeps the reference numbering
-    }
+    if (r == e) kd.rep[fe + id] = e;
 }
 
 template <int D>
@@ -406,20 +403,6 @@ __global__ void __launch_bounds__(kBlock) k_slice2(KernelDev kd, CrfDev c, const
 // ---------------------------------------------------------------------------------------
 
 // unary[i][:] from a label and the three energy tables {u, n[L], p[L]}.  densecrf3d.h:116-129.
-__global__ void __launch_bounds__(kBlock) k_unary_from_label(CrfDev c, const int16_t *__restrict__ label,
-                                                             const float *__restrict__ tbl)
-{
-    const int f = blockIdx.y;
-    const int idx = blockIdx.x * kBlock + threadIdx.x;
-    if (idx >= c.n_points[f] * c.L) return;
-    const int i = idx / c.L, m = idx - i * c.L;
-    const int t = label[(size_t)f * c.maxN + i];
-    float u;
-    if (t < 0 || t >= c.L) u = tbl[0];      // -1 = unknown; out-of-range labels (UB in the reference) likewise
-    else u = (m == t) ? tbl[1 + c.L + t] : tbl[1 + t];
-    c.unary[((size_t)f * c.maxN + i) * c.L + m] = u;
-}
-
 __global__ void __launch_bounds__(kBlock) k_unary_from_label_tbl(CrfDev c, const int16_t *__restrict__ label, UnaryTable tbl)
 {
     const int f = blockIdx.y;
@@ -428,7 +411,7 @@ __global__ void __launch_bounds__(kBlock) k_unary_from_label_tbl(CrfDev c, const
     const int i = idx / c.L, m = idx - i * c.L;
     const int t = label[(size_t)f * c.maxN + i];
     float u;
-    if (t < 0 || t >= c.L) u = tbl.v[0];
+    if (t < 0 || t >= c.L) u = tbl.v[0];      // -1 = unknown; out-of-range labels (UB in the reference) likewise
     else u = (m == t) ? tbl.v[1 + c.L + t] : tbl.v[1 + t];
     c.unary[((size_t)f * c.maxN + i) * c.L + m] = u;
 }
@@ -529,11 +512,6 @@ void launch_norm(const KernelDev &kd, const CrfDev &c, int maxV, hipStream_t s)
     const float *res;
     filter_passes(kd, c.F, maxV, 1, s, &res);
     k_slice<<<grid_for(c.maxN, c.F), kBlock, 0, s>>>(kd, c, res, 1, SLICE_NORM);
-}
-
-void launch_unary_from_label(const CrfDev &c, const int16_t *label, const float *tbl, hipStream_t s)
-{
-    k_unary_from_label<<<grid_for((long)c.maxN * c.L, c.F), kBlock, 0, s>>>(c, label, tbl);
 }
 
 void launch_unary_from_label_tbl(const CrfDev &c, const int16_t *label, const UnaryTable &tbl, hipStream_t s)

@@ -9,3 +9,4 @@ done
 for k in 1 2; do
 LCCRF_BUILD_TIMING=$k timeout 200 python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-check --no-extras 2>&1 | grep "build timing" | tail -1
 done
+LCCRF_FRAME_TIMING=1 timeout 200 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-check --no-extras 2>&1 | grep "frame timing" | tail -1

@@ -1,0 +1,214 @@
+"""The one-launch-per-frame kernel (csrc/frame_engine.hip, lccrf_batch_run and the object API's inference()):
+lattice build + normalisation + mean-field inference of a frame in ONE launch, against
+  (1) the committed golden vectors generated from the reference itself (tests/golden/slam.npz),
+  (2) the oracle on fresh seeded frames of every size class (every N % 4, 1 .. 4 points per lane),
+  (3) adversarial lattices (one cell, long rows, rows on the chain's unit boundaries, lattices too large
+      for the kernel -> its fallback), ragged batches, raw unaries, relax != 1, a single kernel,
+  (4) the two-kernel path (LCCRF_NO_FRAME) bit for bit.
+Bar: labels identical, Q bit-identical, V equal to the reference's M_.
+"""
+import importlib
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import crf_cases as cc
+from test_hip_parity import _shaped_problem
+
+pkg = importlib.import_module("lc-crf-slam_amd")
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _batch_of(pbs, maxN=None, use_unary=False):
+    F = len(pbs)
+    maxN = maxN or max(max(pb["N"] for pb in pbs), 1)
+    K = len(pbs[0]["kernels"])
+    feats = [np.zeros((F, maxN, 2), np.float32) for _ in range(K)]
+    label = np.full((F, maxN), -1, np.int16)
+    unary = np.zeros((F, maxN, 2), np.float32)
+    for f, pb in enumerate(pbs):
+        n = pb["N"]
+        if "label" in pb:
+            label[f, :n] = pb["label"]
+        if "unary" in pb:
+            unary[f, :n] = pb["unary"]
+        for k in range(K):
+            feats[k][f, :n] = pb["kernels"][k][0]
+    b = pkg.BatchCRF(F, maxN, 2, [2] * K, [float(pbs[0]["kernels"][k][1]) for k in range(K)])
+    if use_unary:
+        b.set_inputs_host([pb["N"] for pb in pbs], feats, unary=unary)
+    else:
+        b.set_inputs_host([pb["N"] for pb in pbs], feats, label=label, conf=pbs[0].get("conf", 0.7))
+    return b
+
+
+def _check_vs_oracle(po, pbs, b, n_iter, relax=1.0, expect_engine=3):
+    b.run(n_iter, True, relax=relax)
+    Q, M = b.probability(), b.map()
+    assert b.engine() == expect_engine
+    Vs = [b.lattice_sizes(k) for k in range(len(pbs[0]["kernels"]))]
+    for f, pb in enumerate(pbs):
+        o = cc.setup(po.OracleCRF, pb)
+        o.inference_native(n_iter, True, relax)
+        n = pb["N"]
+        for k in range(len(pb["kernels"])):
+            assert Vs[k][f] == (o.kernel(k)["V"] if n else 0), (f, k)
+        assert cc.same_bits(Q[f, :n], o.probability()), (f, n)
+        assert np.array_equal(M[f, :n], o.map()), (f, n)
+        o.close()
+
+
+def _slam_cases():
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "slam.npz"))
+    return [str(c) for c in z["cases"]]
+
+
+@pytest.mark.parametrize("case", _slam_cases())
+def test_frame_kernel_on_reference_fixtures(golden, case):
+    """Golden vectors generated from the reference's own headers: Q after t iterations and the labels, for every
+    recorded t, each as one launch."""
+    z = golden["slam"]
+    pb, exp = cc.case_problem(z, case), cc.case_expected(z, case)
+    b = _batch_of([pb, pb])
+    for t in sorted(exp["Q"]):
+        b.run(t, True, relax=exp["relax"])
+        Q, M = b.probability(), b.map()
+        assert b.engine() == 3
+        for f in range(2):
+            assert cc.same_bits(Q[f, :pb["N"]], exp["Q"][t]), (case, t)
+            assert np.array_equal(M[f, :pb["N"]], exp["map"][t]), (case, t)
+        for k, V in enumerate(exp["V"]):
+            assert list(b.lattice_sizes(k)) == [V, V]
+    b.close()
+
+
+@pytest.mark.parametrize("N", [1, 2, 3, 4, 5, 63, 64, 65, 511, 1000, 1001, 1024, 1025, 2000, 2002, 2047, 2999, 3000, 3073, 4096])
+def test_frame_kernel_matches_oracle_sizes(po, wl, N):
+    pbs = [wl.slam_problem(N, seed=700 + N), wl.slam_problem(max(N - 1, 1), seed=701 + N)]
+    b = _batch_of(pbs)
+    _check_vs_oracle(po, pbs, b, 5)
+    b.close()
+
+
+def test_frame_kernel_ragged_batch_and_idempotence(po, wl):
+    sizes = [2000, 0, 1, 777, 1999, 5, 1024, 2000, 0, 333]
+    pbs = [wl.slam_problem(n, seed=40 + i) for i, n in enumerate(sizes)]
+    b = _batch_of(pbs, maxN=2000)
+    _check_vs_oracle(po, pbs, b, 5)
+    Q, M = b.probability(), b.map()
+    b.run(5, True)                                         # running the same batch again changes nothing
+    assert cc.same_bits(b.probability(), Q) and np.array_equal(b.map(), M)
+    b.close()
+
+
+@pytest.mark.parametrize("shape,N", [("one_cell", 2000), ("one_cell", 4096), ("one_cell", 70), ("two_clusters", 2047),
+                                     ("two_clusters", 2600), ("rows_of_8", 2000), ("rows_of_8", 1030)])
+def test_frame_kernel_on_adversarial_lattices(po, wl, shape, N):
+    pb = _shaped_problem(wl, N, shape, seed=5)
+    b = _batch_of([pb])
+    _check_vs_oracle(po, [pb], b, 4)
+    b.close()
+    pb1 = dict(pb, kernels=pb["kernels"][:1])              # and as the only kernel (K = 1), damped
+    b = _batch_of([pb1])
+    _check_vs_oracle(po, [pb1], b, 3, relax=0.8)
+    b.close()
+
+
+def test_frame_kernel_falls_back_when_a_lattice_does_not_fit(po, wl):
+    """Every point in its own cell: V = 3N vertices per kernel cannot live in one workgroup's LDS.  The launch
+    flags it, the library re-runs the batch on the build + inference kernels: same answers, engine != 3."""
+    pbs = [_shaped_problem(wl, 1200, "sparse", seed=5), wl.slam_problem(1200, seed=9)]
+    b = _batch_of(pbs)
+    b.run(4, True)
+    Q, M = b.probability(), b.map()
+    assert b.engine() in (1, 2)
+    for f, pb in enumerate(pbs):
+        o = cc.setup(po.OracleCRF, pb)
+        o.inference_native(4, True)
+        assert cc.same_bits(Q[f, :pb["N"]], o.probability()) and np.array_equal(M[f, :pb["N"]], o.map())
+
+
+def test_frame_kernel_with_raw_unaries_and_unknown_labels(po, wl):
+    rng = np.random.default_rng(11)
+    pb = wl.slam_problem(1500, seed=21)
+    pu = dict(pb)
+    del pu["label"]
+    pu["unary"] = rng.uniform(0.05, 3.0, (1500, 2)).astype(np.float32)
+    pu["unary"][::50] = np.float32([0.0, 45.0])             # beyond fast_exp's cut-off
+    b = _batch_of([pu], use_unary=True)
+    _check_vs_oracle(po, [pu], b, 5)
+    b.close()
+    pl = dict(pb, label=pb["label"].copy())
+    pl["label"][::7] = -1                                   # unknown labels: uniform energies (densecrf3d.h:119)
+    b = _batch_of([pl])
+    _check_vs_oracle(po, [pl], b, 5)
+    b.close()
+
+
+def test_frame_kernel_equals_two_kernel_path_bitwise(wl):
+    """lccrf_batch_run (one launch) vs lccrf_batch_build + lccrf_batch_inference (build_small + fused)."""
+    sizes = [2000, 1999, 1000, 2000, 0, 7, 3000, 2500]
+    pbs = [wl.slam_problem(n, seed=60 + i) for i, n in enumerate(sizes)]
+    b = _batch_of(pbs, maxN=3000)
+    b.run(5, True)
+    q1, m1 = b.probability(), b.map()
+    assert b.engine() == 3
+    v1 = [b.lattice_sizes(k) for k in range(2)]
+    b.build()
+    b.inference(5, True)
+    q2, m2 = b.probability(), b.map()
+    assert b.engine() == 2
+    for f, n in enumerate(sizes):
+        assert cc.same_bits(q1[f, :n], q2[f, :n]) and np.array_equal(m1[f, :n], m2[f, :n]), f
+    for k in range(2):
+        assert np.array_equal(v1[k], b.lattice_sizes(k))
+    b.close()
+
+
+def test_object_api_inference_is_one_launch_and_probes_still_work(po, wl):
+    """DenseCRFHIP.inference() right after add_pairwise runs the frame kernel (nothing was built); the parity
+    probes afterwards build the lattices on demand and agree with the oracle's numbering."""
+    pb = wl.slam_problem(2000, seed=88)
+    o, h = cc.setup(po.OracleCRF, pb), cc.setup(pkg.DenseCRFHIP, pb)
+    o.inference_native(5, True)
+    h.inference(5, True)
+    assert cc.same_bits(h.probability(), o.probability()) and np.array_equal(h.map(), o.map())
+    assert cc.same_bits(h.unary(), o.unary())
+    for k in range(2):
+        ko, kh = o.kernel(k), h.kernel(k)
+        assert ko["V"] == kh["V"]
+        for name in ("offset", "bary", "nbr", "norm"):
+            assert cc.same_bits(ko[name], kh[name]), (k, name)
+    h.inference(3, True)                                   # lattices are in HBM now: iterate on those
+    o.inference_native(3, True)
+    assert cc.same_bits(h.probability(), o.probability())
+    h.step_inference()
+    o.step_inference()
+    assert cc.same_bits(h.probability(), o.probability())
+
+
+def test_no_frame_switch_gives_the_same_bits(wl):
+    """LCCRF_NO_FRAME (two-kernel path for the object API) in a child process."""
+    code = r"""
+import importlib, sys, numpy as np
+sys.path.insert(0, %r)
+pkg = importlib.import_module("lc-crf-slam_amd"); wl = importlib.import_module("lc-crf-slam_amd.workloads")
+out = []
+for N in (5, 700, 2000, 3000):
+    pb = wl.slam_problem(N, seed=123)
+    h = pkg.DenseCRFHIP(pb["N"], pb["L"]); h.set_unary_from_label(pb["label"], pb["conf"])
+    for f, w in pb["kernels"]: h.add_pairwise(f, w)
+    h.inference(5, True); out.append(h.probability()); out.append(h.map().astype(np.float32)); h.close()
+np.save(sys.argv[1], np.concatenate([o.ravel() for o in out]))
+""" % ROOT
+    res = []
+    for env in ({}, {"LCCRF_NO_FRAME": "1"}):
+        path = os.path.join(ROOT, "gpurun_out", "noframe_%d.npy" % len(res))
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        subprocess.run([sys.executable, "-c", code, path], check=True, env=dict(os.environ, **env), timeout=600)
+        res.append(np.load(path))
+    assert cc.same_bits(res[0], res[1])
