@@ -60,7 +60,7 @@ struct FrameArgs {
     int *V_out[kMaxFusedK];               // [F] vertices per kernel (reference M_), or null
     int *status;                          // pinned host word: set to 1 when a frame does not fit this kernel's LDS plan
     long long *timing;                    // instrumented builds only
-    int timing_block;
+    int timing_block, timing_lane;
 };
 
 struct Hdr {                              // lives at smem + 192
@@ -78,28 +78,32 @@ __device__ __forceinline__ unsigned hash32(unsigned key)
     return h;
 }
 
+// Inclusive scan over the 64 lanes of a wavefront with DPP: Hillis-Steele inside each row of 16 lanes (row_shr),
+// then the row totals are handed on with row_bcast:15 (into rows 1, 3) and row_bcast:31 (into rows 2, 3).
+__device__ __forceinline__ int wave_incl_scan(int x)
+{
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);
+    return x;
+}
+
 // Exclusive scan of one int per lane over the workgroup; returns the prefix, `total` the grand total.
 // Two barriers; wave_sum may be reused right after the call returns only behind another barrier.
 __device__ __forceinline__ int block_excl_scan(int x, int tid, int *wave_sum, int &total)
 {
     const int lane = tid & 63, wave = tid >> 6;
-    int incl = x;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int y = __shfl_up(incl, o, 64);
-        if (lane >= o) incl += y;
-    }
+    const int incl = wave_incl_scan(x);
     __syncthreads();                                      // a previous scan's readers are done with wave_sum
     if (lane == 63) wave_sum[wave] = incl;
     __syncthreads();
-    int wbase = 0, tot = 0;
-#pragma unroll
-    for (int w = 0; w < kNT / 64; ++w) {
-        const int y = wave_sum[w];
-        if (w < wave) wbase += y;
-        tot += y;
-    }
-    total = tot;
+    const int ws = lane < kNT / 64 ? wave_sum[lane] : 0;  // the 16 wavefront totals, scanned again inside every wavefront
+    const int wincl = wave_incl_scan(ws);
+    total = __builtin_amdgcn_readlane(wincl, kNT / 64 - 1);
+    const int wbase = __builtin_amdgcn_readlane(wincl - ws, __builtin_amdgcn_readfirstlane(wave));
     return wbase + incl - x;
 }
 
@@ -118,7 +122,7 @@ __global__ void __launch_bounds__(kNT) k_frame(CrfDev c, FrameArgs a)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int f = blockIdx.x, tid = threadIdx.x;
     const int N = c.n_points[f];
-    Instr ins{a.timing, a.timing_block, 8, 0};
+    Instr ins{a.timing, a.timing_block, 8, 0, a.timing_lane};
     FL_STAMP();
     if (N <= 0) {                                         // an empty frame has no lattice (V = 0) and nothing to infer
         if (tid < K && a.V_out[tid]) a.V_out[tid][f] = 0;
@@ -126,7 +130,7 @@ __global__ void __launch_bounds__(kNT) k_frame(CrfDev c, FrameArgs a)
     }
     const int Npad = (N + 3) & ~3;                       // blocks of four, permutohedral_cpu.h:294 (quirk Q1)
     Hdr *hdr = reinterpret_cast<Hdr *>(smem + 192);
-    const int hcap = a.hcap, per = hcap / kNT;
+    const int hcap = a.hcap;
     const unsigned mask = (unsigned)hcap - 1u;
     const int hk_off = a.lds_total - hcap * 4, ido_off = hk_off - hcap * 2;
     unsigned *hk = reinterpret_cast<unsigned *>(smem + hk_off);                  // hash table: the keys themselves
@@ -180,48 +184,48 @@ __global__ void __launch_bounds__(kNT) k_frame(CrfDev c, FrameArgs a)
         __syncthreads();
         FL_PSTAMP();
 
-        // ---- B: insert.  ds_cmpst either claims an empty slot for the key or returns the key that lives there ----
-        unsigned slot[PPT][2];            // slot0 | slot1 << 16, slot2
+        // ---- B: insert.  ds_cmpst either claims an empty slot for the key (this entry CREATES the vertex) or returns
+        //      the key that lives there.  Every entry's first probe is issued before any result is looked at (the
+        //      table is at most ~3/4 full and usually ~1/7: the first probe nearly always settles it).
+        unsigned slot[PPT][D1], got[PPT][D1];
+        bool bad = false;
 #pragma unroll
-        for (int s = 0; s < PPT; ++s) {
-            unsigned sl[D1] = {0u, 0u, 0u};
-            if (tid + s * kNT < Npad) {
+        for (int s = 0; s < PPT; ++s)
 #pragma unroll
-                for (int j = 0; j < D1; ++j) {
-                    const unsigned kk = key[s][j];
-                    unsigned h = hash32(kk) & mask;
-                    int probes = 0;
-                    for (;;) {
-                        const unsigned prev = atomicCAS(&hk[h], kEmptyKey, kk);
-                        if (prev == kEmptyKey || prev == kk) break;
-                        h = (h + 1u) & mask;
-                        if (++probes >= hcap) { hdr->fail = 1; break; }
-                    }
-                    if (kk == kEmptyKey) hdr->fail = 1;
-                    sl[j] = h;
-                }
+            for (int j = 0; j < D1; ++j) {
+                slot[s][j] = hash32(key[s][j]) & mask;
+                got[s][j] = key[s][j];
+                bad |= key[s][j] == kEmptyKey;
+                if (tid + s * kNT < Npad) got[s][j] = atomicCAS(&hk[slot[s][j]], kEmptyKey, key[s][j]);
             }
-            slot[s][0] = sl[0] | (sl[1] << 16);
-            slot[s][1] = sl[2];
-        }
-        __syncthreads();
+        int ncreated = 0;
+#pragma unroll
+        for (int s = 0; s < PPT; ++s)
+#pragma unroll
+            for (int j = 0; j < D1; ++j) {
+                const unsigned kk = key[s][j];
+                if (got[s][j] != kEmptyKey && got[s][j] != kk) {           // somebody else's key lives there: linear probing
+                    unsigned h = slot[s][j];
+                    for (int probes = 0;; ++probes) {
+                        h = (h + 1u) & mask;
+                        got[s][j] = atomicCAS(&hk[h], kEmptyKey, kk);
+                        if (got[s][j] == kEmptyKey || got[s][j] == kk) break;
+                        if (probes >= hcap) { bad = true; break; }
+                    }
+                    slot[s][j] = h;
+                }
+                ncreated += got[s][j] == kEmptyKey;
+            }
+        if (bad) hdr->fail = 1;
         FL_PSTAMP();
 
-        // ---- C: dense vertex ids in slot order; carve this kernel's persistent tables -------------------
-        unsigned okey[16];                // this lane's `per` consecutive slots (per <= 16)
-        int nocc = 0;
-#pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            okey[u] = kEmptyKey;
-            if (u < per) {
-                okey[u] = hk[tid * per + u];
-                nocc += okey[u] != kEmptyKey;
-            }
-        }
+        // ---- C: dense vertex ids, handed out to the entries that created their vertex (any numbering will do: a
+        //      vertex's value is a sum over its own row, its neighbours are found by key); carve this kernel's tables
         int Vk;
-        int id = block_excl_scan(nocc, tid, hdr->wave_sum, Vk);
+        int id = block_excl_scan(ncreated, tid, hdr->wave_sum, Vk);       // (its barriers also close phase B)
         V[k] = Vk;
-        const int W = (Npad + 31) >> 5;                   // bitmap words per vertex
+        FL_PSTAMP();
+        const int W = (((Npad + 31) >> 5) + 3) & ~3;      // bitmap words per vertex, a multiple of 4
         auto take = [&](int &o, int bytes) { const int r = o; o += (bytes + 15) & ~15; return r; };
         lay.val[k][0] = take(cursor, (Vk + 1) * 8);
         lay.val[k][1] = take(cursor, (Vk + 1) * 8);
@@ -232,12 +236,12 @@ __global__ void __launch_bounds__(kNT) k_frame(CrfDev c, FrameArgs a)
         const int cnt_off = take(vs, (Vk + 1) * 4);       // short mode: arrival counters, then start | length of every row list
         const int E = N * D1;
         // long rows (few vertices, many entries each): rank by bitmap, if the bitmap fits
-        const bool bitmap = (long)E >= 16L * Vk && vs + 6 * Vk * W + 64 <= ido_off;
-        const int bm_off = vs, pre_off = bm_off + ((Vk * W * 4 + 15) & ~15);
-        const int list_off = vs;                          // short mode: u16 entry lists, rows padded to 4
-        const int list_cap = (E + 3 * Vk + 8) & ~7;
-        const int vs_end = bitmap ? pre_off + Vk * W * 2 : list_off + list_cap * 2;
-        if (vs_end > ido_off || Vk >= 65534 || hdr->fail) {                         // does not fit: leave the frame to the fallback path
+        const bool bitmap = (long)E >= 16L * Vk && vs + 5 * Vk * W + 64 <= ido_off;
+        const int bm_off = vs, pre_off = bm_off + Vk * W * 4;             // pre: entries before every 4-word group (u16)
+        const int list_off = vs;                          // short mode: u16 entry lists, rows padded to 8
+        const int list_cap = (E + 7 * Vk + 8) & ~7;
+        const int vs_end = bitmap ? pre_off + Vk * W / 2 : list_off + list_cap * 2;
+        if (vs_end > ido_off || Vk >= 32767 || E + 7 * Vk >= 65535 || hdr->fail) {   // does not fit: leave the frame to the fallback path
             if (tid == 0 && a.status) *a.status = 1;
             return;                                       // uniform: every lane read the same V and the same flag
         }
@@ -247,37 +251,46 @@ __global__ void __launch_bounds__(kNT) k_frame(CrfDev c, FrameArgs a)
         unsigned short *pre = reinterpret_cast<unsigned short *>(smem + pre_off);
         unsigned short *list = reinterpret_cast<unsigned short *>(smem + list_off);
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            if (u < per && okey[u] != kEmptyKey) {
-                ido[tid * per + u] = (unsigned short)id;
-                vkey[id] = okey[u];
-                ++id;
-            }
-        }
+        for (int s = 0; s < PPT; ++s)
+#pragma unroll
+            for (int j = 0; j < D1; ++j)
+                if (got[s][j] == kEmptyKey) {
+                    ido[slot[s][j]] = (unsigned short)id;
+                    vkey[id] = key[s][j];
+                    ++id;
+                }
         for (int v = tid; v <= Vk; v += kNT) cnt[v] = 0u;
+        {
+            unsigned *nbz = reinterpret_cast<unsigned *>(smem + lay.nbr[k]);   // absent neighbours stay 0
+            for (int u = tid; u < D1 * Vk; u += kNT) nbz[u] = 0u;
+        }
         if (bitmap) {
-            for (int u = tid; u < Vk * W; u += kNT) bm[u] = 0u;
+            uint4 *b4 = reinterpret_cast<uint4 *>(bm);
+            for (int u = tid; u < Vk * W / 4; u += kNT) b4[u] = make_uint4(0u, 0u, 0u, 0u);
         } else {
-            unsigned long long *l8 = reinterpret_cast<unsigned long long *>(list);
-            for (int u = tid; u < list_cap / 4; u += kNT) l8[u] = ~0ull;           // pads compare greater than every entry
+            uint4 *l4 = reinterpret_cast<uint4 *>(list);   // pads compare greater than every entry (entries are < 0x7fff)
+            for (int u = tid; u < list_cap / 8; u += kNT) l4[u] = make_uint4(0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu);
         }
         if (tid == 0) {
             reinterpret_cast<float2 *>(smem + lay.val[k][0])[0] = make_float2(0.f, 0.f);
             reinterpret_cast<float2 *>(smem + lay.val[k][1])[0] = make_float2(0.f, 0.f);
-            if (a.V_out[k]) a.V_out[k][f] = Vk;
         }
+        FL_PSTAMP();
         __syncthreads();
         FL_PSTAMP();
 
         // ---- D: every entry learns its vertex and joins the vertex's row; blur neighbours per vertex ------
         unsigned vid[PPT][D1], arr[PPT][D1];              // vertex id, arrival index inside the row (short mode)
 #pragma unroll
+        for (int s = 0; s < PPT; ++s)
+#pragma unroll
+            for (int j = 0; j < D1; ++j) vid[s][j] = (tid + s * kNT < Npad) ? (unsigned)ido[slot[s][j]] : 0u;
+        FL_PSTAMP();
+#pragma unroll
         for (int s = 0; s < PPT; ++s) {
             const int i = tid + s * kNT;
 #pragma unroll
             for (int j = 0; j < D1; ++j) {
-                const unsigned h = j == 0 ? (slot[s][0] & 0xffffu) : (j == 1 ? slot[s][0] >> 16 : slot[s][1]);
-                vid[s][j] = i < Npad ? (unsigned)ido[h] : 0u;
                 arr[s][j] = 0u;
                 if (i < N) {                              // real points only: phantoms add vertices, not products
                     if (bitmap) atomicOr(&bm[vid[s][j] * W + (i >> 5)], 1u << (i & 31));
@@ -285,61 +298,63 @@ __global__ void __launch_bounds__(kNT) k_frame(CrfDev c, FrameArgs a)
                 }
             }
         }
+        FL_PSTAMP();
         {
-            unsigned *nbr = reinterpret_cast<unsigned *>(smem + lay.nbr[k]);
-            for (int v = tid; v < Vk; v += kNT) {         // permutohedral_cpu.h:408-421 with d = 2
+            // permutohedral_cpu.h:408-421 with d = 2: n1 = key - 1 (coordinate `axis`: + d), n2 = key + 1 (axis: - d).
+            // The relation is mutual -- B = n2_j(A) iff A = n1_j(B) -- so one probe per (axis, vertex) finds n2 and
+            // fills both halves; absent neighbours keep the 0 the table was cleared to.
+            unsigned short *nb16 = reinterpret_cast<unsigned short *>(smem + lay.nbr[k]);   // [axis][vertex][n1+1, n2+1]
+            for (int t = tid; t < D1 * Vk; t += kNT) {
+                const int j = t >= 2 * Vk ? 2 : (t >= Vk ? 1 : 0), v = t - j * Vk;
                 const unsigned kk = vkey[v];
-                const unsigned x = kk & 0xffffu, y = kk >> 16;
-#pragma unroll
-                for (int j = 0; j < D1; ++j) {
-                    unsigned res = 0u;
-#pragma unroll
-                    for (int side = 0; side < 2; ++side) {
-                        const unsigned step = side ? 1u : 0xffffu, jump = side ? 0xfffeu : 2u;       // n1 = key - 1 (axis: + d), n2 = key + 1 (axis: - d)
-                        const unsigned qx = (x + (j == 0 ? jump : step)) & 0xffffu, qy = (y + (j == 1 ? jump : step)) & 0xffffu;
-                        const unsigned q = qx | (qy << 16);
-                        unsigned h = hash32(q) & mask, found = 0u;
-                        for (int probes = 0; probes < hcap; ++probes) {
-                            const unsigned o = hk[h];
-                            if (o == kEmptyKey) break;
-                            if (o == q) { found = (unsigned)ido[h] + 1u; break; }
-                            h = (h + 1u) & mask;
-                        }
-                        res |= found << (16 * side);
-                    }
-                    nbr[j * Vk + v] = res;
+                const unsigned qx = ((kk & 0xffffu) + (j == 0 ? 0xfffeu : 1u)) & 0xffffu, qy = ((kk >> 16) + (j == 1 ? 0xfffeu : 1u)) & 0xffffu;
+                const unsigned q = qx | (qy << 16);
+                unsigned h = hash32(q) & mask;
+                unsigned o = hk[h];
+                for (int probes = 0; o != kEmptyKey && o != q && probes < hcap; ++probes) {
+                    h = (h + 1u) & mask;
+                    o = hk[h];
+                }
+                if (o == q) {
+                    const unsigned b = ido[h];
+                    nb16[2 * t + 1] = (unsigned short)(b + 1u);                       // my n2
+                    nb16[2 * (j * Vk + (int)b)] = (unsigned short)(v + 1);          // its n1
                 }
             }
         }
+        FL_PSTAMP();
         __syncthreads();
         FL_PSTAMP();
 
         // ---- E: row lengths -> row starts (and, short mode, the start of every padded entry list) -------
-        if (bitmap) {                                     // one wavefront per vertex: prefix popcounts of its bitmap words
-            const int lane = tid & 63, wave = tid >> 6;
-            const int wpl = (W + 63) >> 6;                // words per lane (1 for N <= 2048, 2 up to 4096)
-            for (int v = wave; v < Vk; v += kNT / 64) {
+        if (bitmap) {
+            // prefix popcounts of every vertex's bitmap, one 16-lane group per vertex (W <= 128 words = 32 groups of 4
+            // words: 2 groups per lane at most): pre[v][g] = entries of v in points before word group g
+            const int lane16 = tid & 15, ng = W >> 2, gpl = (ng + 15) >> 4;
+            for (int v = tid >> 4; v < Vk; v += kNT / 16) {
                 int pc[2] = {0, 0}, sum = 0;
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
-                    const int wd = lane * wpl + u;
-                    if (u < wpl && wd < W) pc[u] = __popc(bm[v * W + wd]);
+                    const int g = lane16 * gpl + u;
+                    if (u < gpl && g < ng) {
+                        const uint4 b = *reinterpret_cast<const uint4 *>(bm + v * W + 4 * g);
+                        pc[u] = __popc(b.x) + __popc(b.y) + __popc(b.z) + __popc(b.w);
+                    }
                     sum += pc[u];
                 }
-                int incl = sum;
-#pragma unroll
-                for (int o = 1; o < 64; o <<= 1) {
-                    const int t = __shfl_up(incl, o, 64);
-                    if (lane >= o) incl += t;
-                }
+                int incl = sum;                            // scan inside the 16-lane row only
+                incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xf, 0xf, false);
+                incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xf, 0xf, false);
+                incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xf, 0xf, false);
+                incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xf, 0xf, false);
                 int run = incl - sum;
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
-                    const int wd = lane * wpl + u;
-                    if (u < wpl && wd < W) pre[v * W + wd] = (unsigned short)run;
+                    const int g = lane16 * gpl + u;
+                    if (u < gpl && g < ng) pre[v * ng + g] = (unsigned short)run;
                     run += pc[u];
                 }
-                if (lane == 63) cnt[v] = (unsigned)incl;
+                if (lane16 == 15) cnt[v] = (unsigned)incl;
             }
             __syncthreads();
         }
@@ -352,7 +367,7 @@ __global__ void __launch_bounds__(kNT) k_frame(CrfDev c, FrameArgs a)
                 const int v = v0 + u;
                 if (v < Vk) {
                     const unsigned n = cnt[v];
-                    sum += n | (((n + 3u) & ~3u) << 16);
+                    sum += n | (((n + 7u) & ~7u) << 16);
                     mx = max(mx, (int)n);
                 }
             }
@@ -365,7 +380,7 @@ __global__ void __launch_bounds__(kNT) k_frame(CrfDev c, FrameArgs a)
                     const unsigned n = v < Vk ? cnt[v] : 0u;
                     row[v] = (unsigned short)(run & 0xffffu);
                     cnt[v] = (run >> 16) | (n << 16);      // list start | row length
-                    run += n | (((n + 3u) & ~3u) << 16);
+                    run += n | (((n + 7u) & ~7u) << 16);
                 }
             }
             if (k == 0) {                                 // longest row of kernel 0 decides the chain path
@@ -378,42 +393,88 @@ __global__ void __launch_bounds__(kNT) k_frame(CrfDev c, FrameArgs a)
         FL_PSTAMP();
 
         // ---- F/G: the place of every entry in its row = number of smaller entries of the same vertex ----
+        const unsigned short *row = reinterpret_cast<const unsigned short *>(smem + lay.row[k]);
+        unsigned lc[PPT][D1], rw[PPT][D1];
+#pragma unroll
+        for (int s = 0; s < PPT; ++s)
+#pragma unroll
+            for (int j = 0; j < D1; ++j) {
+                lc[s][j] = cnt[vid[s][j]];
+                rw[s][j] = row[vid[s][j]];
+            }
         if (!bitmap) {
 #pragma unroll
             for (int s = 0; s < PPT; ++s) {
                 const int i = tid + s * kNT;
                 if (i < N) {
 #pragma unroll
-                    for (int j = 0; j < D1; ++j) list[(cnt[vid[s][j]] & 0xffffu) + arr[s][j]] = (unsigned short)(i * D1 + j);
+                    for (int j = 0; j < D1; ++j) list[(lc[s][j] & 0xffffu) + arr[s][j]] = (unsigned short)(i * D1 + j);
                 }
             }
             __syncthreads();
         }
-        const unsigned short *row = reinterpret_cast<const unsigned short *>(smem + lay.row[k]);
+        FL_PSTAMP();
+        unsigned rank[PPT][D1];
+        if (bitmap) {
+            uint4 bw[PPT][D1];
+            unsigned pv[PPT][D1];
 #pragma unroll
-        for (int s = 0; s < PPT; ++s) {
-            const int i = tid + s * kNT;
+            for (int s = 0; s < PPT; ++s) {
+                const int i = min(tid + s * kNT, N - 1);
 #pragma unroll
-            for (int j = 0; j < D1; ++j) {
-                unsigned rank = 0u;
-                const unsigned v = vid[s][j];
-                if (i < N) {
-                    if (bitmap) {
-                        rank = (unsigned)pre[v * W + (i >> 5)] + (unsigned)__popc(bm[v * W + (i >> 5)] & ((1u << (i & 31)) - 1u));
-                    } else {
-                        const unsigned lc = cnt[v], e = (unsigned)(i * D1 + j);
-                        const uint2 *lp = reinterpret_cast<const uint2 *>(list + (lc & 0xffffu));
-                        const int n4 = (int)(((lc >> 16) + 3u) >> 2);
-                        for (int u = 0; u < n4; ++u) {
-                            const uint2 x = lp[u];
-                            rank += ((x.x & 0xffffu) < e) + ((x.x >> 16) < e) + ((x.y & 0xffffu) < e) + ((x.y >> 16) < e);
-                        }
-                    }
+                for (int j = 0; j < D1; ++j) {
+                    bw[s][j] = *reinterpret_cast<const uint4 *>(bm + vid[s][j] * W + ((i >> 5) & ~3));   // the 4-word group of my word
+                    pv[s][j] = pre[vid[s][j] * (W >> 2) + (i >> 7)];
                 }
-                pk[s][k][j] = (v + 1u) | (((unsigned)row[v] + rank) << 16);
+            }
+#pragma unroll
+            for (int s = 0; s < PPT; ++s) {
+                const int i = min(tid + s * kNT, N - 1);
+                const int wq = (i >> 5) & 3;
+                const unsigned low = (1u << (i & 31)) - 1u;
+#pragma unroll
+                for (int j = 0; j < D1; ++j) {
+                    const uint4 b = bw[s][j];
+                    rank[s][j] = pv[s][j] + (wq > 0 ? __popc(b.x) : 0) + (wq > 1 ? __popc(b.y) : 0) + (wq > 2 ? __popc(b.z) : 0) +
+                                 __popc((wq == 0 ? b.x : wq == 1 ? b.y : wq == 2 ? b.z : b.w) & low);
+                }
+            }
+        } else {
+            uint4 first[PPT][D1];
+#pragma unroll
+            for (int s = 0; s < PPT; ++s)
+#pragma unroll
+                for (int j = 0; j < D1; ++j) first[s][j] = *reinterpret_cast<const uint4 *>(list + (lc[s][j] & 0xffffu));
+            // eight 16-bit entries against e at once: entries and e are < 0x8000, so (x | 0x8000) - e keeps bit 15 of a
+            // half exactly when that half is >= e, and no half ever borrows from its neighbour
+            auto below = [](const uint4 &x, unsigned e) {
+                const unsigned e2 = e | (e << 16), hi = 0x80008000u;
+                return 8u - (unsigned)(__popc(((x.x | hi) - e2) & hi) + __popc(((x.y | hi) - e2) & hi) + __popc(((x.z | hi) - e2) & hi) +
+                                       __popc(((x.w | hi) - e2) & hi));
+            };
+#pragma unroll
+            for (int s = 0; s < PPT; ++s) {
+                const int i = tid + s * kNT;
+#pragma unroll
+                for (int j = 0; j < D1; ++j) {
+                    const unsigned e = (unsigned)(i * D1 + j);
+                    unsigned r = below(first[s][j], e);
+                    const uint4 *lp = reinterpret_cast<const uint4 *>(list + (lc[s][j] & 0xffffu));
+                    const int n8 = (int)(((lc[s][j] >> 16) + 7u) >> 3);
+                    for (int u = 1; u < n8; ++u) r += below(lp[u], e);    // rows of more than 8 entries
+                    rank[s][j] = r;
+                }
             }
         }
+#pragma unroll
+        for (int s = 0; s < PPT; ++s)
+#pragma unroll
+            for (int j = 0; j < D1; ++j) {
+                const bool real = tid + s * kNT < N;
+                pk[s][k][j] = (vid[s][j] + 1u) | ((rw[s][j] + (real ? rank[s][j] : 0u)) << 16);
+            }
         if (k == 0) row0max = hdr->rowmax;
+        FL_PSTAMP();
         __syncthreads();                                  // the next kernel's build (or the loop's product buffers) reuses the scratch
         FL_PSTAMP();
     }
@@ -472,8 +533,9 @@ __global__ void __launch_bounds__(kNT) k_frame(CrfDev c, FrameArgs a)
     for (int k = 0; k < K; ++k) alpha[k] = a.alpha;
     mean_field<PPT, K, 2>(smem, lay, V, N, tid, pr, cl, alpha, a.n_iter, a.relax, ins);
     store_results(c, f, N, tid, pr, a.with_map);
+    if (tid < K && a.V_out[tid]) a.V_out[tid][f] = tid == 0 ? V[0] : V[K - 1];
     FL_STAMP();
-    if (kInstr && a.timing && (int)blockIdx.x == a.timing_block && tid == 0) a.timing[63] = ins.n;
+    if (kInstr && a.timing && (int)blockIdx.x == a.timing_block && tid == a.timing_lane) a.timing[63] = ins.n;
 }
 
 int frame_hcap(int NA)
@@ -533,6 +595,7 @@ void launch_frame(const CrfDev &c, const KernelDev *kds, int n_iter, int with_ma
     a.timing = want_timing ? timing_buf : nullptr;
     a.timing_block = want_timing ? std::max(atoi(getenv("LCCRF_FRAME_TIMING")) - 1, 0) : 0;
     if (a.timing_block >= c.F) a.timing_block = 0;
+    a.timing_lane = (want_timing && getenv("LCCRF_FRAME_TIMING_LANE")) ? atoi(getenv("LCCRF_FRAME_TIMING_LANE")) & (kNT - 1) : 0;
     const int ppt = (NA + kNT - 1) / kNT;
 #define FRAME_CASE(P)                                          \
     case P:                                                    \

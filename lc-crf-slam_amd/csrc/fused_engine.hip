@@ -53,7 +53,7 @@ __global__ void __launch_bounds__(kNT) k_fused(CrfDev c, FusedArgs a)
     const int f = blockIdx.x;
     const int tid = threadIdx.x;
     const int N = c.n_points[f];
-    Instr ins{a.timing, a.timing_block, a.dbg, 0};
+    Instr ins{a.timing, a.timing_block, a.dbg, 0, 0};
     FL_STAMP();
 
     PointRegs<PPT, K> pr;

@@ -55,11 +55,12 @@ struct Instr {
     int timing_block;
     int dbg;
     int n;
+    int lane;                             // the lane whose clock is stamped (LCCRF_*_TIMING_LANE, default 0)
 };
 #define FL_DBG(bit) (::lccrf::fl::kInstr && (ins.dbg & (bit)))
 #define FL_STAMP()                                                                                                   \
     do {                                                                                                             \
-        if (::lccrf::fl::kInstr && ins.timing && (int)blockIdx.x == ins.timing_block && threadIdx.x == 0) ins.timing[ins.n++] = clock64(); \
+        if (::lccrf::fl::kInstr && ins.timing && (int)blockIdx.x == ins.timing_block && (int)threadIdx.x == ins.lane) ins.timing[ins.n++] = clock64(); \
     } while (0)
 #define FL_PSTAMP()                   \
     do {                              \
