@@ -222,52 +222,70 @@ def single_frame_latency(pkg, pbs, n_iter, reps=240):
     return out
 
 
-def c5_record(pkg, wl, torch, dev, steps=10):
-    """Config C5 (100 000 points, one 6-D kernel, V ~ 5.9e5, 20 iterations, one frame): the configuration whose
-    working set lives in HBM/L2, i.e. the one where the 8 TB/s roof is the applicable one."""
+def c5_record(pkg, wl, torch, dev, steps=6, frames=8):
+    """Config C5 (100 000 points, one 6-D kernel, V ~ 5.9e5, 20 iterations): the configuration whose working set lives in
+    HBM, i.e. the one where the 8 TB/s roof is the applicable one.  `frames` frames in flight (distinct buffers: ~340 MB
+    of lattice values and neighbour tables per iteration, beyond the 256 MB Infinity Cache) and, for the latency view, one."""
     import numpy as np
     N, n_iter, _, desc = WORKLOADS["c5"]
-    pb = wl.bilateral_problem(N, 1)
-    f = torch.from_numpy(pb["kernels"][0][0][None]).to(dev)
-    lab = torch.from_numpy(pb["label"][None]).to(dev)
-    npt = torch.full((1,), N, dtype=torch.int32, device=dev)
-    b = pkg.BatchCRF(1, N, 2, [6], [float(pb["kernels"][0][1])], device=dev.index)
-    b.bind_inputs_device(1, npt.data_ptr(), [f.data_ptr()], d_label=lab.data_ptr(), conf=pb["conf"])
-    b.build(); b.synchronize(); b.build(); b.synchronize()
-    build_ms = b.last_timing()["build_ms"]
-    V = float(b.lattice_sizes(0)[0])
-    for _ in range(2):
-        b.inference(n_iter, True)
-    b.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        b.inference(n_iter, True)
-    b.synchronize()
-    dt = (time.perf_counter() - t0) / steps
-    ms = []
-    for _ in range(5):
-        b.inference(n_iter, True)
-        ms.append(b.last_timing()["inference_ms"])
-    inf_ms = float(np.median(ms))
-    bytes_iter = algorithmic_bytes_per_iter(N, 2, [6], [V])
-    achieved = bytes_iter * n_iter / (inf_ms * 1e-3) / 1e9
+    pbs = [wl.bilateral_problem(N, s + 1) for s in range(2)]
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import pyoracle as po
-    o = po.OracleCRF(N, 2)
-    o.set_unary_from_label(pb["label"], pb["conf"])
-    o.add_pairwise(*pb["kernels"][0])
-    o.inference_native(n_iter, True)
-    match = float((b.map()[0] == o.map()).mean())
-    dq = float(np.abs(b.probability()[0] - o.probability()).max())
-    o.close()
-    b.close()
-    return {"workload": desc, "value": n_iter / dt, "unit": "iters/s", "ms_per_inference": dt * 1e3,
-            "lattice_vertices": V, "build_ms": build_ms,
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "algorithmic_bytes_per_iteration": bytes_iter,
-                         "inference_ms": inf_ms, "us_per_iteration": inf_ms * 1e3 / n_iter,
-                         "note": "algorithmic bytes (SURVEY 8d) / HIP-event time of the 20-iteration inference"},
-            "label_match_vs_cpu_reference": match, "max_abs_dQ_vs_cpu_reference": dq}
+    out = {"workload": desc, "unit": "iters/s"}
+    for F in (frames, 1):
+        idx = [i % len(pbs) for i in range(F)]
+        f = torch.from_numpy(np.stack([pbs[i]["kernels"][0][0] for i in idx])).to(dev)
+        lab = torch.from_numpy(np.stack([pbs[i]["label"] for i in idx])).to(dev)
+        npt = torch.full((F,), N, dtype=torch.int32, device=dev)
+        b = pkg.BatchCRF(F, N, 2, [6], [float(pbs[0]["kernels"][0][1])], device=dev.index)
+        b.bind_inputs_device(F, npt.data_ptr(), [f.data_ptr()], d_label=lab.data_ptr(), conf=pbs[0]["conf"])
+        b.build(); b.synchronize(); b.build(); b.synchronize()
+        build_ms = b.last_timing()["build_ms"]
+        V = float(b.lattice_sizes(0).astype(np.float64).mean())
+        for _ in range(2):
+            b.inference(n_iter, True)
+        b.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            b.inference(n_iter, True)
+        b.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        ms = []
+        for _ in range(3):
+            b.inference(n_iter, True)
+            ms.append(b.last_timing()["inference_ms"])
+        inf_ms = float(np.median(ms))
+        bytes_iter = algorithmic_bytes_per_iter(N, 2, [6], [V])
+        achieved = bytes_iter * n_iter * F / (inf_ms * 1e-3) / 1e9
+        rec = {"frames_in_flight": F, "value": F * n_iter / dt, "us_per_iteration_per_frame": dt * 1e6 / n_iter / F,
+               "lattice_vertices": V, "build_ms_per_batch": build_ms,
+               "roofline_whole_iteration": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                            "frac": achieved / HBM_PEAK_GBS, "algorithmic_bytes_per_iteration": bytes_iter,
+                                            "inference_ms": inf_ms,
+                                            "note": "algorithmic bytes (SURVEY 8d) x frames / HIP-event time of the 20-iteration "
+                                                    "inference (9 launches per iteration: splat, 7 blur passes, slice + softmax)"}}
+        if F == frames:
+            blur_ms, nv = b.time_blur_pass(0, 40)
+            blur_bytes = 40.0 * nv                      # SURVEY 8d: (d+1) x (8 V L + 8 V) per iteration = 40 B per vertex and pass at L = 2
+            rec["roofline"] = {"bound": "hbm", "kernel": "k_blur2 (one Jacobi blur pass over every frame), HIP events, 40 launches",
+                               "achieved": blur_bytes / (blur_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": blur_bytes / (blur_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                               "launch_ms": blur_ms, "algorithmic_bytes_per_launch": blur_bytes}
+            M, Q = b.map(), b.probability()
+            o = po.OracleCRF(N, 2)
+            o.set_unary_from_label(pbs[0]["label"], pbs[0]["conf"])
+            o.add_pairwise(*pbs[0]["kernels"][0])
+            o.inference_native(n_iter, True)
+            rec["label_match_vs_cpu_reference"] = float((M[0] == o.map()).mean())
+            rec["max_abs_dQ_vs_cpu_reference"] = float(np.abs(Q[0] - o.probability()).max())
+            o.close()
+            out.update(rec)
+        else:
+            out["single_frame"] = rec
+        b.close()
+        del f, lab, npt
+        torch.cuda.empty_cache()
+    return out
 
 
 def pmc_traffic(tag):

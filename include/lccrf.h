@@ -181,6 +181,11 @@ int  lccrf_batch_get_engine(lccrf_batch_handle b, int *engine_in_use);
  * on its stream, the number of launches of the dominant kernel and their summed
  * duration as seen by events around them (0 if not instrumented).                       */
 int  lccrf_batch_last_timing(lccrf_batch_handle b, float *inference_ms, float *build_ms);
+/* Measurement support: average HIP-event duration of `reps` launches of the streaming engine's dominant kernel (one
+ * Jacobi blur pass of `kernel` over every frame of the batch, permutohedral_cpu.h:663-679) and the number of lattice
+ * vertices one launch processes.  Needs lccrf_batch_build; leaves the CRF state (Q, labels) untouched.            */
+int  lccrf_batch_time_blur_pass(lccrf_batch_handle b, int kernel, int reps, float *ms_per_launch,
+                                int64_t *vertices_per_launch);
 
 /* ======================================================================================
  * 3. Unary builder -- the step right before the CRF (first "next" row):

@@ -111,6 +111,7 @@ def lib():
     L.lccrf_batch_set_engine.argtypes = [vp, C.c_int]
     L.lccrf_batch_get_engine.argtypes = [vp, C.POINTER(C.c_int)]
     L.lccrf_batch_last_timing.argtypes = [vp, _f32p, _f32p]
+    L.lccrf_batch_time_blur_pass.argtypes = [vp, C.c_int, C.c_int, _f32p, C.POINTER(C.c_int64)]
     L.lccrf_bf_match.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_double, _i32p, _i32p]
     L.lccrf_default_params.argtypes = [C.POINTER(CrfParams)]
     L.lccrf_default_params.restype = None
@@ -348,6 +349,12 @@ class BatchCRF:
         p, w = C.c_void_p(), C.c_int(0)
         _check(lib().lccrf_batch_device_label_bits(self.h, C.byref(p), C.byref(w)))
         return p.value, w.value
+
+    def time_blur_pass(self, kernel=0, reps=50):
+        """(ms per launch, vertices per launch) of one blur pass of `kernel` over all frames (streaming engine)."""
+        ms, nv = C.c_float(0), C.c_int64(0)
+        _check(lib().lccrf_batch_time_blur_pass(self.h, int(kernel), int(reps), C.byref(ms), C.byref(nv)))
+        return ms.value, nv.value
 
     def last_timing(self):
         a, b = C.c_float(0), C.c_float(0)

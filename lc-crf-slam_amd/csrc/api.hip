@@ -1189,6 +1189,25 @@ int lccrf_bf_match(int device_id, int n_query, const uint8_t *desc_query, int n_
     return LCCRF_OK;
 }
 
+int lccrf_batch_time_blur_pass(lccrf_batch_handle b, int kernel, int reps, float *ms_per_launch, int64_t *vertices_per_launch)
+{
+    CHECK_H(b);
+    CHECK_K(b, kernel);
+    if (reps < 1 || !ms_per_launch) return fail(LCCRF_E_INVALID, "reps < 1 or NULL output");
+    Engine &e = b->eng;
+    if (!e.built) return fail(LCCRF_E_STATE, "lccrf_batch_build has not run for these inputs");
+    int rc = e.learn_sizes();
+    if (rc) return rc;
+    if (vertices_per_launch) {
+        int64_t tot = 0;
+        for (int f = 0; f < e.F; ++f) tot += e.V_host[(size_t)kernel * e.Fcap + f];
+        *vertices_per_launch = tot;
+    }
+    hipError_t er = time_blur_pass(e.kdevs[kernel], e.F, e.maxV[kernel], e.L, reps, e.stream, ms_per_launch);
+    if (er != hipSuccess) return fail(LCCRF_E_HIP, "time_blur_pass: %s", hipGetErrorString(er));
+    return LCCRF_OK;
+}
+
 int lccrf_batch_last_timing(lccrf_batch_handle b, float *inference_ms, float *build_ms)
 {
     CHECK_H(b);

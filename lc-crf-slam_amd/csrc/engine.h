@@ -82,6 +82,7 @@ void launch_start(const CrfDev &c, hipStream_t s);
 void launch_step_stream(const CrfDev &c, const KernelDev *kds, const int *maxV, float relax,
                         hipStream_t s);
 void launch_map(const CrfDev &c, hipStream_t s);
+hipError_t time_blur_pass(const KernelDev &kd, int F, int maxV, int L, int reps, hipStream_t s, float *ms_per_launch);
 // out[f] = clamp(in[f], 0, maxN); *bad (pinned host memory) is set to 1 if anything had to be clamped
 void launch_validate_npoints(const int *in, int *out, int F, int maxN, int *bad, hipStream_t s);
 

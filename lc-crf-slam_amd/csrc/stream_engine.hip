@@ -110,39 +110,94 @@ __global__ void __launch_bounds__(kBlock) k_first_flag(KernelDev kd, const int *
     kd.flag[(size_t)f * (kd.Epad + 1) + e] = v;
 }
 
-// Exclusive scan of n ints per frame by one 1024-thread workgroup (wave scans + carry).
-// in/out strided by `stride` per frame; the grand total goes to total[f] if non-null.
-__global__ void __launch_bounds__(1024) k_scan_frame(const int *__restrict__ in, int *__restrict__ out,
-                                                     int n, int stride, int *__restrict__ total)
+// Exclusive scan of n ints per frame, any n, by many workgroups: every workgroup scans a tile of kScanTile
+// elements and leaves the tile's total (k_scan_tiles), one workgroup per frame scans the tile totals
+// (k_scan_totals), every tile adds its prefix (k_scan_apply).  in/out strided by `stride` per frame; the grand
+// total goes to total[f] if non-null.  (Round 1 scanned a frame with ONE workgroup: 0.75 ms per 700k entries.)
+constexpr int kScanTile = 4096;           // 1024 lanes x 4 consecutive elements
+
+__device__ __forceinline__ int wave_incl_scan_i32(int x)     // DPP: row_shr 1,2,4,8 then row_bcast:15 / :31
+{
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);
+    return x;
+}
+
+// exclusive prefix of one value per lane over a 1024-lane workgroup; `total` = sum over the workgroup
+__device__ __forceinline__ int block_excl_scan_1024(int x, int &total)
 {
     __shared__ int wave_sum[16];
-    __shared__ int carry_s;
-    const int f = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int incl = wave_incl_scan_i32(x);
+    __syncthreads();
+    if (lane == 63) wave_sum[wave] = incl;
+    __syncthreads();
+    const int ws = lane < 16 ? wave_sum[lane] : 0;
+    const int wincl = wave_incl_scan_i32(ws);
+    total = __builtin_amdgcn_readlane(wincl, 15);
+    return __builtin_amdgcn_readlane(wincl - ws, __builtin_amdgcn_readfirstlane(wave)) + incl - x;
+}
+
+__global__ void __launch_bounds__(1024) k_scan_tiles(const int *__restrict__ in, int *__restrict__ out, int n, int stride,
+                                                     int *__restrict__ tile_sum, int tiles)
+{
+    const int f = blockIdx.y, t = blockIdx.x;
     in += (size_t)f * stride;
     out += (size_t)f * stride;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) carry_s = 0;
-    __syncthreads();
-    for (int base = 0; base < n; base += 1024) {
-        const int i = base + threadIdx.x;
-        const int x = (i < n) ? in[i] : 0;
-        int incl = x;
+    const int i0 = t * kScanTile + threadIdx.x * 4;
+    int x[4];
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int y = __shfl_up(incl, o, 64);
-            if (lane >= o) incl += y;
-        }
-        if (lane == 63) wave_sum[wave] = incl;
-        __syncthreads();
-        int wbase = 0;
-        for (int w = 0; w < wave; ++w) wbase += wave_sum[w];
-        const int carry = carry_s;
-        if (i < n) out[i] = carry + wbase + incl - x;
-        __syncthreads();
-        if (threadIdx.x == 1023) carry_s = carry + wbase + incl;
+    for (int u = 0; u < 4; ++u) x[u] = (i0 + u < n) ? in[i0 + u] : 0;
+    int total;
+    int run = block_excl_scan_1024(x[0] + x[1] + x[2] + x[3], total);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        if (i0 + u < n) out[i0 + u] = run;                // prefix inside the tile; k_scan_apply adds the tiles before it
+        run += x[u];
+    }
+    if (threadIdx.x == 0) tile_sum[(size_t)f * tiles + t] = total;
+}
+
+__global__ void __launch_bounds__(1024) k_scan_totals(int *__restrict__ tile_sum, int tiles, int *__restrict__ total)
+{
+    const int f = blockIdx.x;
+    int *ts = tile_sum + (size_t)f * tiles;
+    int carry = 0;
+    for (int base = 0; base < tiles; base += 1024) {      // (one round up to 4M elements per frame)
+        const int i = base + threadIdx.x;
+        const int x = i < tiles ? ts[i] : 0;
+        int tot;
+        const int ex = block_excl_scan_1024(x, tot);
+        if (i < tiles) ts[i] = carry + ex;
+        carry += tot;
         __syncthreads();
     }
-    if (total && threadIdx.x == 0) total[f] = carry_s;
+    if (total && threadIdx.x == 0) total[f] = carry;
+}
+
+__global__ void __launch_bounds__(1024) k_scan_apply(int *__restrict__ out, int n, int stride, const int *__restrict__ tile_sum,
+                                                     int tiles)
+{
+    const int f = blockIdx.y, t = blockIdx.x;
+    const int add = tile_sum[(size_t)f * tiles + t];
+    out += (size_t)f * stride;
+    const int i0 = t * kScanTile + threadIdx.x * 4;
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+        if (i0 + u < n) out[i0 + u] += add;
+}
+
+// tile_sum: scratch of F * ceil(n / kScanTile) ints
+void scan_frames(const int *in, int *out, int n, int stride, int *total, int *tile_sum, int F, hipStream_t s)
+{
+    const int tiles = (n + kScanTile - 1) / kScanTile;
+    k_scan_tiles<<<dim3(tiles, F), 1024, 0, s>>>(in, out, n, stride, tile_sum, tiles);
+    k_scan_totals<<<F, 1024, 0, s>>>(tile_sum, tiles, total);
+    if (tiles > 1) k_scan_apply<<<dim3(tiles, F), 1024, 0, s>>>(out, n, stride, tile_sum, tiles);
 }
 
 // offset[e] = dense id of e's vertex; the first entry of each vertex registers as its
@@ -180,7 +235,9 @@ __device__ __forceinline__ int find_vertex(const KernelDev &kd, int f, const int
     }
 }
 
-// One thread per (axis j, vertex v): the two blur neighbours.  ref: :408-421.
+// One thread per (axis j, vertex v): the blur neighbours, ref: :408-421.  The relation is mutual -- B = n2_j(A)
+// iff A = n1_j(B) -- so one hash probe per (axis, vertex) finds n2 and fills both sides; the table was preset to
+// -1 (absent) by the caller.
 template <int D>
 __global__ void __launch_bounds__(kBlock) k_neighbors(KernelDev kd)
 {
@@ -190,21 +247,30 @@ __global__ void __launch_bounds__(kBlock) k_neighbors(KernelDev kd)
     const int idx = blockIdx.x * kBlock + threadIdx.x;
     if (idx >= V * D1) return;
     const int j = idx / V, v = idx - j * V;
-    int16_t key[D], n1[D], n2[D];
+    int16_t key[D], n2[D];
     load_entry_key<D>(kd, f, kd.rep[(size_t)f * kd.Epad + v], key);
 #pragma unroll
-    for (int t = 0; t < D; ++t) {
-        n1[t] = (int16_t)(key[t] - 1);
-        n2[t] = (int16_t)(key[t] + 1);
-    }
+    for (int t = 0; t < D; ++t) n2[t] = (int16_t)(key[t] + 1);
 #pragma unroll
     for (int t = 0; t < D; ++t)          // axis d touches only the implied last coordinate
-        if (t == j) { n1[t] = (int16_t)(key[t] + D); n2[t] = (int16_t)(key[t] - D); }
-    int2 r;
-    r.x = find_vertex<D>(kd, f, n1);
-    r.y = find_vertex<D>(kd, f, n2);
-    reinterpret_cast<int2 *>(kd.nbr)[((size_t)f * D1 + j) * kd.Epad + v] = r;
-    if (kd.Epad < 65535) kd.nbr16[((size_t)f * D1 + j) * kd.Epad + v] = (unsigned)(r.x + 1) | ((unsigned)(r.y + 1) << 16);
+        if (t == j) n2[t] = (int16_t)(key[t] - D);
+    const int b = find_vertex<D>(kd, f, n2);
+    if (b < 0) return;
+    int *nb = kd.nbr + ((size_t)f * D1 + j) * kd.Epad * 2;
+    nb[2 * v + 1] = b;                   // my n2
+    nb[2 * b] = v;                       // its n1
+}
+
+// nbr16 = (n1 + 1) | (n2 + 1) << 16 per (axis, vertex) for frames whose ids fit 16 bits (the fused engine's table)
+__global__ void __launch_bounds__(kBlock) k_neighbors16(KernelDev kd)
+{
+    const int f = blockIdx.y;
+    const int V = kd.V[f];
+    const int idx = blockIdx.x * kBlock + threadIdx.x;
+    if (idx >= V * kd.D1) return;
+    const int j = idx / V, v = idx - j * V;
+    const int2 r = reinterpret_cast<const int2 *>(kd.nbr)[((size_t)f * kd.D1 + j) * kd.Epad + v];
+    kd.nbr16[((size_t)f * kd.D1 + j) * kd.Epad + v] = (unsigned)(r.x + 1) | ((unsigned)(r.y + 1) << 16);
 }
 
 // ---- CSR of splat contributions: vertex -> (point, weight), points ascending ------------
@@ -224,9 +290,11 @@ __global__ void __launch_bounds__(kBlock) k_row_max(KernelDev kd)
 {
     const int f = blockIdx.y;
     const int v = blockIdx.x * kBlock + threadIdx.x;
-    if (v >= kd.V[f]) return;
     const int *rp = kd.rowptr + (size_t)f * (kd.Epad + 1);
-    atomicMax(&kd.rowmax[f], rp[v + 1] - rp[v]);
+    int m = v < kd.V[f] ? rp[v + 1] - rp[v] : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o, 64));      // one atomic per wavefront, not per vertex
+    if ((threadIdx.x & 63) == 0 && m > 0) atomicMax(&kd.rowmax[f], m);
 }
 
 __global__ void __launch_bounds__(kBlock) k_csr_fill(KernelDev kd, const int *__restrict__ n_points)
@@ -240,6 +308,20 @@ __global__ void __launch_bounds__(kBlock) k_csr_fill(KernelDev kd, const int *__
     kd.slot_of[(size_t)f * kd.Epad + kd.rowptr[f1 + v] + k] = e;   // slot_of reused: unsorted rows
 }
 
+// Rows come out of k_csr_fill in arrival order; the splat needs them in ascending entry order.  Short rows (the
+// common case: a vertex holds a handful of contributions): every entry counts the smaller entries of its row.
+// That is quadratic in the row length, so rows longer than kLongRow (clustered or identical features put tens of
+// thousands of entries on one vertex) are only listed here and sorted by k_csr_sort_long, one workgroup per row.
+constexpr int kLongRow = 128;
+
+__device__ __forceinline__ void csr_emit(const KernelDev &kd, size_t fe, int pos, int e, int v)
+{
+    kd.csr_pt[fe + pos] = e / kd.D1;
+    kd.csr_w[fe + pos] = kd.bary[fe + e];
+    kd.csr_pos[fe + e] = pos;
+    if (kd.Epad < 65535) kd.pk[fe + e] = (unsigned)(v + 1) | ((unsigned)pos << 16);
+}
+
 __global__ void __launch_bounds__(kBlock) k_csr_order(KernelDev kd, const int *__restrict__ n_points)
 {
     const int f = blockIdx.y;
@@ -250,12 +332,46 @@ __global__ void __launch_bounds__(kBlock) k_csr_order(KernelDev kd, const int *_
     const int e = rows[p];
     const int v = kd.offset[fe + e];
     const int s = kd.rowptr[f1 + v], t = kd.rowptr[f1 + v + 1];
+    if (t - s > kLongRow) {                              // flag[] is all zero again after k_csr_fill: reuse it as the list of
+        if (p == s) kd.flag[f1 + atomicAdd(&kd.flag[f1 + kd.Epad], 1)] = v;   // long rows, its last slot as their count
+        return;
+    }
     int rank = 0;
     for (int q = s; q < t; ++q) rank += (rows[q] < e);
-    kd.csr_pt[fe + s + rank] = e / kd.D1;
-    kd.csr_w[fe + s + rank] = kd.bary[fe + e];
-    kd.csr_pos[fe + e] = s + rank;
-    if (kd.Epad < 65535) kd.pk[fe + e] = (unsigned)(v + 1) | ((unsigned)(s + rank) << 16);
+    csr_emit(kd, fe, s + rank, e, v);
+}
+
+// One workgroup per long row: bitonic sort of the row's entry ids in place (global memory, the row belongs to this
+// workgroup alone), O(n log^2 n) compare-exchanges instead of n^2 compares.
+__global__ void __launch_bounds__(kBlock) k_csr_sort_long(KernelDev kd)
+{
+    const int f = blockIdx.y;
+    const size_t fe = (size_t)f * kd.Epad, f1 = (size_t)f * (kd.Epad + 1);
+    const int nlong = kd.flag[f1 + kd.Epad];
+    int *rows = kd.slot_of + fe;
+    for (int li = blockIdx.x; li < nlong; li += gridDim.x) {
+        const int v = kd.flag[f1 + li];
+        const int s = kd.rowptr[f1 + v], n = kd.rowptr[f1 + v + 1] - s;
+        int *r = rows + s;
+        int np2 = 1;
+        while (np2 < n) np2 <<= 1;
+        // every compare-exchange orders its pair ascending (first step of a merge: partner = mirror image inside the
+        // block of k, then half-cleaners), so the virtual +infinity elements behind n never have to move
+        for (int k = 2; k <= np2; k <<= 1) {
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int i = threadIdx.x; i < np2; i += kBlock) {
+                    const int l = (j == (k >> 1)) ? (i ^ (k - 1)) : (i ^ j);
+                    if (l > i && l < n) {
+                        const int a = r[i], b = r[l];
+                        if (a > b) { r[i] = b; r[l] = a; }
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        for (int i = threadIdx.x; i < n; i += kBlock) csr_emit(kd, fe, s + i, r[i], v);
+        __syncthreads();
+    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -462,15 +578,18 @@ void build_kernel_d(const KernelDev &kd, const CrfDev &c, hipStream_t s)
     k_points<D><<<grid_for(kd.maxNpad, F), kBlock, 0, s>>>(kd, c.n_points);
     k_insert<D><<<grid_for(kd.Epad, F), kBlock, 0, s>>>(kd, c.n_points);
     k_first_flag<<<grid_for(kd.Epad + 1, F), kBlock, 0, s>>>(kd, c.n_points);
-    k_scan_frame<<<F, 1024, 0, s>>>(kd.flag, kd.prefix, kd.Epad + 1, kd.Epad + 1, kd.V);
+    scan_frames(kd.flag, kd.prefix, kd.Epad + 1, kd.Epad + 1, kd.V, kd.rep, F, s);     // (rep is written later, by k_offsets: free scratch)
     k_offsets<<<grid_for(kd.Epad, F), kBlock, 0, s>>>(kd, c.n_points);
+    (void)hipMemsetAsync(kd.nbr, 0xff, (size_t)F * D1 * kd.Epad * 2 * sizeof(int), s);          // every neighbour absent (-1)
     k_neighbors<D><<<grid_for((long)kd.Epad * D1, F), kBlock, 0, s>>>(kd);
+    if (kd.Epad < 65535) k_neighbors16<<<grid_for((long)kd.Epad * D1, F), kBlock, 0, s>>>(kd);
     // CSR
     (void)hipMemsetAsync(kd.flag, 0, (size_t)F * (kd.Epad + 1) * sizeof(int), s);
     k_csr_count<<<grid_for(kd.Epad, F), kBlock, 0, s>>>(kd, c.n_points);
-    k_scan_frame<<<F, 1024, 0, s>>>(kd.flag, kd.rowptr, kd.Epad + 1, kd.Epad + 1, nullptr);
+    scan_frames(kd.flag, kd.rowptr, kd.Epad + 1, kd.Epad + 1, nullptr, kd.csr_pos, F, s);   // (csr_pos is written later, by k_csr_order)
     k_csr_fill<<<grid_for(kd.Epad, F), kBlock, 0, s>>>(kd, c.n_points);
     k_csr_order<<<grid_for(kd.Epad, F), kBlock, 0, s>>>(kd, c.n_points);
+    k_csr_sort_long<<<dim3(64, F), kBlock, 0, s>>>(kd);                     // rows of more than kLongRow entries, if any
     (void)hipMemsetAsync(kd.rowmax, 0, (size_t)F * sizeof(int), s);
     k_row_max<<<grid_for(kd.Epad, F), kBlock, 0, s>>>(kd);
 }
@@ -568,6 +687,33 @@ void launch_step_stream(const CrfDev &c, const KernelDev *kds, const int *maxV, 
                                                                  k == 0 ? SLICE_APPLY_FIRST : SLICE_APPLY);
     }
     k_softmax<<<grid_for(c.maxN, c.F), kBlock, 0, s>>>(c, c.next, c.Q, 1.0f, relax);
+}
+
+// Measurement support (bench.py's roofline object): `reps` launches of the streaming engine's dominant kernel --
+// one blur pass of kernel kd over all F frames -- bracketed by HIP events on stream s.  The lattice values it
+// scribbles over are recomputed from Q by every mean-field step.
+hipError_t time_blur_pass(const KernelDev &kd, int F, int maxV, int L, int reps, hipStream_t s, float *ms_per_launch)
+{
+    hipEvent_t e0, e1;
+    hipError_t rc = hipEventCreate(&e0);
+    if (rc != hipSuccess) return rc;
+    if ((rc = hipEventCreate(&e1)) != hipSuccess) { (void)hipEventDestroy(e0); return rc; }
+    auto pass = [&](int i) {
+        const float *src = (i & 1) ? kd.val1 : kd.val0;
+        float *dst = (i & 1) ? kd.val0 : kd.val1;
+        if (L == 2) k_blur2<<<grid_for(maxV, F), kBlock, 0, s>>>(kd, src, dst, i % kd.D1);
+        else k_blur<<<grid_for((long)maxV * L, F), kBlock, 0, s>>>(kd, src, dst, i % kd.D1, L);
+    };
+    for (int i = 0; i < 3; ++i) pass(i);
+    (void)hipEventRecord(e0, s);
+    for (int i = 0; i < reps; ++i) pass(i);
+    (void)hipEventRecord(e1, s);
+    rc = hipEventSynchronize(e1);
+    if (rc == hipSuccess) rc = hipEventElapsedTime(ms_per_launch, e0, e1);
+    *ms_per_launch /= (float)reps;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return rc;
 }
 
 void launch_validate_npoints(const int *in, int *out, int F, int maxN, int *bad, hipStream_t s)

@@ -1,0 +1,13 @@
+#!/bin/bash
+# A/B of a compile-time switch on the GPU box:  scripts/gpu_ab.sh "-DLCCRF_CHAIN_EXCL=0" [workloads...]
+# builds a second library with the extra flag and runs the same bench lines with both, interleaved.
+FLAG="$1"; shift
+make -C lc-crf-slam_amd -j8 EXTRA="$FLAG" BUILD=build_ab LIB=liblccrf_hip_ab.so >/dev/null || exit 1
+for w in ${@:-c2}; do
+for rep in 1 2; do
+for lib in liblccrf_hip.so liblccrf_hip_ab.so; do
+LCCRF_LIB=$PWD/lc-crf-slam_amd/$lib timeout 300 python bench.py --workload $w --no-cpu-baseline --no-extras 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1])
+print('$lib $w iters/s %.4g launch_ms %.4f | one-launch %.4f ms | match %s' % (d['value'], d['roofline']['launch_ms'], d['end_to_end']['one_launch_ms_per_batch'], d['label_match_vs_cpu_reference']))"
+done; done; done

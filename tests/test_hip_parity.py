@@ -481,3 +481,23 @@ def test_hip_c5_full_size_matches_oracle(po, wl):
     assert cc.same_bits(b.probability()[0], o.probability()) and np.array_equal(b.map()[0], o.map())
     assert int(b.lattice_sizes(0)[0]) == ko["V"]
     b.close()
+
+
+@pytest.mark.parametrize("N,d,L", [(6000, 2, 3), (5000, 3, 2), (700, 5, 4)])
+def test_streaming_build_with_very_long_rows(po, wl, N, d, L):
+    """clustered / identical features put thousands of entries on one vertex; the streaming build orders such
+    rows with a per-row sort instead of the quadratic rank (k_csr_sort_long).  Lattice and results vs the oracle."""
+    rng = np.random.default_rng(7)
+    pb = wl.generic_problem(N, [d], L, seed=3)
+    f = pb["kernels"][0][0].copy()
+    f[: N // 2] = f[0]                                     # half the points in ONE cell: d+1 rows of N/2 entries
+    f[N // 2: N // 2 + N // 4] = f[-1] + rng.normal(0, 0.01, (N // 4, d)).astype(np.float32)   # a tight cluster
+    pb["kernels"] = [(f, pb["kernels"][0][1])]
+    o, h = cc.setup(po.OracleCRF, pb), cc.setup(pkg.DenseCRFHIP, pb)
+    ko, kh = o.kernel(0), h.kernel(0)
+    assert ko["V"] == kh["V"]
+    for name in ("offset", "bary", "nbr", "norm"):
+        assert cc.same_bits(ko[name], kh[name]), name
+    o.inference_native(3, True)
+    h.inference(3, True)
+    assert cc.same_bits(o.probability(), h.probability()) and np.array_equal(o.map(), h.map())
