@@ -103,6 +103,26 @@ int  lccrf_inference(lccrf_handle h, int n_iterations, int with_map, float relax
 int  lccrf_get_map(lccrf_handle h, int16_t *map_out);
 int  lccrf_get_probability(lccrf_handle h, float *prob_out);
 
+/* ---- the reference's two plug-in points, on HOST arrays (device in, device out behind the call) ------------------
+ * PairwisePotential::apply(out_values, in_values, tmp)        densecrf_base.h:18, pairwise3d.h:73-78
+ *   out_values[i][k] += w * norm[i] * compute(in_values)[i][k] for pairwise term `kernel` of this CRF (both
+ *   [N][n_labels]; the reference's `tmp` scratch lives on the device).  This is the one pure virtual of the
+ *   reference's plug-in class: a caller that mixes its own PairwisePotential subclasses with ours drives the
+ *   mean-field step itself (densecrf_base.h:82-91) and calls this for our terms.                               */
+int  lccrf_pairwise_apply(lccrf_handle h, int kernel, float *out_values, const float *in_values);
+/* DenseCRF's protected virtuals (densecrf_base.h:34-36), for exactly that kind of caller:
+ *   expAndNormalize(out, in, scale, relax)    densecrf3d.h:70-98   (out is read too when relax != 1)
+ *   stepInit(): next = -unary                 densecrf3d.h:154-158
+ *   buildMap() on a given probability array   densecrf3d.h:136-151                                            */
+int  lccrf_exp_and_normalize(lccrf_handle h, float *out, const float *in, float scale, float relax);
+int  lccrf_step_init(lccrf_handle h, float *next_out);
+int  lccrf_map_of(lccrf_handle h, const float *prob, int16_t *map_out);
+/* PermutohedralLatticeCPU::init(features, d, N) + compute(out, in, value_size)   permutohedral_cpu.h:241-424,634-699
+ * the bare lattice filter (splat, d+1 blurs, slice; no normalisation, no weight) with any value_size in
+ * [1, LCCRF_MAX_LABELS]; n_vertices (may be NULL) receives the lattice size M_.                                */
+int  lccrf_lattice_filter(int device_id, const float *features, int n_points, int d, const float *in,
+                          int value_size, float *out, int *n_vertices);
+
 /* Parity probes (no reference API; the reference keeps these protected):
  * lattice size M_ (permutohedral_cpu.h:398) and PottsPotential3D::norm_ (pairwise3d.h:18).
  * offset/bary are [N][d+1], nbr is [d+1][V][2]; any output pointer may be NULL.         */

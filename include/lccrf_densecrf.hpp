@@ -14,13 +14,27 @@
 // (see INTEGRATION.md).  Method names, argument meaning, defaults and ownership follow
 //   densecrf_base.h:22-92   (DenseCRF)            densecrf3d.h:13-49   (DenseCRF3D<M>)
 //   densecrf_base.h:12-19   (PairwisePotential)   pairwise3d.h:13-79   (PottsPotential3D<M,F>)
+//
+// The adapters DERIVE from the reference's two abstract classes.  With the reference tree on the include
+// path (-I Thirdparty/DenseCRF/include) those are the reference's own densecrf_base.h, so
+//   * a DenseCRF* / PairwisePotential* held by reference code can point at a DenseCRFHIP / PottsPotentialHIP;
+//   * PottsPotentialHIP::apply() is the reference's pure virtual (densecrf_base.h:18) on the GPU -- it can be
+//     added to the reference's CPU DenseCRF3D, or called on its own;
+//   * the reference's (or a user's) own PairwisePotential subclasses can be added to a DenseCRFHIP: the
+//     mean-field step then runs as densecrf_base.h:82-91 writes it -- stepInit, every potential's apply on the
+//     host arrays, expAndNormalize -- with this library's share of each step on the GPU (lccrf_step_init,
+//     lccrf_pairwise_apply, lccrf_exp_and_normalize) and the foreign potentials where their authors put them.
+// Without the reference tree (this repository's own tests; -DLCCRF_NO_REFERENCE_BASES forces it) the same two
+// shapes are declared below.  When every potential is ours, inference() is ONE kernel launch per frame.
+//
 // Differences, all deliberate:
 //   * errors are loud: any non-zero lccrf status throws std::runtime_error (the reference has
 //     no error path at all); there is no CPU fallback behind these classes;
-//   * getMap()/getProbability() return pointers into object-owned HOST buffers that are
-//     refreshed on call (the reference returns its live internal arrays);
-//   * a potential is a feature carrier until it is added: the lattice is built on the GPU when
-//     the CRF takes ownership (the reference builds it in the potential's constructor).
+//   * the unary energies live on the device: the base's unary_ stays null;
+//   * getMap() is refreshed by inference(n, true) / buildMap(); getProbability() by this class's own (const)
+//     getter -- a caller that reads probabilities through a DenseCRF* base pointer calls syncProbability() first;
+//   * a potential is a feature carrier until it is added or applied: the lattice is built on the GPU then
+//     (the reference builds it in the potential's constructor).
 #pragma once
 
 #include <cstdint>
@@ -30,6 +44,65 @@
 
 #include "lccrf.h"
 
+#if !defined(LCCRF_NO_REFERENCE_BASES) && defined(__has_include)
+#if __has_include("densecrf_base.h")
+#include "densecrf_base.h"
+#define LCCRF_HAVE_REFERENCE_BASES 1
+#endif
+#endif
+
+#ifndef LCCRF_HAVE_REFERENCE_BASES
+namespace DenseCRF {
+// The two abstract shapes of densecrf_base.h (:7-9, :12-19, :22-92), for builds without the reference tree.
+enum Device { CPU, GPU };
+
+class PairwisePotential {
+protected:
+    int N_;
+public:
+    explicit PairwisePotential(int N) : N_(N) {}
+    virtual ~PairwisePotential() = default;
+    virtual void apply(float *out_values, const float *in_values, float *tmp) const = 0;
+};
+
+class DenseCRF {
+protected:
+    int N_;
+    float *unary_ = nullptr, *current_ = nullptr, *next_ = nullptr, *tmp_ = nullptr;
+    short *map_ = nullptr;
+    std::vector<PairwisePotential *> pairwise_;
+    virtual void expAndNormalize(float *out, const float *in, float scale = 1.0, float relax = 1.0) = 0;
+    virtual void buildMap() = 0;
+    virtual void stepInit() = 0;
+public:
+    explicit DenseCRF(int N) : N_(N) {}
+    virtual ~DenseCRF()
+    {
+        for (PairwisePotential *p : pairwise_) delete p;          // the CRF owns its terms
+    }
+    void addPairwiseEnergy(PairwisePotential *potential) { pairwise_.push_back(potential); }
+    virtual void setUnaryEnergy(const float *unary) = 0;
+    virtual void setUnaryEnergyFromLabel(const short *label, float *confidences) = 0;
+    virtual void setUnaryEnergyFromLabel(const short *label, float confidence = 0.5) = 0;
+    virtual void startInference() { expAndNormalize(current_, unary_, -1); }
+    virtual void stepInference(float relax = 1.0)
+    {
+        stepInit();
+        for (PairwisePotential *p : pairwise_) p->apply(next_, current_, tmp_);
+        expAndNormalize(current_, next_, 1.0, relax);
+    }
+    virtual void inference(int n_iterations, bool with_map = false, float relax = 1.0)
+    {
+        startInference();
+        for (int it = 0; it < n_iterations; ++it) stepInference(relax);
+        if (with_map) buildMap();
+    }
+    short *getMap() const { return map_; }
+    float *getProbability() const { return current_; }
+};
+}  // namespace DenseCRF
+#endif
+
 namespace DenseCRF {
 
 inline void lccrf_check(int rc, const char *what)
@@ -38,33 +111,59 @@ inline void lccrf_check(int rc, const char *what)
         throw std::runtime_error(std::string(what) + ": lccrf status " + std::to_string(rc) + ": " + lccrf_last_error());
 }
 
-// ---- PairwisePotential ----------------------------------------------------------------
-class PairwisePotentialHIP {
-protected:
-    int N_;
+// What a DenseCRFHIP needs to know about a potential that runs on this library's kernels.
+class HipPotential {
 public:
-    explicit PairwisePotentialHIP(int N) : N_(N) {}
-    virtual ~PairwisePotentialHIP() = default;
+    virtual ~HipPotential() = default;
     virtual int dims() const = 0;
     virtual float weight() const = 0;
     virtual const float *features() const = 0;      // [N][dims], already divided by the stdevs
+    virtual void bind(lccrf_handle crf, int kernel) const = 0;   // from now on apply() is term `kernel` of that CRF
 };
+using PairwisePotentialHIP = HipPotential;          // (round-1 name)
 
 // PottsPotential3D<M,F>, pairwise3d.h:13-79
 template <int M, int F>
-class PottsPotentialHIP : public PairwisePotentialHIP {
+class PottsPotentialHIP : public PairwisePotential, public HipPotential {
 protected:
     float w_;
     std::vector<float> feat_;
+    mutable lccrf_handle h_ = nullptr;              // the CRF this term belongs to, or a private one-term CRF (own_)
+    mutable int k_ = -1;
+    mutable bool own_ = false;
 public:
     // pairwise3d.h:20 -- features are [N][F] AoS
     PottsPotentialHIP(const float *features, int N, float w)
-        : PairwisePotentialHIP(N), w_(w), feat_(features, features + (size_t)N * F) {}
+        : PairwisePotential(N), w_(w), feat_(features, features + (size_t)N * F) {}
     PottsPotentialHIP(const PottsPotentialHIP &) = delete;
+    ~PottsPotentialHIP() override
+    {
+        if (own_) lccrf_destroy(h_);
+    }
 
     int dims() const override { return F; }
     float weight() const override { return w_; }
     const float *features() const override { return feat_.data(); }
+    void bind(lccrf_handle crf, int kernel) const override
+    {
+        if (own_) lccrf_destroy(h_);
+        own_ = false;
+        h_ = crf;
+        k_ = kernel;
+    }
+
+    // densecrf_base.h:18 / pairwise3d.h:73-78: out_values += w * norm * compute(in_values), both [N][M] on the host.
+    // `tmp` is the reference's scratch for compute(); ours lives on the device.
+    void apply(float *out_values, const float *in_values, float * /*tmp*/) const override
+    {
+        if (!h_) {                                   // not part of a DenseCRFHIP (yet): a private one-term CRF carries the lattice
+            lccrf_check(lccrf_create(&h_, 0, N_, M), "lccrf_create");
+            own_ = true;
+            k_ = 0;
+            lccrf_check(lccrf_add_pairwise(h_, feat_.data(), F, w_), "lccrf_add_pairwise");
+        }
+        lccrf_check(lccrf_pairwise_apply(h_, k_, out_values, in_values), "lccrf_pairwise_apply");
+    }
 
     // pairwise3d.h:37-48
     template <class T = float>
@@ -98,69 +197,145 @@ public:
 
 // ---- DenseCRF3D<M> ---------------------------------------------------------------------
 template <int M>
-class DenseCRFHIP {
+class DenseCRFHIP : public DenseCRF {
 protected:
-    int N_;
-    lccrf_handle h_;
-    std::vector<short> map_;
-    std::vector<float> prob_;
+    lccrf_handle h_ = nullptr;
+    size_t adopted_ = 0;                  // pairwise_[0, adopted_) have been looked at
+    int n_hip_ = 0;                       // ... of which this many are terms of the handle
+    bool mixed_ = false;                  // some potential is not ours: host-array stepping (densecrf_base.h:82-91)
+    mutable std::vector<short> map_buf_;
+    mutable std::vector<float> cur_buf_, next_buf_, tmp_buf_;
+
+    // Potentials may also arrive through the base class's non-virtual addPairwiseEnergy (a DenseCRF* in reference
+    // code): whatever is new in pairwise_ is taken in before anything runs.
+    void adopt()
+    {
+        for (; adopted_ < pairwise_.size(); ++adopted_) {
+            const HipPotential *hp = dynamic_cast<const HipPotential *>(pairwise_[adopted_]);
+            if (hp) {
+                lccrf_check(lccrf_add_pairwise(h_, hp->features(), hp->dims(), hp->weight()), "lccrf_add_pairwise");
+                hp->bind(h_, n_hip_++);
+            } else {
+                mixed_ = true;
+            }
+        }
+    }
+
+    // DenseCRF's protected virtuals (densecrf_base.h:34-36), each one kernel on the GPU
+    void expAndNormalize(float *out, const float *in, float scale = 1.0, float relax = 1.0) override   // densecrf3d.h:70-98
+    {
+        lccrf_check(lccrf_exp_and_normalize(h_, out, in, scale, relax), "lccrf_exp_and_normalize");
+    }
+    void stepInit() override                                                   // densecrf3d.h:154-158
+    {
+        lccrf_check(lccrf_step_init(h_, next_), "lccrf_step_init");
+    }
+    void buildMap() override                                                   // densecrf3d.h:136-151
+    {
+        if (mixed_) {
+            lccrf_check(lccrf_map_of(h_, current_, map_), "lccrf_map_of");
+        } else {
+            lccrf_check(lccrf_build_map(h_), "lccrf_build_map");
+            lccrf_check(lccrf_get_map(h_, map_), "lccrf_get_map");
+        }
+    }
+
 public:
-    explicit DenseCRFHIP(int N, int device_id = 0) : N_(N), h_(nullptr)       // densecrf3d.h:23
+    explicit DenseCRFHIP(int N, int device_id = 0)                              // densecrf3d.h:23
+        : DenseCRF(N), map_buf_((size_t)N + 1), cur_buf_((size_t)N * M + 1), next_buf_((size_t)N * M + 1), tmp_buf_((size_t)N * M + 1)
     {
         lccrf_check(lccrf_create(&h_, device_id, N, M), "lccrf_create");
+        current_ = cur_buf_.data();       // the buffers the base class's getters hand out
+        next_ = next_buf_.data();
+        tmp_ = tmp_buf_.data();
+        map_ = map_buf_.data();
     }
-    ~DenseCRFHIP() { lccrf_destroy(h_); }                                     // densecrf3d.h:30
+    ~DenseCRFHIP() override                                                    // densecrf3d.h:30; ~DenseCRF deletes the potentials
+    {
+        lccrf_destroy(h_);
+        current_ = next_ = tmp_ = nullptr;
+        map_ = nullptr;
+    }
     DenseCRFHIP(DenseCRFHIP &) = delete;
 
     // densecrf_base.h:54 -- ownership of the potential moves to the CRF
-    void addPairwiseEnergy(PairwisePotentialHIP *potential)
+    void addPairwiseEnergy(PairwisePotential *potential)
     {
-        const int rc = lccrf_add_pairwise(h_, potential->features(), potential->dims(), potential->weight());
-        delete potential;
-        lccrf_check(rc, "lccrf_add_pairwise");
+        DenseCRF::addPairwiseEnergy(potential);
+        adopt();
     }
 
-    void setUnaryEnergy(const float *unary) { lccrf_check(lccrf_set_unary(h_, unary), "lccrf_set_unary"); }
+    void setUnaryEnergy(const float *unary) override { lccrf_check(lccrf_set_unary(h_, unary), "lccrf_set_unary"); }
 
-    void setUnaryEnergyFromLabel(const short *label, float *confidences)      // densecrf3d.h:107
+    void setUnaryEnergyFromLabel(const short *label, float *confidences) override    // densecrf3d.h:107
     {
         lccrf_check(lccrf_set_unary_from_label(h_, label, confidences), "lccrf_set_unary_from_label");
     }
-    void setUnaryEnergyFromLabel(const short *label, float confidence = 0.5)  // densecrf3d.h:100
+    void setUnaryEnergyFromLabel(const short *label, float confidence = 0.5) override   // densecrf3d.h:100
     {
         float c[M];
         for (int i = 0; i < M; ++i) c[i] = confidence;
         setUnaryEnergyFromLabel(label, c);
     }
 
-    void inference(int n_iterations, bool with_map = false, float relax = 1.0)   // densecrf_base.h:65
+    void inference(int n_iterations, bool with_map = false, float relax = 1.0) override   // densecrf_base.h:65
     {
+        adopt();
+        if (mixed_) {
+            DenseCRF::inference(n_iterations, with_map, relax);
+            return;
+        }
         lccrf_check(lccrf_inference(h_, n_iterations, with_map ? 1 : 0, relax), "lccrf_inference");
+        if (with_map) lccrf_check(lccrf_get_map(h_, map_), "lccrf_get_map");
     }
-    void startInference() { lccrf_check(lccrf_start_inference(h_), "lccrf_start_inference"); }
-    void stepInference(float relax = 1.0) { lccrf_check(lccrf_step_inference(h_, relax), "lccrf_step_inference"); }
-    void buildMap() { lccrf_check(lccrf_build_map(h_), "lccrf_build_map"); }
+    void startInference() override                                             // densecrf_base.h:78
+    {
+        adopt();
+        if (mixed_) {
+            lccrf_check(lccrf_step_init(h_, next_), "lccrf_step_init");       // next = -unary (the unaries live on the device) ...
+            expAndNormalize(current_, next_, 1.0, 1.0);                         // ... so softmax(-unary) is expAndNormalize(next, scale 1)
+        } else {
+            lccrf_check(lccrf_start_inference(h_), "lccrf_start_inference");
+        }
+    }
+    void stepInference(float relax = 1.0) override                             // densecrf_base.h:82
+    {
+        adopt();
+        if (mixed_) DenseCRF::stepInference(relax);
+        else lccrf_check(lccrf_step_inference(h_, relax), "lccrf_step_inference");
+    }
 
-    short *getMap()                                                            // densecrf_base.h:74
+    // densecrf_base.h:74-75.  Pointers into object-owned host buffers, valid until destruction.
+    short *getMap() const { return map_; }
+    float *getProbability() const
     {
-        map_.resize((size_t)N_ + 1);
-        lccrf_check(lccrf_get_map(h_, map_.data()), "lccrf_get_map");
-        return map_.data();
+        syncProbability();
+        return current_;
     }
-    float *getProbability()                                                    // densecrf_base.h:75
+    // refresh the host copy of Q behind getProbability() (a no-op in mixed mode, where Q lives in current_ anyway)
+    void syncProbability() const
     {
-        prob_.resize((size_t)N_ * M + 1);
-        lccrf_check(lccrf_get_probability(h_, prob_.data()), "lccrf_get_probability");
-        return prob_.data();
+        if (!mixed_) lccrf_check(lccrf_get_probability(h_, current_), "lccrf_get_probability");
     }
 
     int latticeSize(int kernel)
     {
+        adopt();
         int V = 0;
         lccrf_check(lccrf_get_lattice_size(h_, kernel, &V), "lccrf_get_lattice_size");
         return V;
     }
+    bool mixed() const { return mixed_; }
     lccrf_handle handle() const { return h_; }
 };
+
+// DenseCRF::Create<M>(N) is an empty stub in the reference (densecrf_base.h:47-51) next to its Device enum (:7-9);
+// this is the factory it points at: the GPU implementation behind the abstract type.
+template <int M>
+inline DenseCRF *CreateDenseCRF(int N, Device device = GPU, int device_id = 0)
+{
+    if (device != GPU) throw std::runtime_error("CreateDenseCRF: this library has no CPU implementation (use the reference's DenseCRF3D)");
+    return new DenseCRFHIP<M>(N, device_id);
+}
 
 }  // namespace DenseCRF

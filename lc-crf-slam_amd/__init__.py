@@ -91,6 +91,11 @@ def lib():
     L.lccrf_get_probability.argtypes = [vp, _f32p]
     L.lccrf_get_unary.argtypes = [vp, _f32p]
     L.lccrf_get_lattice_size.argtypes = [vp, C.c_int, C.POINTER(C.c_int)]
+    L.lccrf_pairwise_apply.argtypes = [vp, C.c_int, _f32p, _f32p]
+    L.lccrf_exp_and_normalize.argtypes = [vp, _f32p, _f32p, C.c_float, C.c_float]
+    L.lccrf_step_init.argtypes = [vp, _f32p]
+    L.lccrf_map_of.argtypes = [vp, _f32p, _i16p]
+    L.lccrf_lattice_filter.argtypes = [C.c_int, _f32p, C.c_int, C.c_int, _f32p, C.c_int, _f32p, C.POINTER(C.c_int)]
     L.lccrf_get_norm.argtypes = [vp, C.c_int, _f32p]
     L.lccrf_get_lattice.argtypes = [vp, C.c_int, _i32p, _f32p, _i32p]
     L.lccrf_batch_create.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(BatchDesc)]
@@ -213,6 +218,31 @@ class DenseCRFHIP:
             self.step_inference(relax)
             out[t + 1] = self.probability()
         return out
+
+    # -- the reference's plug-in points (densecrf_base.h:18,34-36) on host arrays ------------
+    def apply(self, k, out, x):
+        """PairwisePotential::apply of kernel k: returns out + w * norm * compute(x)."""
+        o = _f32(out).reshape(self.N, self.L).copy()
+        xin = _f32(x).reshape(self.N, self.L)
+        _check(lib().lccrf_pairwise_apply(self.h, int(k), _p(o, _f32p), _p(xin, _f32p)))
+        return o
+
+    def exp_and_normalize(self, x, scale=1.0, relax=1.0, old=None):
+        xin = _f32(x).reshape(self.N, self.L)
+        o = np.zeros_like(xin) if old is None else _f32(old).reshape(self.N, self.L).copy()
+        _check(lib().lccrf_exp_and_normalize(self.h, _p(o, _f32p), _p(xin, _f32p), float(scale), float(relax)))
+        return o
+
+    def step_init(self):
+        o = np.empty((self.N, self.L), np.float32)
+        _check(lib().lccrf_step_init(self.h, _p(o, _f32p)))
+        return o
+
+    def map_of(self, prob):
+        p = _f32(prob).reshape(self.N, self.L)
+        m = np.empty(self.N, np.int16)
+        _check(lib().lccrf_map_of(self.h, _p(p, _f32p), _p(m, _i16p)))
+        return m
 
     # -- results -----------------------------------------------------------------------
     def map(self):
@@ -360,6 +390,18 @@ class BatchCRF:
         a, b = C.c_float(0), C.c_float(0)
         _check(lib().lccrf_batch_last_timing(self.h, C.byref(a), C.byref(b)))
         return dict(inference_ms=a.value, build_ms=b.value)
+
+
+def lattice_filter(features, x, device=0):
+    """PermutohedralLatticeCPU::init + compute on the GPU (lccrf_lattice_filter): returns (y, V)."""
+    f = _f32(features)
+    N, d = f.shape
+    xa = _f32(x)
+    xin = xa.reshape(N, xa.shape[-1] if xa.ndim == 2 else max(xa.size // max(N, 1), 1))
+    out = np.empty_like(xin)
+    V = C.c_int(0)
+    _check(lib().lccrf_lattice_filter(int(device), _p(f, _f32p), N, d, _p(xin, _f32p), xin.shape[1], _p(out, _f32p), C.byref(V)))
+    return out, V.value
 
 
 def default_params():

@@ -133,6 +133,20 @@ struct Engine {
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   // build begin/end, inference begin/end
     hipEvent_t ev_order = nullptr;     // orders a caller-supplied stream against the engine's own (StreamScope)
     int *npoints_bad = nullptr;        // pinned: set by the validation kernel when a bound n_points[f] is outside [0, maxN]
+    float *io_a = nullptr, *io_b = nullptr;   // device [Fcap][maxN][L] each: caller buffers of apply / expAndNormalize / ... (lazy)
+    int16_t *io_map = nullptr;
+
+    int need_io()
+    {
+        if (io_a) return LCCRF_OK;
+        const size_t nl = (size_t)Fcap * maxN * L;
+        int rc;
+        if ((rc = mem.alloc(&io_a, nl))) return rc;
+        if ((rc = mem.alloc(&io_b, nl))) return rc;
+        if ((rc = mem.alloc(&io_map, (size_t)Fcap * maxN))) return rc;
+        HIP_TRY(hipStreamSynchronize(stream));
+        return LCCRF_OK;
+    }
     // Late-bound fused inference (object API): queued right behind the build, before the host has seen
     // the lattice sizes; `late_status` (pinned) tells afterwards whether the frame fitted.
     int *late_status = nullptr;
@@ -221,8 +235,10 @@ struct Engine {
         k.maxNpad = maxNpad;
         k.Epad = maxNpad * k.D1;
         k.cap = next_pow2(2L * k.Epad);
-        k.vstride = (k.Epad + 1) * L;
-        k.vbase = L;
+        // lattice values of a frame: [0, L) unused, [L, 2L) the all-zero "absent neighbour" (vertex -1), vertex v at
+        // vbase + v*L; with L = 2 and an even stride, vertex pairs (2t, 2t+1) are 16-byte aligned (k_blur2)
+        k.vstride = (k.Epad + 2) * L;
+        k.vbase = 2 * L;
         k.w = w;
         // permutohedral_cpu.h:681 / :249 / :282-285 (quirk Q4): same expressions, same types
         k.alpha = 1.0f / (1 + powf(2, -d));
@@ -646,6 +662,12 @@ int lccrf_trim_cache(void)
         HIP_TRY(hipSetDevice((h)->eng.device));                       \
     } while (0)
 
+#define CHECK_K(h, k)                                                                      \
+    do {                                                                                   \
+        if ((k) < 0 || (k) >= (int)(h)->eng.kernels.size())                                \
+            return fail(LCCRF_E_INVALID, "kernel index %d out of range", (k));             \
+    } while (0)
+
 int lccrf_set_unary(lccrf_handle h, const float *unary)
 {
     CHECK_H(h);
@@ -754,6 +776,115 @@ int lccrf_inference(lccrf_handle h, int n_iterations, int with_map, float relax)
     return h->eng.inference(n_iterations, with_map, relax);
 }
 
+// ---- the reference's plug-in points on host arrays: PairwisePotential::apply and DenseCRF's protected virtuals --------
+int lccrf_pairwise_apply(lccrf_handle h, int kernel, float *out_values, const float *in_values)
+{
+    CHECK_H(h);
+    CHECK_K(h, kernel);
+    if ((!out_values || !in_values) && h->N) return fail(LCCRF_E_INVALID, "out_values / in_values is NULL");
+    Engine &e = h->eng;
+    int rc = e.resolve_late();
+    if (!rc) rc = e.learn_sizes();                        // builds the lattice if it only exists as staged features
+    if (!rc) rc = e.need_io();
+    if (rc) return rc;
+    const size_t n = (size_t)h->N * e.L * sizeof(float);
+    if (!n) return LCCRF_OK;
+    HIP_TRY(hipStreamSynchronize(e.stream));
+    HIP_TRY(hipMemcpy(e.io_a, in_values, n, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(e.io_b, out_values, n, hipMemcpyHostToDevice));
+    launch_filter(e.kdevs[kernel], e.crf, e.maxV[kernel], e.io_a, e.io_b, 1, e.stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(e.stream));
+    HIP_TRY(hipMemcpy(out_values, e.io_b, n, hipMemcpyDeviceToHost));
+    return LCCRF_OK;
+}
+
+int lccrf_exp_and_normalize(lccrf_handle h, float *out, const float *in, float scale, float relax)
+{
+    CHECK_H(h);
+    if ((!out || !in) && h->N) return fail(LCCRF_E_INVALID, "out / in is NULL");
+    Engine &e = h->eng;
+    int rc = e.resolve_late();
+    if (!rc) rc = e.need_io();
+    if (rc) return rc;
+    const size_t n = (size_t)h->N * e.L * sizeof(float);
+    if (!n) return LCCRF_OK;
+    HIP_TRY(hipStreamSynchronize(e.stream));
+    HIP_TRY(hipMemcpy(e.io_a, in, n, hipMemcpyHostToDevice));
+    if (relax != 1.0f) HIP_TRY(hipMemcpy(e.io_b, out, n, hipMemcpyHostToDevice));   // the blend reads the old out (densecrf3d.h:91-94)
+    launch_exp_and_normalize(e.crf, e.io_a, e.io_b, scale, relax, e.stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(e.stream));
+    HIP_TRY(hipMemcpy(out, e.io_b, n, hipMemcpyDeviceToHost));
+    return LCCRF_OK;
+}
+
+int lccrf_step_init(lccrf_handle h, float *next_out)
+{
+    CHECK_H(h);
+    if (!next_out && h->N) return fail(LCCRF_E_INVALID, "next_out is NULL");
+    Engine &e = h->eng;
+    if (!e.unary_set) return fail(LCCRF_E_STATE, "unary energies not set");
+    int rc = e.resolve_late();
+    if (!rc) rc = e.ensure_unary();
+    if (!rc) rc = e.need_io();
+    if (rc) return rc;
+    const size_t n = (size_t)h->N * e.L * sizeof(float);
+    if (!n) return LCCRF_OK;
+    launch_step_init(e.crf, e.io_a, e.stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(e.stream));
+    HIP_TRY(hipMemcpy(next_out, e.io_a, n, hipMemcpyDeviceToHost));
+    return LCCRF_OK;
+}
+
+int lccrf_map_of(lccrf_handle h, const float *prob, int16_t *map_out)
+{
+    CHECK_H(h);
+    if ((!prob || !map_out) && h->N) return fail(LCCRF_E_INVALID, "prob / map_out is NULL");
+    Engine &e = h->eng;
+    int rc = e.resolve_late();
+    if (!rc) rc = e.need_io();
+    if (rc) return rc;
+    if (!h->N) return LCCRF_OK;
+    HIP_TRY(hipStreamSynchronize(e.stream));
+    HIP_TRY(hipMemcpy(e.io_a, prob, (size_t)h->N * e.L * sizeof(float), hipMemcpyHostToDevice));
+    launch_map_of(e.crf, e.io_a, e.io_map, e.stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(e.stream));
+    HIP_TRY(hipMemcpy(map_out, e.io_map, (size_t)h->N * sizeof(int16_t), hipMemcpyDeviceToHost));
+    return LCCRF_OK;
+}
+
+int lccrf_lattice_filter(int device_id, const float *features, int n_points, int d, const float *in, int value_size,
+                         float *out, int *n_vertices)
+{
+    if (n_points < 0) return fail(LCCRF_E_INVALID, "n_points < 0");
+    if ((!features || !in || !out) && n_points) return fail(LCCRF_E_INVALID, "features / in / out is NULL");
+    lccrf_handle h = nullptr;
+    int rc = lccrf_create(&h, device_id, n_points, value_size);        // value_size plays the part of the label count
+    if (rc) return rc;
+    rc = lccrf_add_pairwise(h, features, d, 1.0f);
+    Engine &e = h->eng;
+    if (!rc) rc = e.learn_sizes();
+    if (!rc) rc = e.need_io();
+    const size_t n = (size_t)n_points * value_size * sizeof(float);
+    hipError_t er = hipSuccess;
+    if (!rc && n) {
+        er = hipStreamSynchronize(e.stream);
+        if (er == hipSuccess) er = hipMemcpy(e.io_a, in, n, hipMemcpyHostToDevice);
+        if (er == hipSuccess) {
+            launch_filter(e.kdevs[0], e.crf, e.maxV[0], e.io_a, e.io_b, 0, e.stream);
+            er = hipStreamSynchronize(e.stream);
+        }
+        if (er == hipSuccess) er = hipMemcpy(out, e.io_b, n, hipMemcpyDeviceToHost);
+        if (er != hipSuccess) rc = fail(LCCRF_E_HIP, "lccrf_lattice_filter: %s", hipGetErrorString(er));
+    }
+    if (!rc && n_vertices) *n_vertices = e.V_host[0];
+    lccrf_destroy(h);
+    return rc;
+}
+
 int lccrf_get_map(lccrf_handle h, int16_t *map_out)
 {
     CHECK_H(h);
@@ -790,12 +921,6 @@ int lccrf_get_unary(lccrf_handle h, float *unary_out)
     { int ru = h->eng.ensure_unary(); if (ru) return ru; }
     return copy_out_f32(h, h->eng.crf.unary, unary_out, (size_t)h->N * h->eng.L);
 }
-
-#define CHECK_K(h, k)                                                                      \
-    do {                                                                                   \
-        if ((k) < 0 || (k) >= (int)(h)->eng.kernels.size())                                \
-            return fail(LCCRF_E_INVALID, "kernel index %d out of range", (k));             \
-    } while (0)
 
 int lccrf_get_lattice_size(lccrf_handle h, int kernel, int *n_vertices)
 {

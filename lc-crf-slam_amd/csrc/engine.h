@@ -25,9 +25,9 @@ struct KernelDev {
     int maxNpad;          // maxN rounded up to a multiple of 4 (phantom points, quirk Q1)
     int Epad;             // entries per frame = maxNpad * D1 (also the vertex capacity)
     int cap;              // hash capacity per frame (power of two >= 2*Epad)
-    int vstride;          // per-frame stride of val0/val1 = (Epad+1)*L of the owning CRF
-    int vbase;            // = L of the owning CRF: vertex v, label l of a width-W pass sits at
-                          //   vbase + v*W + l; [0,vbase) stays zero and serves as vertex -1
+    int vstride;          // per-frame stride of val0/val1 = (Epad+2)*L of the owning CRF
+    int vbase;            // = 2L of the owning CRF: vertex v, label l of a width-W pass sits at
+                          //   vbase + v*W + l; [0,vbase) stays zero and [vbase-W, vbase) serves as vertex -1
     float w;              // kernel weight (PottsPotential3D::w_)
     float alpha;          // 1/(1+2^-d)                     permutohedral_cpu.h:681
     float inv_dp1;        // 1.0f/(d+1)                     permutohedral_cpu.h:249
@@ -82,6 +82,10 @@ void launch_start(const CrfDev &c, hipStream_t s);
 void launch_step_stream(const CrfDev &c, const KernelDev *kds, const int *maxV, float relax,
                         hipStream_t s);
 void launch_map(const CrfDev &c, hipStream_t s);
+void launch_map_of(const CrfDev &c, const float *prob, int16_t *map, hipStream_t s);
+void launch_exp_and_normalize(const CrfDev &c, const float *in, float *out, float scale, float relax, hipStream_t s);
+void launch_step_init(const CrfDev &c, float *out, hipStream_t s);
+void launch_filter(const KernelDev &kd, const CrfDev &c, int maxV, const float *in, float *out, int accumulate, hipStream_t s);
 hipError_t time_blur_pass(const KernelDev &kd, int F, int maxV, int L, int reps, hipStream_t s, float *ms_per_launch);
 // out[f] = clamp(in[f], 0, maxN); *bad (pinned host memory) is set to 1 if anything had to be clamped
 void launch_validate_npoints(const int *in, int *out, int F, int maxN, int *bad, hipStream_t s);

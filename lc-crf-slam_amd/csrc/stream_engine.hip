@@ -416,7 +416,7 @@ __global__ void __launch_bounds__(kBlock) k_blur(KernelDev kd, const float *__re
     dst[fv + kd.vbase + (long)v * L + l] = o[(long)v * L + l] + 0.5f * (a + c);
 }
 
-enum SliceMode { SLICE_NORM = 0, SLICE_APPLY_FIRST = 1, SLICE_APPLY = 2 };
+enum SliceMode { SLICE_NORM = 0, SLICE_APPLY_FIRST = 1, SLICE_APPLY = 2, SLICE_PLAIN = 3 };
 
 // slice (+ what the caller does with it).  ref: :684-694, pairwise3d.h:25-27,73-78,
 // densecrf3d.h:154-158.
@@ -438,6 +438,8 @@ __global__ void __launch_bounds__(kBlock) k_slice(KernelDev kd, CrfDev c, const 
     }
     if (mode == SLICE_NORM) {
         kd.norm[(size_t)f * kd.maxN + i] = 1.0f / (t + 1e-20f);
+    } else if (mode == SLICE_PLAIN) {                      // the bare filter: out = compute(in), permutohedral_cpu.h:634-699
+        c.next[((size_t)f * c.maxN + i) * L + l] = t;
     } else {
         const size_t q = ((size_t)f * c.maxN + i) * L + l;
         const float base = (mode == SLICE_APPLY_FIRST) ? -c.unary[q] : c.next[q];
@@ -465,17 +467,29 @@ __global__ void __launch_bounds__(kBlock) k_splat2(KernelDev kd, const float2 *_
     reinterpret_cast<float2 *>(kd.val0 + (size_t)f * kd.vstride + kd.vbase)[v] = make_float2(a0, a1);
 }
 
+// Two vertices per thread: the neighbour pairs (int4), the centres (float4) and the results (float4) move as 16-byte
+// accesses (the frame's value array is laid out so that vertex 2t is 16-byte aligned, see Engine::add_kernel).
 __global__ void __launch_bounds__(kBlock) k_blur2(KernelDev kd, const float *__restrict__ src,
                                                   float *__restrict__ dst, int j)
 {
     const int f = blockIdx.y;
-    const int v = blockIdx.x * kBlock + threadIdx.x;
-    if (v >= kd.V[f]) return;
-    const int2 nb = reinterpret_cast<const int2 *>(kd.nbr)[((size_t)f * kd.D1 + j) * kd.Epad + v];
+    const int V = kd.V[f];
+    const int v = 2 * (blockIdx.x * kBlock + threadIdx.x);
+    if (v >= V) return;
     const float2 *o = reinterpret_cast<const float2 *>(src + (size_t)f * kd.vstride + kd.vbase);   // o[-1] = absent
-    const float2 c = o[v], x = o[nb.x], y = o[nb.y];
-    reinterpret_cast<float2 *>(dst + (size_t)f * kd.vstride + kd.vbase)[v] =
-        make_float2(c.x + 0.5f * (x.x + y.x), c.y + 0.5f * (x.y + y.y));
+    float2 *d = reinterpret_cast<float2 *>(dst + (size_t)f * kd.vstride + kd.vbase);
+    const int *nbp = kd.nbr + (((size_t)f * kd.D1 + j) * kd.Epad + v) * 2;
+    if (v + 1 < V) {
+        const int4 nb = *reinterpret_cast<const int4 *>(nbp);
+        const float4 c = *reinterpret_cast<const float4 *>(o + v);
+        const float2 x0 = o[nb.x], y0 = o[nb.y], x1 = o[nb.z], y1 = o[nb.w];
+        *reinterpret_cast<float4 *>(d + v) = make_float4(c.x + 0.5f * (x0.x + y0.x), c.y + 0.5f * (x0.y + y0.y),
+                                                         c.z + 0.5f * (x1.x + y1.x), c.w + 0.5f * (x1.y + y1.y));
+    } else {
+        const int2 nb = *reinterpret_cast<const int2 *>(nbp);
+        const float2 c = o[v], x = o[nb.x], y = o[nb.y];
+        d[v] = make_float2(c.x + 0.5f * (x.x + y.x), c.y + 0.5f * (x.y + y.y));
+    }
 }
 
 // slice + apply for L = 2; the LAST kernel of the step also does the softmax (saves a pass over next).
@@ -543,18 +557,28 @@ __global__ void __launch_bounds__(kBlock) k_softmax(CrfDev c, const float *__res
     exp_and_normalize_row(in + q, out + q, c.L, scale, relax);
 }
 
-__global__ void __launch_bounds__(kBlock) k_map(CrfDev c)
+// next = -unary (DenseCRF3D::stepInit, densecrf3d.h:154-158) into an arbitrary buffer
+__global__ void __launch_bounds__(kBlock) k_step_init(CrfDev c, float *__restrict__ out)
+{
+    const int f = blockIdx.y;
+    const int idx = blockIdx.x * kBlock + threadIdx.x;
+    if (idx >= c.n_points[f] * c.L) return;
+    const size_t q = (size_t)f * c.maxN * c.L + idx;
+    out[q] = -c.unary[q];
+}
+
+__global__ void __launch_bounds__(kBlock) k_map(CrfDev c, const float *__restrict__ Q, int16_t *__restrict__ map)
 {
     const int f = blockIdx.y;
     const int i = blockIdx.x * kBlock + threadIdx.x;
     const int N = c.n_points[f];
     int lab = 0;
     if (i < N) {
-        const float *p = c.Q + ((size_t)f * c.maxN + i) * c.L;
+        const float *p = Q + ((size_t)f * c.maxN + i) * c.L;
         lab = argmax_row(p, c.L);
-        c.map[(size_t)f * c.maxN + i] = (int16_t)lab;
+        map[(size_t)f * c.maxN + i] = (int16_t)lab;
     }
-    if (c.map_bits && c.L == 2 && (i & ~63) < N) {           // one bit per label: the label gather's wire format
+    if (c.map_bits && map == c.map && c.L == 2 && (i & ~63) < N) {           // one bit per label: the label gather's wire format
         const unsigned long long m = __ballot(lab == 1);
         if ((threadIdx.x & 63) == 0) c.map_bits[(size_t)f * c.bits_stride + (i >> 6)] = m;
     }
@@ -658,7 +682,7 @@ void launch_step_stream(const CrfDev &c, const KernelDev *kds, const int *maxV, 
             const float *src = kd.val0;
             float *dst = kd.val1;
             for (int j = 0; j < kd.D1; ++j) {
-                k_blur2<<<grid_for(maxV[k], c.F), kBlock, 0, s>>>(kd, src, dst, j);
+                k_blur2<<<grid_for((maxV[k] + 1) / 2, c.F), kBlock, 0, s>>>(kd, src, dst, j);
                 const float *t = src;
                 src = dst;
                 dst = const_cast<float *>(t);
@@ -701,7 +725,7 @@ hipError_t time_blur_pass(const KernelDev &kd, int F, int maxV, int L, int reps,
     auto pass = [&](int i) {
         const float *src = (i & 1) ? kd.val1 : kd.val0;
         float *dst = (i & 1) ? kd.val0 : kd.val1;
-        if (L == 2) k_blur2<<<grid_for(maxV, F), kBlock, 0, s>>>(kd, src, dst, i % kd.D1);
+        if (L == 2) k_blur2<<<grid_for((maxV + 1) / 2, F), kBlock, 0, s>>>(kd, src, dst, i % kd.D1);
         else k_blur<<<grid_for((long)maxV * L, F), kBlock, 0, s>>>(kd, src, dst, i % kd.D1, L);
     };
     for (int i = 0; i < 3; ++i) pass(i);
@@ -723,7 +747,36 @@ void launch_validate_npoints(const int *in, int *out, int F, int maxN, int *bad,
 
 void launch_map(const CrfDev &c, hipStream_t s)
 {
-    k_map<<<grid_for(c.maxN, c.F), kBlock, 0, s>>>(c);
+    k_map<<<grid_for(c.maxN, c.F), kBlock, 0, s>>>(c, c.Q, c.map);
+}
+
+// ---- the protected virtuals of DenseCRF / the pure virtual of PairwisePotential on caller-chosen device buffers ------
+void launch_map_of(const CrfDev &c, const float *prob, int16_t *map, hipStream_t s)
+{
+    k_map<<<grid_for(c.maxN, c.F), kBlock, 0, s>>>(c, prob, map);
+}
+
+void launch_exp_and_normalize(const CrfDev &c, const float *in, float *out, float scale, float relax, hipStream_t s)
+{
+    k_softmax<<<grid_for(c.maxN, c.F), kBlock, 0, s>>>(c, in, out, scale, relax);
+}
+
+void launch_step_init(const CrfDev &c, float *out, hipStream_t s)
+{
+    k_step_init<<<grid_for((long)c.maxN * c.L, c.F), kBlock, 0, s>>>(c, out);
+}
+
+// out (+)= [w * norm *] compute(in) with value width c.L: PairwisePotential::apply (accumulate = 1, pairwise3d.h:73-78)
+// or the bare PermutohedralLatticeCPU::compute (accumulate = 0, permutohedral_cpu.h:634-699)
+void launch_filter(const KernelDev &kd, const CrfDev &c, int maxV, const float *in, float *out, int accumulate, hipStream_t s)
+{
+    const int L = c.L;
+    k_splat<<<grid_for((long)maxV * L, c.F), kBlock, 0, s>>>(kd, in, c.maxN * L, L);
+    const float *res;
+    filter_passes(kd, c.F, maxV, L, s, &res);
+    CrfDev c2 = c;
+    c2.next = out;
+    k_slice<<<grid_for((long)c.maxN * L, c.F), kBlock, 0, s>>>(kd, c2, res, L, accumulate ? SLICE_APPLY : SLICE_PLAIN);
 }
 
 }  // namespace lccrf

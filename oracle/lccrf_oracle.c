@@ -474,6 +474,19 @@ void orc_crf_step_inference(orc_crf *c, float relax)   /* ref: densecrf_base.h:8
     orc_exp_and_normalize(c->current, c->next, c->N, c->L, 1.0f, relax);
 }
 
+/* PairwisePotential::apply, ref: densecrf_base.h:18, pairwise3d.h:73-78: out += w * norm * compute(in) */
+void orc_pairwise_apply(const orc_crf *c, int k, float *out, const float *in)
+{
+    const orc_pairwise *p = c->pw[k];
+    float *tmp = (float *)malloc(sizeof(float) * ((size_t)c->N * c->L + 1));
+    orc_lattice_compute(&p->lat, tmp, in, c->L);
+    size_t t = 0;
+    for (int i = 0; i < c->N; i++)
+        for (int j = 0; j < c->L; j++, t++)
+            out[t] += p->w * p->norm[i] * tmp[t];
+    free(tmp);
+}
+
 void orc_crf_build_map(orc_crf *c)        /* ref: densecrf3d.h:136-151 */
 {
     if (!c->map) c->map = (int16_t *)malloc(sizeof(int16_t) * (size_t)(c->N + 1));

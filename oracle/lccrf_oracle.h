@@ -76,6 +76,7 @@ int  orc_crf_add_pairwise(orc_crf *crf, const float *features, int d, float w);
 void orc_crf_start_inference(orc_crf *crf);
 void orc_crf_step_inference(orc_crf *crf, float relax);
 void orc_crf_build_map(orc_crf *crf);
+void orc_pairwise_apply(const orc_crf *crf, int k, float *out /* [N*L], accumulated into */, const float *in /* [N*L] */);
 void orc_crf_inference(orc_crf *crf, int n_iter, int with_map, float relax);
 
 float orc_fast_exp(float x);

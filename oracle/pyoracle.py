@@ -80,7 +80,9 @@ def oracle_lib():
         lib.orc_crf_start_inference.argtypes = [C.POINTER(_Crf)]
         lib.orc_crf_step_inference.argtypes = [C.POINTER(_Crf), C.c_float]
         lib.orc_crf_build_map.argtypes = [C.POINTER(_Crf)]
+        lib.orc_pairwise_apply.argtypes = [C.POINTER(_Crf), C.c_int, _f32p, _f32p]
         lib.orc_crf_inference.argtypes = [C.POINTER(_Crf), C.c_int, C.c_int, C.c_float]
+        lib.orc_exp_and_normalize.argtypes = [_f32p, _f32p, C.c_int, C.c_int, C.c_float, C.c_float]
         lib.orc_fast_exp.restype = C.c_float
         lib.orc_fast_exp.argtypes = [C.c_float]
         lib.orc_lattice_init.argtypes = [C.POINTER(_Lattice), _f32p, C.c_int, C.c_int]
@@ -122,6 +124,7 @@ def ref_lib():
         lib.ref_crf_step_inference.argtypes = [C.c_void_p, C.c_float]
         lib.ref_crf_inference.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float]
         lib.ref_crf_build_map.argtypes = [C.c_void_p]
+        lib.ref_kernel_apply.argtypes = [C.c_void_p, C.c_int, _f32p, _f32p]
         lib.ref_crf_probability.restype = _f32p
         lib.ref_crf_probability.argtypes = [C.c_void_p]
         lib.ref_crf_map.restype = _i16p
@@ -205,6 +208,13 @@ class OracleCRF(_CrfBase):
     def inference_native(self, n_iter, with_map=True, relax=1.0):
         self.lib.orc_crf_inference(self.h, int(n_iter), int(with_map), float(relax))
 
+    def apply(self, k, out, x):
+        """PairwisePotential::apply of kernel k: returns out + w * norm * compute(x)."""
+        o = _f32(out).reshape(self.N, self.L).copy()
+        xin = _f32(x).reshape(self.N, self.L)
+        self.lib.orc_pairwise_apply(self.h, int(k), _ptr(o, _f32p), _ptr(xin, _f32p))
+        return o
+
     def probability(self):
         return np.ctypeslib.as_array(self.h.contents.current, (self.N * self.L,)).reshape(
             self.N, self.L).copy()
@@ -266,6 +276,12 @@ class RefCRF(_CrfBase):
         if rc:
             raise ValueError("reference shim instantiates d in 1..6 only")
         self._d.append(f.shape[1])
+
+    def apply(self, k, out, x):
+        o = _f32(out).reshape(self.N, self.L).copy()
+        xin = _f32(x).reshape(self.N, self.L)
+        self.lib.ref_kernel_apply(self.h, int(k), _ptr(o, _f32p), _ptr(xin, _f32p))
+        return o
 
     def start_inference(self):
         self.lib.ref_crf_start_inference(self.h)

@@ -58,6 +58,7 @@ struct PotProbe : DenseCRF::PottsPotentialCPU<M, F> {
 };
 
 struct KernelView {
+    const DenseCRF::PairwisePotential *pot;   /* owned by the CRF (densecrf_base.h:54) */
     int d, V;
     const float *norm;
     const int *offset;
@@ -91,6 +92,7 @@ int add_kernel(Handle *h, const float *feat, float w)
 {
     auto *p = new PotProbe<M, F>(feat, h->N, w);
     KernelView kv;
+    kv.pot = p;
     kv.d = F;
     kv.V = LatProbe::V(p->lat());
     kv.norm = p->norm();
@@ -187,6 +189,14 @@ const float *ref_kernel_norm(void *hv, int k) { return static_cast<Handle *>(hv)
 const int *ref_kernel_offset(void *hv, int k) { return static_cast<Handle *>(hv)->kernels[k].offset; }
 const float *ref_kernel_bary(void *hv, int k) { return static_cast<Handle *>(hv)->kernels[k].bary; }
 const int *ref_kernel_nbr(void *hv, int k) { return static_cast<Handle *>(hv)->kernels[k].nbr; }
+
+/* PairwisePotential::apply (densecrf_base.h:18, pairwise_cpu.h:53-57 == pairwise3d.h:73-78): out += w * norm * compute(in) */
+void ref_kernel_apply(void *hv, int k, float *out, const float *in)
+{
+    Handle *h = static_cast<Handle *>(hv);
+    std::vector<float> tmp((size_t)h->N * h->L + 16);
+    h->kernels[k].pot->apply(out, in, tmp.data());
+}
 
 /* bare lattice filter: out = compute(in) for one feature set (permutohedral_cpu.h:241,634) */
 int ref_lattice_filter(const float *feat, int d, int N, const float *in, float *out, int value_size)
