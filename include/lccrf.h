@@ -259,6 +259,35 @@ int  lccrf_bf_match(int device_id, int n_query, const uint8_t *desc_query, int n
                     const uint8_t *desc_train, double ratio, int32_t *train_of_query_out,
                     int32_t *n_matches_out);
 
+/* ======================================================================================
+ * 5. Pose optimisation -- the step right after the CRF
+ *
+ * Optimizer::PoseOptimization (src/Optimizer.cc:239-450, called at src/Tracking.cc:1002): motion-only bundle
+ * adjustment of the frame pose on the matches the CRF left standing -- g2o Levenberg-Marquardt on one SE3 vertex,
+ * pose-only reprojection edges (monocular where u_right < 0, stereo otherwise), Huber kernel, 4 rounds of 10
+ * iterations from the same initial pose with chi2 re-classification (5.991 / 7.815) in between.  PARITY UNPINNED:
+ * g2o needs Eigen (absent here) and the reference holds no fixture for it; csrc/pose_opt.hip states what is and is
+ * not reproduced.  Double precision on the device, one workgroup per frame.
+ *   Xw [n][3]         MapPoint::GetWorldPos()              kp [n][2]   mvKeysUn[i].pt
+ *   u_right [n]       mvuRight[i] (< 0: monocular edge)    inv_sigma2 [n]  mvInvLevelSigma2[kpUn.octave]
+ *   valid [n]         mvpMapPoints[i] != NULL, or NULL for "all"
+ *   label [n]         CRF labels, or NULL: a point labelled 0 (moving) has been nulled by
+ *                     Tracking::DynamicDetectionWithCRF (Tracking.cc:1945-1955) and contributes no edge
+ *   K4                fx fy cx cy;  bf = mbf;  Tcw row-major 4x4 float (pFrame->mTcw in, SetPose out)
+ *   outlier_out [n]   mvbOutlier (entries of points without an edge are left as they were)
+ *   n_inliers_out     the return value nInitialCorrespondences - nBad (0 with < 3 correspondences: pose untouched)  */
+int  lccrf_pose_optimization(int device_id, int n_points, const float *Xw, const float *kp, const float *u_right,
+                             const float *inv_sigma2, const uint8_t *valid, const int16_t *label, const float *K4,
+                             float bf, const float *Tcw_in, float *Tcw_out, uint8_t *outlier_out,
+                             int32_t *n_inliers_out);
+/* The same for every frame of a batch, on DEVICE arrays strided by the batch's max_points ([F][max_points][..],
+ * Tcw [F][16], counts [F]), with the labels of the batch's last inference read where the kernel left them: the
+ * labels never visit the host between the CRF and the pose.  Asynchronous on `stream` (NULL: the batch's own).   */
+int  lccrf_batch_pose_optimization(lccrf_batch_handle b, const float *d_Xw, const float *d_kp, const float *d_u_right,
+                                   const float *d_inv_sigma2, const uint8_t *d_valid, const float *K4, float bf,
+                                   const float *d_Tcw_in, float *d_Tcw_out, uint8_t *d_outlier,
+                                   int32_t *d_n_inliers, int32_t *d_n_initial, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

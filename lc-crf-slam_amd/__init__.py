@@ -118,6 +118,9 @@ def lib():
     L.lccrf_batch_last_timing.argtypes = [vp, _f32p, _f32p]
     L.lccrf_batch_time_blur_pass.argtypes = [vp, C.c_int, C.c_int, _f32p, C.POINTER(C.c_int64)]
     L.lccrf_bf_match.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_double, _i32p, _i32p]
+    L.lccrf_pose_optimization.argtypes = [C.c_int, C.c_int, _f32p, _f32p, _f32p, _f32p, C.c_void_p, _i16p, _f32p, C.c_float,
+                                          _f32p, _f32p, C.c_void_p, _i32p]
+    L.lccrf_batch_pose_optimization.argtypes = [vp, vp, vp, vp, vp, vp, _f32p, C.c_float, vp, vp, vp, vp, vp, vp]
     L.lccrf_default_params.argtypes = [C.POINTER(CrfParams)]
     L.lccrf_default_params.restype = None
     L.lccrf_unary_build.argtypes = [C.c_int, C.c_int, _f32p, _i32p, _i32p, C.POINTER(C.c_double), C.c_int, _f32p,
@@ -386,6 +389,15 @@ class BatchCRF:
         _check(lib().lccrf_batch_time_blur_pass(self.h, int(kernel), int(reps), C.byref(ms), C.byref(nv)))
         return ms.value, nv.value
 
+    def pose_optimization(self, d_Xw, d_kp, d_u_right, d_inv_sigma2, K4, bf, d_Tcw_in, d_Tcw_out, d_outlier, d_n_inliers,
+                          d_n_initial, d_valid=None, stream=None):
+        """lccrf_batch_pose_optimization: raw device addresses; consumes the labels of the last inference on the device."""
+        K = _f32(K4)
+        v = lambda p: C.c_void_p(int(p)) if p is not None else None
+        _check(lib().lccrf_batch_pose_optimization(self.h, v(d_Xw), v(d_kp), v(d_u_right), v(d_inv_sigma2), v(d_valid), _p(K, _f32p),
+                                                   float(bf), v(d_Tcw_in), v(d_Tcw_out), v(d_outlier), v(d_n_inliers),
+                                                   v(d_n_initial), C.c_void_p(stream) if stream else None))
+
     def last_timing(self):
         a, b = C.c_float(0), C.c_float(0)
         _check(lib().lccrf_batch_last_timing(self.h, C.byref(a), C.byref(b)))
@@ -402,6 +414,22 @@ def lattice_filter(features, x, device=0):
     V = C.c_int(0)
     _check(lib().lccrf_lattice_filter(int(device), _p(f, _f32p), N, d, _p(xin, _f32p), xin.shape[1], _p(out, _f32p), C.byref(V)))
     return out, V.value
+
+
+def pose_optimization(Xw, kp, u_right, inv_sigma2, K4, bf, Tcw, valid=None, label=None, device=0):
+    """Optimizer::PoseOptimization on the GPU (lccrf_pose_optimization): (Tcw_out [4,4], outlier u8[n], n_inliers)."""
+    Xw, kp = _f32(Xw).reshape(-1, 3), _f32(kp).reshape(-1, 2)
+    n = Xw.shape[0]
+    ur, is2, K, T = _f32(u_right), _f32(inv_sigma2), _f32(K4), _f32(Tcw).reshape(16)
+    va = None if valid is None else np.ascontiguousarray(valid, np.uint8)
+    la = None if label is None else np.ascontiguousarray(label, np.int16)
+    out = np.empty(16, np.float32)
+    outl = np.zeros(n, np.uint8)
+    ninl = np.zeros(1, np.int32)
+    _check(lib().lccrf_pose_optimization(int(device), n, _p(Xw, _f32p), _p(kp, _f32p), _p(ur, _f32p), _p(is2, _f32p),
+                                         va.ctypes.data if va is not None else None, _p(la, _i16p) if la is not None else None,
+                                         _p(K, _f32p), float(bf), _p(T, _f32p), _p(out, _f32p), outl.ctypes.data, _p(ninl, _i32p)))
+    return out.reshape(4, 4), outl, int(ninl[0])
 
 
 def default_params():

@@ -1333,6 +1333,75 @@ int lccrf_batch_time_blur_pass(lccrf_batch_handle b, int kernel, int reps, float
     return LCCRF_OK;
 }
 
+int lccrf_pose_optimization(int device_id, int n_points, const float *Xw, const float *kp, const float *u_right,
+                            const float *inv_sigma2, const uint8_t *valid, const int16_t *label, const float *K4, float bf,
+                            const float *Tcw_in, float *Tcw_out, uint8_t *outlier_out, int32_t *n_inliers_out)
+{
+    if (n_points < 0) return fail(LCCRF_E_INVALID, "n_points < 0");
+    if (n_points > 16384) return fail(LCCRF_E_CAPACITY, "at most 16384 keypoints per frame");
+    if (!K4 || !Tcw_in || !Tcw_out) return fail(LCCRF_E_INVALID, "K4 / Tcw is NULL");
+    if (n_points && (!Xw || !kp || !u_right || !inv_sigma2 || !outlier_out)) return fail(LCCRF_E_INVALID, "NULL array");
+    int rc = use_device(device_id);
+    if (rc) return rc;
+    const size_t n = (size_t)std::max(n_points, 1);
+    struct Bufs {                                         // one device arena per call: [Xw | kp | ur | is2 | Tin | Tout | label | valid | outlier | ints]
+        void *p = nullptr;
+        ~Bufs() { if (p) (void)hipFree(p); }
+    } bufs;
+    const size_t off_kp = n * 12, off_ur = off_kp + n * 8, off_is2 = off_ur + n * 4, off_tin = off_is2 + n * 4, off_tout = off_tin + 64,
+                 off_lab = off_tout + 64, off_val = off_lab + ((n * 2 + 15) & ~(size_t)15), off_out = off_val + ((n + 15) & ~(size_t)15),
+                 off_int = off_out + ((n + 15) & ~(size_t)15), total = off_int + 16;
+    HIP_TRY(hipMalloc(&bufs.p, total));
+    char *d = static_cast<char *>(bufs.p);
+    if (n_points) {
+        HIP_TRY(hipMemcpy(d, Xw, (size_t)n_points * 12, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(d + off_kp, kp, (size_t)n_points * 8, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(d + off_ur, u_right, (size_t)n_points * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(d + off_is2, inv_sigma2, (size_t)n_points * 4, hipMemcpyHostToDevice));
+        if (label) HIP_TRY(hipMemcpy(d + off_lab, label, (size_t)n_points * 2, hipMemcpyHostToDevice));
+        if (valid) HIP_TRY(hipMemcpy(d + off_val, valid, (size_t)n_points, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(d + off_out, outlier_out, (size_t)n_points, hipMemcpyHostToDevice));   // entries of invalid points pass through
+    }
+    HIP_TRY(hipMemcpy(d + off_tin, Tcw_in, 64, hipMemcpyHostToDevice));
+    int *ints = reinterpret_cast<int *>(d + off_int);     // n_points, n_inliers, n_initial
+    HIP_TRY(hipMemcpy(ints, &n_points, sizeof(int), hipMemcpyHostToDevice));
+    hipError_t er = launch_pose_optimization(1, (int)n, ints, reinterpret_cast<float *>(d), reinterpret_cast<float *>(d + off_kp),
+                                             reinterpret_cast<float *>(d + off_ur), reinterpret_cast<float *>(d + off_is2),
+                                             valid ? reinterpret_cast<uint8_t *>(d + off_val) : nullptr,
+                                             label ? reinterpret_cast<int16_t *>(d + off_lab) : nullptr, K4, bf,
+                                             reinterpret_cast<float *>(d + off_tin), reinterpret_cast<float *>(d + off_tout),
+                                             reinterpret_cast<uint8_t *>(d + off_out), ints + 1, ints + 2, nullptr);
+    if (er != hipSuccess) return fail(LCCRF_E_HIP, "pose optimisation: %s", hipGetErrorString(er));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(Tcw_out, d + off_tout, 64, hipMemcpyDeviceToHost));
+    if (n_points) HIP_TRY(hipMemcpy(outlier_out, d + off_out, (size_t)n_points, hipMemcpyDeviceToHost));
+    int res[3];
+    HIP_TRY(hipMemcpy(res, ints, sizeof(res), hipMemcpyDeviceToHost));
+    if (n_inliers_out) *n_inliers_out = res[1];
+    return LCCRF_OK;
+}
+
+int lccrf_batch_pose_optimization(lccrf_batch_handle b, const float *d_Xw, const float *d_kp, const float *d_u_right,
+                                  const float *d_inv_sigma2, const uint8_t *d_valid, const float *K4, float bf,
+                                  const float *d_Tcw_in, float *d_Tcw_out, uint8_t *d_outlier, int32_t *d_n_inliers,
+                                  int32_t *d_n_initial, void *stream)
+{
+    CHECK_H(b);
+    if (!d_Xw || !d_kp || !d_u_right || !d_inv_sigma2 || !K4 || !d_Tcw_in || !d_Tcw_out || !d_outlier || !d_n_inliers || !d_n_initial)
+        return fail(LCCRF_E_INVALID, "NULL array");
+    Engine &e = b->eng;
+    if (!e.started) return fail(LCCRF_E_STATE, "no inference has produced labels yet");
+    if (e.maxN > 16384) return fail(LCCRF_E_CAPACITY, "at most 16384 keypoints per frame");
+    StreamScope scope(e, stream);
+    int rc = scope.enter();
+    if (rc) return rc;
+    // the labels are read where the inference kernel wrote them: no host round trip between the CRF and the pose
+    hipError_t er = launch_pose_optimization(e.F, e.maxN, e.crf.n_points, d_Xw, d_kp, d_u_right, d_inv_sigma2, d_valid, e.crf.map, K4, bf,
+                                             d_Tcw_in, d_Tcw_out, d_outlier, d_n_inliers, d_n_initial, e.stream);
+    if (er != hipSuccess) return fail(LCCRF_E_HIP, "pose optimisation: %s", hipGetErrorString(er));
+    return LCCRF_OK;
+}
+
 int lccrf_batch_last_timing(lccrf_batch_handle b, float *inference_ms, float *build_ms)
 {
     CHECK_H(b);

@@ -118,4 +118,10 @@ hipError_t run_unary_build(int device_id, int n_points, const float *Xw, const i
 hipError_t run_bf_match(int device_id, int n_query, const uint8_t *desc_query, int n_train, const uint8_t *desc_train,
                         double ratio, int32_t *train_of_query_out, int32_t *n_matches_out);
 
+// ---- Optimizer::PoseOptimization (src/Optimizer.cc:239-450), csrc/pose_opt.hip; every pointer device-accessible ----
+hipError_t launch_pose_optimization(int F, int maxN, const int *n_points, const float *Xw, const float *kp, const float *ur,
+                                    const float *is2, const uint8_t *valid, const int16_t *label, const float *K4, float bf,
+                                    const float *Tcw_in, float *Tcw_out, uint8_t *outlier, int *n_inliers, int *n_initial,
+                                    hipStream_t s);
+
 }  // namespace lccrf

@@ -147,3 +147,40 @@ def map_point_scene(n_points, n_kf, seed, max_obs=12):
             obs_kp[obs_ptr[i] + j] = (u + noise[0], v + noise[1])
     return dict(Xw=Xw, obs_ptr=obs_ptr, obs_kf=obs_kf, obs_kp=obs_kp, kf_pose=poses.reshape(n_kf, 12),
                 kf_intr=intr, kf_bounds=bounds, dynamic=dyn)
+
+
+def pose_scene(n, seed, noise=0.7, outlier_frac=0.15, mono_frac=0.2, n_invalid=0):
+    """A synthetic frame for Optimizer::PoseOptimization (src/Optimizer.cc:239-450): map points in front of an RGB-D
+    camera (TUM fr3 intrinsics, bf = 40), keypoints at their projections under a true pose plus pixel noise, a fraction
+    of gross outliers (moving points the CRF missed), a fraction of monocular observations (no depth: u_right < 0),
+    octave-dependent information (1.2^-2k), and an initial pose a few centimetres / a degree off."""
+    rng = np.random.default_rng([int(seed), int(n), 77])
+    fx = fy = 535.4
+    cx, cy, bf = 320.1, 247.6, 40.0
+    a, b = 0.05, 0.03
+    Ry = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]])
+    Rx = np.array([[1, 0, 0], [0, np.cos(b), -np.sin(b)], [0, np.sin(b), np.cos(b)]])
+    R, t = Ry @ Rx, np.array([0.12, -0.05, 0.08])
+    Xw = np.stack([rng.uniform(-2, 2, n), rng.uniform(-1.5, 1.5, n), rng.uniform(1.0, 6.0, n)], 1).astype(np.float32)
+    pc = Xw.astype(np.float64) @ R.T + t
+    u, v = fx * pc[:, 0] / pc[:, 2] + cx, fy * pc[:, 1] / pc[:, 2] + cy
+    ur = u - bf / pc[:, 2]
+    kp = np.stack([u, v], 1) + rng.normal(0, noise, (n, 2)) if noise else np.stack([u, v], 1)
+    ur = ur + (rng.normal(0, noise, n) if noise else 0.0)
+    bad = rng.random(n) < outlier_frac
+    kp[bad] += rng.normal(0, 25, (int(bad.sum()), 2))
+    mono = rng.random(n) < mono_frac
+    ur = np.where(mono, -1.0, ur)
+    octave = rng.integers(0, 4, n)
+    T = np.eye(4)
+    T[:3, :3], T[:3, 3] = R, t
+    a0 = a + 0.02
+    T0 = np.eye(4)
+    T0[:3, :3] = np.array([[np.cos(a0), 0, np.sin(a0)], [0, 1, 0], [-np.sin(a0), 0, np.cos(a0)]])
+    T0[:3, 3] = t + np.array([0.03, -0.02, 0.04])
+    valid = np.ones(n, np.uint8)
+    if n_invalid:
+        valid[rng.choice(n, n_invalid, replace=False)] = 0
+    return dict(Xw=Xw, kp=kp.astype(np.float32), u_right=ur.astype(np.float32),
+                inv_sigma2=(1.0 / 1.2 ** (2 * octave)).astype(np.float32), valid=valid,
+                K4=np.array([fx, fy, cx, cy], np.float32), bf=np.float32(bf), T_true=T, T_init=T0.astype(np.float32), gross=bad)

@@ -12,6 +12,7 @@
 #include "lccrf_oracle.h"
 
 #include <limits.h>
+#include <float.h>
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -668,4 +669,307 @@ void orc_bf_match(int n_query, const uint8_t *desc_query, int n_train, const uin
         nm += m >= 0;
     }
     if (n_matches) *n_matches = nm;
+}
+
+/* ======================================================================== */
+/* Optimizer::PoseOptimization (src/Optimizer.cc:239-450): the step right    */
+/* after the CRF (src/Tracking.cc:1002).  PARITY UNPINNED: the reference     */
+/* runs it on g2o (Thirdparty/g2o, needs Eigen 3, absent in this image) and  */
+/* holds no test or fixture for it.  This restates, in double precision and  */
+/* operation by operation,                                                   */
+/*   - the two pose-only edges, types_six_dof_expmap.{h,cpp}:153-196,266-364 */
+/*     (the stereo projection's `const float invz = 1.0f/z` included),       */
+/*   - RobustKernelHuber, robust_kernel_impl.cpp:78-91, and the first-order  */
+/*     robustified quadratic form, base_unary_edge.hpp:43-72,                */
+/*   - OptimizationAlgorithmLevenberg::solve, optimization_algorithm_        */
+/*     levenberg.cpp:33-150 (tau 1e-5, gain ratio, 10 trials, Raul's stop),  */
+/*   - SE3Quat::exp / operator* / map, se3quat.h:104-110,214-256 with        */
+/*     Eigen's published quaternion <-> matrix conversions,                  */
+/*   - the 4 x 10 schedule with chi2 re-classification, Optimizer.cc:366-440.*/
+/* What is NOT reproduced bit for bit: Eigen's pivoted LDLT of the 6x6       */
+/* system (a plain LDL^T here).  Checked by known answers (Jacobians against */
+/* finite differences, exact recovery of a known pose) -- see tests.         */
+/* ======================================================================== */
+typedef struct { double w, x, y, z; } pq_t;
+
+static void pq_normalize(pq_t *q)                     /* se3quat.h:280-285 */
+{
+    if (q->w < 0) { q->w = -q->w; q->x = -q->x; q->y = -q->y; q->z = -q->z; }
+    const double n = sqrt(q->x * q->x + q->y * q->y + q->z * q->z + q->w * q->w);
+    q->w /= n; q->x /= n; q->y /= n; q->z /= n;
+}
+
+static pq_t pq_from_matrix(const double m[3][3])      /* Eigen::Quaterniond(Matrix3d) */
+{
+    pq_t q;
+    double t = m[0][0] + m[1][1] + m[2][2];
+    if (t > 0) {
+        t = sqrt(t + 1.0);
+        q.w = 0.5 * t;
+        t = 0.5 / t;
+        q.x = (m[2][1] - m[1][2]) * t;
+        q.y = (m[0][2] - m[2][0]) * t;
+        q.z = (m[1][0] - m[0][1]) * t;
+    } else {
+        int i = 0;
+        if (m[1][1] > m[0][0]) i = 1;
+        if (m[2][2] > m[i][i]) i = 2;
+        const int j = (i + 1) % 3, k = (j + 1) % 3;
+        double v[3];
+        t = sqrt(m[i][i] - m[j][j] - m[k][k] + 1.0);
+        v[i] = 0.5 * t;
+        t = 0.5 / t;
+        q.w = (m[k][j] - m[j][k]) * t;
+        v[j] = (m[j][i] + m[i][j]) * t;
+        v[k] = (m[k][i] + m[i][k]) * t;
+        q.x = v[0]; q.y = v[1]; q.z = v[2];
+    }
+    return q;
+}
+
+static void pq_rotate(const pq_t *q, const double v[3], double out[3])   /* Eigen quaternion * vector */
+{
+    double uv[3] = {q->y * v[2] - q->z * v[1], q->z * v[0] - q->x * v[2], q->x * v[1] - q->y * v[0]};
+    uv[0] += uv[0]; uv[1] += uv[1]; uv[2] += uv[2];
+    out[0] = v[0] + q->w * uv[0] + (q->y * uv[2] - q->z * uv[1]);
+    out[1] = v[1] + q->w * uv[1] + (q->z * uv[0] - q->x * uv[2]);
+    out[2] = v[2] + q->w * uv[2] + (q->x * uv[1] - q->y * uv[0]);
+}
+
+static pq_t pq_mul(const pq_t *a, const pq_t *b)      /* Eigen quaternion product */
+{
+    pq_t r;
+    r.w = a->w * b->w - a->x * b->x - a->y * b->y - a->z * b->z;
+    r.x = a->w * b->x + a->x * b->w + a->y * b->z - a->z * b->y;
+    r.y = a->w * b->y + a->y * b->w + a->z * b->x - a->x * b->z;
+    r.z = a->w * b->z + a->z * b->w + a->x * b->y - a->y * b->x;
+    return r;
+}
+
+/* estimate <- SE3Quat::exp(update) * estimate     (VertexSE3Expmap::oplusImpl, se3quat.h:214-256,104-110) */
+static void pose_oplus(const double upd[6], pq_t *q, double t[3])
+{
+    const double om[3] = {upd[0], upd[1], upd[2]}, up[3] = {upd[3], upd[4], upd[5]};
+    const double theta = sqrt(om[0] * om[0] + om[1] * om[1] + om[2] * om[2]);
+    const double O[3][3] = {{0, -om[2], om[1]}, {om[2], 0, -om[0]}, {-om[1], om[0], 0}};
+    double O2[3][3], R[3][3], V[3][3];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) O2[i][j] = O[i][0] * O[0][j] + O[i][1] * O[1][j] + O[i][2] * O[2][j];
+    if (theta < 0.00001) {
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) { R[i][j] = ((i == j) ? 1.0 : 0.0) + O[i][j] + O2[i][j]; V[i][j] = R[i][j]; }
+    } else {
+        const double a = sin(theta) / theta, b = (1 - cos(theta)) / (theta * theta), c = (theta - sin(theta)) / pow(theta, 3);
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) {
+                const double I = (i == j) ? 1.0 : 0.0;
+                R[i][j] = I + a * O[i][j] + b * O2[i][j];
+                V[i][j] = I + b * O[i][j] + c * O2[i][j];
+            }
+    }
+    pq_t dq = pq_from_matrix(R);
+    pq_normalize(&dq);
+    const double dt[3] = {V[0][0] * up[0] + V[0][1] * up[1] + V[0][2] * up[2], V[1][0] * up[0] + V[1][1] * up[1] + V[1][2] * up[2],
+                          V[2][0] * up[0] + V[2][1] * up[1] + V[2][2] * up[2]};
+    double rt[3];
+    pq_rotate(&dq, t, rt);
+    t[0] = dt[0] + rt[0]; t[1] = dt[1] + rt[1]; t[2] = dt[2] + rt[2];
+    *q = pq_mul(&dq, q);
+    pq_normalize(q);
+}
+
+typedef struct {
+    int n;
+    const float *Xw, *kp, *ur, *is2;
+    double fx, fy, cx, cy, bf;
+} pose_prob;
+
+/* _error of edge i at pose (q,t) and chi2 = e^T (invSigma2 I) e; types_six_dof_expmap.h:153-157,184-188 */
+static double pose_edge_error(const pose_prob *p, int i, const pq_t *q, const double t[3], double e[3], double pc[3])
+{
+    const double X[3] = {p->Xw[3 * i], p->Xw[3 * i + 1], p->Xw[3 * i + 2]};
+    pq_rotate(q, X, pc);
+    pc[0] += t[0]; pc[1] += t[1]; pc[2] += t[2];
+    const double w = p->is2[i];
+    if (p->ur[i] < 0) {                                   /* mono: project2d in double, cpp:290-296 */
+        e[0] = (double)p->kp[2 * i] - ((pc[0] / pc[2]) * p->fx + p->cx);
+        e[1] = (double)p->kp[2 * i + 1] - ((pc[1] / pc[2]) * p->fy + p->cy);
+        e[2] = 0.0;
+        return e[0] * (w * e[0]) + e[1] * (w * e[1]);
+    }
+    const float invz = 1.0f / (float)pc[2];              /* cpp:299-306: `const float invz = 1.0f/trans_xyz[2]` */
+    const double u = pc[0] * invz * p->fx + p->cx;
+    e[0] = (double)p->kp[2 * i] - u;
+    e[1] = (double)p->kp[2 * i + 1] - (pc[1] * invz * p->fy + p->cy);
+    e[2] = (double)p->ur[i] - (u - p->bf * invz);
+    return e[0] * (w * e[0]) + e[1] * (w * e[1]) + e[2] * (w * e[2]);
+}
+
+static void huber(double e, double delta, double rho[3])   /* robust_kernel_impl.cpp:78-91 */
+{
+    const double dsqr = delta * delta;
+    if (e <= dsqr) { rho[0] = e; rho[1] = 1.; rho[2] = 0.; }
+    else { const double s = sqrt(e); rho[0] = 2 * s * delta - dsqr; rho[1] = delta / s; rho[2] = -0.5 * rho[1] / e; }
+}
+
+/* Jacobian rows of edge i at camera-frame point pc; cpp:266-288,335-364 */
+static int pose_edge_jacobian(const pose_prob *p, int i, const double pc[3], double J[3][6])
+{
+    const double x = pc[0], y = pc[1], invz = 1.0 / pc[2], invz_2 = invz * invz;
+    J[0][0] = x * y * invz_2 * p->fx;          J[0][1] = -(1 + (x * x * invz_2)) * p->fx; J[0][2] = y * invz * p->fx;
+    J[0][3] = -invz * p->fx;                   J[0][4] = 0;                               J[0][5] = x * invz_2 * p->fx;
+    J[1][0] = (1 + y * y * invz_2) * p->fy;    J[1][1] = -x * y * invz_2 * p->fy;         J[1][2] = -x * invz * p->fy;
+    J[1][3] = 0;                               J[1][4] = -invz * p->fy;                   J[1][5] = y * invz_2 * p->fy;
+    if (p->ur[i] < 0) return 2;
+    J[2][0] = J[0][0] - p->bf * y * invz_2;    J[2][1] = J[0][1] + p->bf * x * invz_2;    J[2][2] = J[0][2];
+    J[2][3] = J[0][3];                         J[2][4] = 0;                               J[2][5] = J[0][5] - p->bf * invz_2;
+    return 3;
+}
+
+/* solve (H + lambda I) x = b for a symmetric 6x6 H by LDL^T; 0 if not positive definite */
+static int solve6(const double H[6][6], double lambda, const double b[6], double x[6])
+{
+    double L[6][6], D[6];
+    for (int j = 0; j < 6; j++) {
+        double d = H[j][j] + lambda;
+        for (int k = 0; k < j; k++) d -= L[j][k] * L[j][k] * D[k];
+        if (!(d > 0)) return 0;
+        D[j] = d;
+        for (int i = j + 1; i < 6; i++) {
+            double s = H[i][j];
+            for (int k = 0; k < j; k++) s -= L[i][k] * L[j][k] * D[k];
+            L[i][j] = s / d;
+        }
+    }
+    double y[6];
+    for (int i = 0; i < 6; i++) { double s = b[i]; for (int k = 0; k < i; k++) s -= L[i][k] * y[k]; y[i] = s; }
+    for (int i = 5; i >= 0; i--) { double s = y[i] / D[i]; for (int k = i + 1; k < 6; k++) s -= L[k][i] * x[k]; x[i] = s; }
+    return 1;
+}
+
+/* computeActiveErrors + activeRobustChi2 (sparse_optimizer.cpp:61-114); edge_chi2[i] keeps what e->chi2() would return */
+static double pose_active_chi2(const pose_prob *p, const uint8_t *level1, const uint8_t *valid, int robust, double dMono,
+                               double dStereo, const pq_t *q, const double t[3], double *edge_chi2)
+{
+    double chi = 0.0, e[3], pc[3], rho[3];
+    for (int i = 0; i < p->n; i++) {
+        if (!valid[i] || level1[i]) continue;
+        const double c = pose_edge_error(p, i, q, t, e, pc);
+        edge_chi2[i] = c;
+        if (robust) { huber(c, p->ur[i] < 0 ? dMono : dStereo, rho); chi += rho[0]; }
+        else chi += c;
+    }
+    return chi;
+}
+
+int orc_pose_optimization(int n, const float *Xw, const float *kp, const float *u_right, const float *inv_sigma2,
+                          const uint8_t *valid, const float *K4, float bf, const float *Tcw_in, float *Tcw_out,
+                          uint8_t *outlier, int *n_initial)
+{
+    pose_prob P = {n, Xw, kp, u_right, inv_sigma2, K4[0], K4[1], K4[2], K4[3], bf};
+    int n_init = 0;
+    uint8_t *level1 = (uint8_t *)calloc((size_t)n + 1, 1);
+    double *edge_chi2 = (double *)calloc((size_t)n + 1, sizeof(double));   /* chi2 of every edge's stored _error */
+    for (int i = 0; i < n; i++) {
+        if (valid[i]) { n_init++; outlier[i] = 0; }     /* Optimizer.cc:283-284 */
+    }
+    if (n_initial) *n_initial = n_init;
+    memcpy(Tcw_out, Tcw_in, 16 * sizeof(float));
+    if (n_init < 3) { free(level1); free(edge_chi2); return 0; }          /* Optimizer.cc:361-362 */
+    double R0[3][3], t0[3];
+    for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) R0[i][j] = Tcw_in[4 * i + j]; t0[i] = Tcw_in[4 * i + 3]; }
+    pq_t q0 = pq_from_matrix(R0);                         /* Converter::toSE3Quat, Converter.cc:37-47 */
+    pq_normalize(&q0);
+    /* deltaMono / deltaStereo are `const float sqrt(5.991)` / `sqrt(7.815)` (Optimizer.cc:274-275) */
+    const double dMono = (double)(float)sqrt(5.991), dStereo = (double)(float)sqrt(7.815);
+    const float chi2Mono = 5.991f, chi2Stereo = 7.815f;
+    pq_t q = q0;
+    double t[3] = {t0[0], t0[1], t0[2]};
+    int nBad = 0;
+    for (int it = 0; it < 4; it++) {
+        const int robust = it < 3;                        /* the kernel is dropped after the third round, :406-407 */
+        q = q0; t[0] = t0[0]; t[1] = t0[1]; t[2] = t0[2]; /* vSE3->setEstimate(toSE3Quat(pFrame->mTcw)), :374 */
+        double lambda = 0, ni = 2;
+        int nBadLM = 0;
+        for (int iter = 0; iter < 10; iter++) {           /* optimizer.optimize(10) */
+            double H[6][6] = {{0}}, b[6] = {0}, currentChi = 0;
+            for (int i = 0; i < n; i++) {
+                if (!valid[i] || level1[i]) continue;
+                double e[3], pc[3], J[3][6], rho[3] = {0, 1, 0};
+                const double c = pose_edge_error(&P, i, &q, t, e, pc);
+                edge_chi2[i] = c;
+                if (robust) { huber(c, u_right[i] < 0 ? dMono : dStereo, rho); currentChi += rho[0]; }
+                else currentChi += c;
+                const int D = pose_edge_jacobian(&P, i, pc, J);
+                const double w = inv_sigma2[i];
+                for (int a = 0; a < 6; a++) {
+                    double s = 0;
+                    for (int r = 0; r < D; r++) s += J[r][a] * (w * e[r]);
+                    b[a] -= rho[1] * s;                   /* base_unary_edge.hpp:62 */
+                    for (int c2 = 0; c2 < 6; c2++) {
+                        double h = 0;
+                        for (int r = 0; r < D; r++) h += J[r][a] * ((rho[1] * w) * J[r][c2]);
+                        H[a][c2] += h;                    /* :63 */
+                    }
+                }
+            }
+            const double iniChi = currentChi;
+            if (iter == 0) {                              /* computeLambdaInit, levenberg.cpp:153-166 */
+                double mx = 0;
+                for (int j = 0; j < 6; j++) mx = fmax(fabs(H[j][j]), mx);
+                lambda = 1e-5 * mx; ni = 2; nBadLM = 0;
+            }
+            double rho_gain = 0;
+            int qmax = 0;
+            do {
+                pq_t qb = q;
+                double tb[3] = {t[0], t[1], t[2]}, x[6] = {0, 0, 0, 0, 0, 0};
+                const int ok2 = solve6(H, lambda, b, x);
+                pose_oplus(x, &q, t);
+                double tempChi = pose_active_chi2(&P, level1, valid, robust, dMono, dStereo, &q, t, edge_chi2);
+                if (!ok2) tempChi = DBL_MAX;
+                rho_gain = currentChi - tempChi;
+                double scale = 0;
+                for (int j = 0; j < 6; j++) scale += x[j] * (lambda * x[j] + b[j]);
+                scale += 1e-3;
+                rho_gain /= scale;
+                if (rho_gain > 0 && isfinite(tempChi)) {
+                    double alpha = 1. - pow(2 * rho_gain - 1, 3);
+                    alpha = fmin(alpha, 2. / 3.);
+                    lambda *= fmax(1. / 3., alpha);
+                    ni = 2;
+                    currentChi = tempChi;
+                } else {
+                    lambda *= ni; ni *= 2;
+                    q = qb; t[0] = tb[0]; t[1] = tb[1]; t[2] = tb[2];
+                }
+                qmax++;
+            } while (rho_gain < 0 && qmax < 10);
+            if (qmax == 10 || rho_gain == 0) break;      /* Terminate */
+            if ((iniChi - currentChi) * 1e3 < iniChi) nBadLM++; else nBadLM = 0;
+            if (nBadLM >= 3) break;
+        }
+        nBad = 0;                                         /* Optimizer.cc:378-432 */
+        for (int i = 0; i < n; i++) {
+            if (!valid[i]) continue;
+            double e[3], pc[3];
+            /* an edge that sat the round out (flagged last time) gets a fresh computeError(); the others still hold the
+             * _error of the LAST computeActiveErrors -- the last LM trial, even if that trial was rejected and the
+             * estimate popped (Optimizer.cc:385-390: `if(pFrame->mvbOutlier[idx]) e->computeError();`) */
+            if (outlier[i]) edge_chi2[i] = pose_edge_error(&P, i, &q, t, e, pc);
+            const float chi2 = (float)edge_chi2[i];                           /* `const float chi2 = e->chi2()` */
+            if (chi2 > (u_right[i] < 0 ? chi2Mono : chi2Stereo)) { outlier[i] = 1; level1[i] = 1; nBad++; }
+            else { outlier[i] = 0; level1[i] = 0; }
+        }
+        if (n_init < 10) break;                           /* optimizer.edges().size() < 10, :434-435 */
+    }
+    /* to_homogeneous_matrix + Converter::toCvMat (float), Optimizer.cc:439-443 */
+    const double tx = 2 * q.x, ty = 2 * q.y, tz = 2 * q.z, twx = tx * q.w, twy = ty * q.w, twz = tz * q.w, txx = tx * q.x,
+                 txy = ty * q.x, txz = tz * q.x, tyy = ty * q.y, tyz = tz * q.y, tzz = tz * q.z;
+    const double R[3][3] = {{1 - (tyy + tzz), txy - twz, txz + twy}, {txy + twz, 1 - (txx + tzz), tyz - twx}, {txz - twy, tyz + twx, 1 - (txx + tyy)}};
+    for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) Tcw_out[4 * i + j] = (float)R[i][j]; Tcw_out[4 * i + 3] = (float)t[i]; }
+    Tcw_out[12] = Tcw_out[13] = Tcw_out[14] = 0.0f; Tcw_out[15] = 1.0f;
+    free(level1);
+    free(edge_chi2);
+    return n_init - nBad;
 }

@@ -126,6 +126,14 @@ void orc_unary_build(int n_points, const float *Xw, const int32_t *obs_ptr, cons
 void orc_bf_match(int n_query, const uint8_t *desc_query, int n_train, const uint8_t *desc_train, double ratio,
                   int32_t *train_of_query, int32_t *n_matches);
 
+/* ---- Optimizer::PoseOptimization (src/Optimizer.cc:239-450), PARITY UNPINNED (g2o needs Eigen) ----
+ * Xw [n][3] MapPoint::GetWorldPos; kp [n][2] mvKeysUn[i].pt; u_right [n] mvuRight[i] (< 0: monocular edge);
+ * inv_sigma2 [n] mvInvLevelSigma2[octave]; valid [n] = (mvpMapPoints[i] != NULL); K4 = fx fy cx cy; Tcw row-major 4x4.
+ * outlier [n] receives mvbOutlier (entries of invalid points are left alone).  Returns nInitialCorrespondences - nBad. */
+int orc_pose_optimization(int n, const float *Xw, const float *kp, const float *u_right, const float *inv_sigma2,
+                          const uint8_t *valid, const float *K4, float bf, const float *Tcw_in, float *Tcw_out,
+                          uint8_t *outlier, int *n_initial);
+
 #ifdef __cplusplus
 }
 #endif

@@ -101,6 +101,8 @@ def oracle_lib():
         lib.orc_unary_build.argtypes = [C.c_int, _f32p, _i32p, _i32p, C.POINTER(C.c_double), _f32p, _f32p, _f32p,
                                         C.POINTER(C.c_double), C.POINTER(CrfParams), _f32p, _f32p, _f32p, _i16p]
         lib.orc_bf_match.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_double, _i32p, _i32p]
+        lib.orc_pose_optimization.argtypes = [C.c_int, _f32p, _f32p, _f32p, _f32p, C.c_void_p, _f32p, C.c_float, _f32p, _f32p,
+                                              C.c_void_p, C.POINTER(C.c_int)]
         _olib = lib
     return _olib
 
@@ -420,3 +422,20 @@ def oracle_bf_match(desc_query, desc_train, ratio=0.6):
     nm = np.zeros(1, np.int32)
     lib.orc_bf_match(q.shape[0], q.ctypes.data, t.shape[0], t.ctypes.data, float(ratio), _ptr(out, _i32p), _ptr(nm, _i32p))
     return out, int(nm[0])
+
+
+def oracle_pose_optimization(Xw, kp, u_right, inv_sigma2, valid, K4, bf, Tcw):
+    """Optimizer::PoseOptimization restated (parity unpinned, see lccrf_oracle.c): returns (Tcw_out [4,4] f32, outlier
+    u8[n], n_inliers, n_initial)."""
+    lib = oracle_lib()
+    Xw, kp = _f32(Xw).reshape(-1, 3), _f32(kp).reshape(-1, 2)
+    n = Xw.shape[0]
+    ur, is2 = _f32(u_right), _f32(inv_sigma2)
+    va = np.ascontiguousarray(valid, np.uint8)
+    K, T = _f32(K4), _f32(Tcw).reshape(16)
+    out = np.empty(16, np.float32)
+    outl = np.zeros(n, np.uint8)
+    ninit = C.c_int(0)
+    r = lib.orc_pose_optimization(n, _ptr(Xw, _f32p), _ptr(kp, _f32p), _ptr(ur, _f32p), _ptr(is2, _f32p), va.ctypes.data,
+                                  _ptr(K, _f32p), float(bf), _ptr(T, _f32p), _ptr(out, _f32p), outl.ctypes.data, C.byref(ninit))
+    return out.reshape(4, 4), outl, int(r), ninit.value

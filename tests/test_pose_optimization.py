@@ -1,0 +1,112 @@
+"""Optimizer::PoseOptimization (reference src/Optimizer.cc:239-450), SURVEY.md section 8f-3 -- PARITY UNPINNED: the
+reference runs it on g2o, which needs Eigen (absent in this image), and holds no test or fixture for it.
+
+CPU part: the oracle's restatement (oracle/lccrf_oracle.c: orc_pose_optimization) against hand-derived known answers
+-- exact data give back the exact pose, gross outliers are flagged and re-admitted as the schedule prescribes, fewer
+than three correspondences leave the pose alone, the schedule is invariant to things it must be invariant to.
+GPU part: the HIP kernel (csrc/pose_opt.hip) against that restatement -- identical outlier flags and inlier counts,
+poses equal as float32 up to 2 ulp (the 6x6 sums are taken in a different order), and the batch entry point that reads
+the CRF's labels where the inference kernel left them."""
+import importlib
+
+import numpy as np
+import pytest
+
+pkg = importlib.import_module("lc-crf-slam_amd")
+
+
+def _run_oracle(po, s, valid=None):
+    return po.oracle_pose_optimization(s["Xw"], s["kp"], s["u_right"], s["inv_sigma2"], s["valid"] if valid is None else valid,
+                                       s["K4"], s["bf"], s["T_init"])
+
+
+def test_oracle_recovers_an_exact_pose(po, wl):
+    for n, mono in ((300, 0.0), (300, 1.0), (500, 0.3), (12, 0.5)):
+        s = wl.pose_scene(n, seed=n, noise=0.0, outlier_frac=0.0, mono_frac=mono)
+        T, outl, ninl, ninit = _run_oracle(po, s)
+        assert ninit == n and ninl == n and not outl.any()
+        assert np.abs(T - s["T_true"]).max() < 5e-6, (n, mono, np.abs(T - s["T_true"]).max())
+        assert np.array_equal(T[3], [0, 0, 0, 1])
+        np.testing.assert_allclose(T[:3, :3] @ T[:3, :3].T, np.eye(3), atol=2e-6)      # a rotation comes back
+
+
+def test_oracle_flags_gross_outliers_and_keeps_the_rest(po, wl):
+    s = wl.pose_scene(900, seed=5, noise=0.7, outlier_frac=0.15)
+    T, outl, ninl, ninit = _run_oracle(po, s)
+    assert ninit == 900 and ninl == 900 - int(outl.sum())
+    assert np.abs(T - s["T_true"]).max() < 2e-3
+    gross = s["gross"]
+    assert (outl[gross] == 1).mean() > 0.97                 # 25 px off: far beyond chi2 = 5.991 / 7.815
+    assert (outl[~gross] == 1).mean() < 0.08                # chi2(2) / chi2(3) at 95 % each flag ~5 % of honest points
+
+
+def test_oracle_too_few_correspondences_and_invalid_points(po, wl):
+    s = wl.pose_scene(40, seed=2)
+    valid = np.zeros(40, np.uint8)
+    valid[[3, 17]] = 1
+    T, outl, ninl, ninit = _run_oracle(po, s, valid)
+    assert (ninit, ninl) == (2, 0) and np.array_equal(T, s["T_init"])          # Optimizer.cc:361-362
+    # invalid points contribute nothing: deleting them from the arrays gives the same answer
+    s = wl.pose_scene(400, seed=9, n_invalid=150)
+    T1, o1, n1, i1 = _run_oracle(po, s)
+    keep = s["valid"] == 1
+    sub = dict(s, Xw=s["Xw"][keep], kp=s["kp"][keep], u_right=s["u_right"][keep], inv_sigma2=s["inv_sigma2"][keep],
+               valid=np.ones(int(keep.sum()), np.uint8))
+    T2, o2, n2, i2 = _run_oracle(po, sub)
+    assert i1 == i2 == 250 and n1 == n2 and np.array_equal(T1, T2) and np.array_equal(o1[keep], o2)
+
+
+def test_oracle_fewer_than_ten_edges_run_one_round(po, wl):
+    """optimizer.edges().size() < 10 -> break after the first round (Optimizer.cc:434-435): a gross outlier among 8 points is
+    flagged by round 0 and never gets the chance to be re-examined; the pose still comes from that single round."""
+    s = wl.pose_scene(8, seed=4, noise=0.0, outlier_frac=0.0, mono_frac=0.0)
+    s["kp"][2] += 40.0
+    T, outl, ninl, ninit = _run_oracle(po, s)
+    assert ninit == 8 and outl[2] == 1 and ninl == 8 - int(outl.sum())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,noise,outf,mono,ninv", [(2000, 0.7, 0.15, 0.2, 300), (500, 0.0, 0.0, 0.0, 0), (333, 1.5, 0.3, 1.0, 10),
+                                                     (9, 0.5, 0.2, 0.5, 0), (2, 0.5, 0.0, 0.0, 0), (4096, 0.7, 0.1, 0.2, 0)])
+def test_hip_pose_optimization_matches_the_restatement(po, wl, n, noise, outf, mono, ninv):
+    s = wl.pose_scene(n, seed=n + 1, noise=noise, outlier_frac=outf, mono_frac=mono, n_invalid=ninv)
+    To, oo, no, _ = _run_oracle(po, s)
+    Th, oh, nh = pkg.pose_optimization(s["Xw"], s["kp"], s["u_right"], s["inv_sigma2"], s["K4"], s["bf"], s["T_init"], valid=s["valid"])
+    assert nh == no and np.array_equal(oh[s["valid"] == 1], oo[s["valid"] == 1])
+    ulp = np.abs(Th.view(np.int32).astype(np.int64) - To.view(np.int32).astype(np.int64))
+    assert ulp.max() <= 2 or np.abs(Th - To).max() < 1e-7, (ulp.max(), np.abs(Th - To).max())
+
+
+@pytest.mark.gpu
+def test_hip_pose_optimization_reads_the_crf_labels_on_the_device(po, wl):
+    """CRF (lccrf_batch_run) -> pose (lccrf_batch_pose_optimization) with the labels staying in HBM: per frame the same as
+    the oracle's pose optimisation on the points the oracle's CRF labels static."""
+    import torch
+    import crf_cases as cc
+    F, N = 5, 1500
+    dev = torch.device("cuda", 0)
+    pbs = [wl.slam_problem(N, seed=900 + f) for f in range(F)]
+    scenes = [wl.pose_scene(N, seed=950 + f) for f in range(F)]
+    b = pkg.BatchCRF(F, N, 2, [2, 2], [10.0, 30.0])
+    b.set_inputs_host([N] * F, [np.stack([pb["kernels"][k][0] for pb in pbs]) for k in range(2)],
+                      label=np.stack([pb["label"] for pb in pbs]), conf=0.7)
+    b.run(5, True)
+    t = lambda key, dt: torch.from_numpy(np.stack([np.ascontiguousarray(s[key]) for s in scenes]).astype(dt)).to(dev)
+    dX, dk, du, di, dTi = t("Xw", np.float32), t("kp", np.float32), t("u_right", np.float32), t("inv_sigma2", np.float32), t("T_init", np.float32)
+    dTo = torch.zeros((F, 16), dtype=torch.float32, device=dev)
+    dout = torch.zeros((F, N), dtype=torch.uint8, device=dev)
+    dni, dn0 = torch.zeros(F, dtype=torch.int32, device=dev), torch.zeros(F, dtype=torch.int32, device=dev)
+    b.pose_optimization(dX.data_ptr(), dk.data_ptr(), du.data_ptr(), di.data_ptr(), scenes[0]["K4"], scenes[0]["bf"], dTi.data_ptr(),
+                        dTo.data_ptr(), dout.data_ptr(), dni.data_ptr(), dn0.data_ptr())
+    b.synchronize()
+    labels = b.map()
+    for f in range(F):
+        o = cc.setup(po.OracleCRF, pbs[f])
+        o.inference_native(5, True)
+        assert np.array_equal(labels[f], o.map())
+        static = (o.map() != 0).astype(np.uint8)
+        s = scenes[f]
+        To, oo, no, n0 = po.oracle_pose_optimization(s["Xw"], s["kp"], s["u_right"], s["inv_sigma2"], static, s["K4"], s["bf"], s["T_init"])
+        assert int(dn0[f]) == n0 == int(static.sum()) and int(dni[f]) == no
+        assert np.array_equal(dout[f].cpu().numpy()[static == 1], oo[static == 1])
+        assert np.abs(dTo[f].cpu().numpy().reshape(4, 4) - To).max() < 1e-6
