@@ -416,35 +416,26 @@ __global__ void __launch_bounds__(kNT) k_frame(CrfDev c, FrameArgs a)
         FL_PSTAMP();
         unsigned rank[PPT][D1];
         if (bitmap) {
-            uint4 bw[PPT][D1];
-            unsigned pv[PPT][D1];
 #pragma unroll
-            for (int s = 0; s < PPT; ++s) {
+            for (int s = 0; s < PPT; ++s) {               // (one point at a time: three 16-byte reads in flight, 12 registers)
                 const int i = min(tid + s * kNT, N - 1);
+                uint4 bw[D1];
+                unsigned pv[D1];
 #pragma unroll
                 for (int j = 0; j < D1; ++j) {
-                    bw[s][j] = *reinterpret_cast<const uint4 *>(bm + vid[s][j] * W + ((i >> 5) & ~3));   // the 4-word group of my word
-                    pv[s][j] = pre[vid[s][j] * (W >> 2) + (i >> 7)];
+                    bw[j] = *reinterpret_cast<const uint4 *>(bm + vid[s][j] * W + ((i >> 5) & ~3));   // the 4-word group of my word
+                    pv[j] = pre[vid[s][j] * (W >> 2) + (i >> 7)];
                 }
-            }
-#pragma unroll
-            for (int s = 0; s < PPT; ++s) {
-                const int i = min(tid + s * kNT, N - 1);
                 const int wq = (i >> 5) & 3;
                 const unsigned low = (1u << (i & 31)) - 1u;
 #pragma unroll
                 for (int j = 0; j < D1; ++j) {
-                    const uint4 b = bw[s][j];
-                    rank[s][j] = pv[s][j] + (wq > 0 ? __popc(b.x) : 0) + (wq > 1 ? __popc(b.y) : 0) + (wq > 2 ? __popc(b.z) : 0) +
+                    const uint4 b = bw[j];
+                    rank[s][j] = pv[j] + (wq > 0 ? __popc(b.x) : 0) + (wq > 1 ? __popc(b.y) : 0) + (wq > 2 ? __popc(b.z) : 0) +
                                  __popc((wq == 0 ? b.x : wq == 1 ? b.y : wq == 2 ? b.z : b.w) & low);
                 }
             }
         } else {
-            uint4 first[PPT][D1];
-#pragma unroll
-            for (int s = 0; s < PPT; ++s)
-#pragma unroll
-                for (int j = 0; j < D1; ++j) first[s][j] = *reinterpret_cast<const uint4 *>(list + (lc[s][j] & 0xffffu));
             // eight 16-bit entries against e at once: entries and e are < 0x8000, so (x | 0x8000) - e keeps bit 15 of a
             // half exactly when that half is >= e, and no half ever borrows from its neighbour
             auto below = [](const uint4 &x, unsigned e) {
@@ -455,10 +446,13 @@ __global__ void __launch_bounds__(kNT) k_frame(CrfDev c, FrameArgs a)
 #pragma unroll
             for (int s = 0; s < PPT; ++s) {
                 const int i = tid + s * kNT;
+                uint4 first[D1];
+#pragma unroll
+                for (int j = 0; j < D1; ++j) first[j] = *reinterpret_cast<const uint4 *>(list + (lc[s][j] & 0xffffu));
 #pragma unroll
                 for (int j = 0; j < D1; ++j) {
                     const unsigned e = (unsigned)(i * D1 + j);
-                    unsigned r = below(first[s][j], e);
+                    unsigned r = below(first[j], e);
                     const uint4 *lp = reinterpret_cast<const uint4 *>(list + (lc[s][j] & 0xffffu));
                     const int n8 = (int)(((lc[s][j] >> 16) + 7u) >> 3);
                     for (int u = 1; u < n8; ++u) r += below(lp[u], e);    // rows of more than 8 entries

@@ -192,8 +192,8 @@ __device__ __forceinline__ float chain_rows(unsigned addr, unsigned end, unsigne
 template <int PPT, int K>
 struct PointRegs {
     float2 un[PPT], q[PPT];
-    unsigned offp[PPT][K][2];             // (id0+1) | (id1+1) << 16,  id2+1     (index into val, 0 = absent)
-    unsigned slp[PPT][K][2];              // slot0 | slot1 << 16,  slot2         (index into prod)
+    unsigned ix[PPT][K][3];               // (id0+1) | (id1+1) << 16,  (id2+1) | slot0 << 16,  slot1 | slot2 << 16
+                                          //   id+1 = index into val (0 = absent), slot = index into prod
     float bary[PPT][K][kD1];
     float wn[PPT][K];                     // w * norm                            pairwise3d.h:77
 };
@@ -215,7 +215,7 @@ __device__ __forceinline__ bool chain_k(const FusedLayout &lay, int k)
 // pk[s][k][j] = (vertex id + 1) | place in the vertex's row << 16 -- the place of entry (i, j) in its
 // vertex's row in ascending point order, the reference's splat order, counted from the start of the CSR
 // (row[v] + rank).  A plain kernel stores its products at exactly that position; the chain kernel re-places
-// row v at pst(row[v], v).  Also fills offp.  The row tables must be in LDS and visible (barrier before).
+// row v at pst(row[v], v).  Fills ix.  The row tables must be in LDS and visible (barrier before).
 template <int PPT, int K, int CH>
 __device__ __forceinline__ void place_products(unsigned char *smem, const FusedLayout &lay, int N, int tid,
                                                const unsigned (&pk)[PPT][K][kD1], PointRegs<PPT, K> &pr)
@@ -225,9 +225,9 @@ __device__ __forceinline__ void place_products(unsigned char *smem, const FusedL
         const unsigned short *row = reinterpret_cast<const unsigned short *>(smem + lay.row[k]);
 #pragma unroll
         for (int s = 0; s < PPT; ++s) {
-            pr.offp[s][k][0] = (pk[s][k][0] & 0xffffu) | (pk[s][k][1] << 16);
-            pr.offp[s][k][1] = pk[s][k][2] & 0xffffu;
-            pr.slp[s][k][0] = pr.slp[s][k][1] = 0;
+            pr.ix[s][k][0] = (pk[s][k][0] & 0xffffu) | (pk[s][k][1] << 16);
+            pr.ix[s][k][1] = pk[s][k][2] & 0xffffu;
+            pr.ix[s][k][2] = 0;
             if (tid + s * kNT < N) {
                 unsigned sl[kD1];
 #pragma unroll
@@ -239,8 +239,8 @@ __device__ __forceinline__ void place_products(unsigned char *smem, const FusedL
                         sl[j] = (unsigned)(pst(r0, v) + ((int)(pk[s][k][j] >> 16) - r0));
                     }
                 }
-                pr.slp[s][k][0] = sl[0] | (sl[1] << 16);
-                pr.slp[s][k][1] = sl[2];
+                pr.ix[s][k][1] |= sl[0] << 16;
+                pr.ix[s][k][2] = sl[1] | (sl[2] << 16);
             }
         }
     }
@@ -319,7 +319,7 @@ __device__ __forceinline__ void splat_blur(unsigned char *smem, const FusedLayou
         for (int s = 0; s < PPT; ++s) {
             const int i = tid + s * kNT;
             if (i < N) {
-                const unsigned s0 = pr.slp[s][k][0] & 0xffffu, s1 = pr.slp[s][k][0] >> 16, s2 = pr.slp[s][k][1];
+                const unsigned s0 = pr.ix[s][k][1] >> 16, s1 = pr.ix[s][k][2] & 0xffffu, s2 = pr.ix[s][k][2] >> 16;
                 if (chain_k<CH>(lay, k)) {                             // chain kernel: one plane per label
                     p0[s0] = pr.bary[s][k][0] * pr.q[s].x;
                     p1[s0] = pr.bary[s][k][0] * pr.q[s].y;
@@ -429,7 +429,7 @@ __device__ __forceinline__ float2 slice_point(const unsigned char *smem, const F
                                               int s, int k, float alpha)
 {
     const float2 *val = reinterpret_cast<const float2 *>(smem + lay.val[k][kD1 & 1]);
-    const float2 x0 = val[pr.offp[s][k][0] & 0xffffu], x1 = val[pr.offp[s][k][0] >> 16], x2 = val[pr.offp[s][k][1]];
+    const float2 x0 = val[pr.ix[s][k][0] & 0xffffu], x1 = val[pr.ix[s][k][0] >> 16], x2 = val[pr.ix[s][k][1] & 0xffffu];
     const float w0 = pr.bary[s][k][0] * alpha, w1 = pr.bary[s][k][1] * alpha, w2 = pr.bary[s][k][2] * alpha;   // permutohedral_cpu.h:689
     float t0 = 0.0f, t1 = 0.0f;
     t0 += w0 * x0.x; t1 += w0 * x0.y;
@@ -448,7 +448,7 @@ __device__ __forceinline__ void opaque(PointRegs<PPT, K> &pr)
     for (int s = 0; s < PPT; ++s) {
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-            asm volatile("" : "+v"(pr.slp[s][k][0]), "+v"(pr.slp[s][k][1]), "+v"(pr.offp[s][k][0]), "+v"(pr.offp[s][k][1]));
+            asm volatile("" : "+v"(pr.ix[s][k][0]), "+v"(pr.ix[s][k][1]), "+v"(pr.ix[s][k][2]));
             asm volatile("" : "+v"(pr.bary[s][k][0]), "+v"(pr.bary[s][k][1]), "+v"(pr.bary[s][k][2]));
         }
     }

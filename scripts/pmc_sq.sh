@@ -14,9 +14,10 @@ for p in ("p1","p2"):
     for fn in glob.glob("gpurun_out/prof/sq/%s/*counter_collection.csv" % p):
         agg = collections.defaultdict(list)
         for r in csv.DictReader(open(fn)):
-            if "k_fused" in r["Kernel_Name"] or "k_frame" in r["Kernel_Name"]:
-                agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
-        for k, v in agg.items():
-            print("%-24s mean/dispatch %.4g  (n=%d)" % (k, sum(v)/len(v), len(v)))
+            for kern in ("k_fused", "k_frame", "k_blur2", "k_splat2", "k_slice2"):
+                if kern in r["Kernel_Name"]:
+                    agg[(kern, r["Counter_Name"])].append(float(r["Counter_Value"]))
+        for (kern, k), v in sorted(agg.items()):
+            print("%-9s %-24s mean/dispatch %.4g  (n=%d)" % (kern, k, sum(v)/len(v), len(v)))
 PY
 tail -3 $OUT/p1.err

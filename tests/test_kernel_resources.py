@@ -1,7 +1,7 @@
 """Compile-time guard for the two hand-tuned kernels (no GPU needed: hipcc cross-compiles gfx950).
 
-The fused engine's SLAM variants (1-2 points per lane) must not spill: scratch traffic inside the
-mean-field loop costs more than any optimisation in that file gains, and
+The one-workgroup-per-frame kernels' SLAM variants must not spill: scratch traffic inside the
+mean-field loop costs more than any optimisation in those files gains, and
 chain_rows' hand-written ring relies on v96..v127 being free around it.  The fused build must not
 spill vector registers either."""
 import os
@@ -34,14 +34,32 @@ def resource_usage(src):
 
 @pytest.mark.skipif(shutil.which(HIPCC) is None, reason="hipcc not installed")
 def test_fused_slam_variants_do_not_spill():
+    """Every BASELINE configuration's variant -- 1000 / 2000 keypoints (1-2 points per lane) and 3000 (3 points per lane,
+    config C4) -- runs without scratch memory."""
     use = resource_usage("fused_engine.hip")
     fused = {k: v for k, v in use.items() if "k_fused" in k}
-    assert len(fused) == 24                                   # PPT 1..4 x K 1..2 x {short rows, chain, late-bound}
+    assert len(fused) == 16                                   # PPT 1..4 x K 1..2 x {short rows, chain}
     for name, r in fused.items():
         ppt = int(re.search(r"k_fusedILi(\d)E", name).group(1))
         assert r["VGPRs"] + r.get("AGPRs", 0) <= 128, name     # 1024 lanes per workgroup
+        if ppt <= 3:
+            assert r["ScratchSize [bytes/lane]"] == 0 and r["VGPRs Spill"] == 0, (name, r)
+
+
+@pytest.mark.skipif(shutil.which(HIPCC) is None, reason="hipcc not installed")
+def test_frame_kernel_slam_variants_do_not_spill():
+    """The one-launch-per-frame kernel: no scratch for 1-2 points per lane (C1, C2, C3); the 3-points-per-lane variant
+    (C4) may spill a few registers in its build phases but stays small."""
+    use = resource_usage("frame_engine.hip")
+    frame = {k: v for k, v in use.items() if "k_frame" in k}
+    assert len(frame) == 8                                    # PPT 1..4 x K 1..2
+    for name, r in frame.items():
+        ppt, K = (int(x) for x in re.search(r"k_frameILi(\d)ELi(\d)E", name).groups())
+        assert r["VGPRs"] + r.get("AGPRs", 0) <= 128, name
         if ppt <= 2:
             assert r["ScratchSize [bytes/lane]"] == 0 and r["VGPRs Spill"] == 0, (name, r)
+        if ppt == 3:
+            assert r["ScratchSize [bytes/lane]"] <= 64, (name, r)
 
 
 @pytest.mark.skipif(shutil.which(HIPCC) is None, reason="hipcc not installed")
