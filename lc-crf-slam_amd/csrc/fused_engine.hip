@@ -38,7 +38,7 @@ struct FusedArgs {
     int n_iter, with_map;
     float relax;
     long long *timing;                    // instrumented builds: shader-clock stamps of one workgroup (LCCRF_FUSED_TIMING=<block index + 1>)
-    int timing_block;
+    int timing_block, timing_lane;
     int dbg;                              // instrumented builds: LCCRF_FUSED_DBG (see fused_loop.h)
 };
 
@@ -53,7 +53,7 @@ __global__ void __launch_bounds__(kNT) k_fused(CrfDev c, FusedArgs a)
     const int f = blockIdx.x;
     const int tid = threadIdx.x;
     const int N = c.n_points[f];
-    Instr ins{a.timing, a.timing_block, a.dbg, 0, 0};
+    Instr ins{a.timing, a.timing_block, a.dbg, 0, a.timing_lane};
     FL_STAMP();
 
     PointRegs<PPT, K> pr;
@@ -158,7 +158,7 @@ __global__ void __launch_bounds__(kNT) k_fused(CrfDev c, FusedArgs a)
 
     store_results(c, f, N, tid, pr, a.with_map);
     FL_STAMP();
-    if (kInstr && a.timing && blockIdx.x == a.timing_block && tid == 0) a.timing[63] = ins.n;
+    if (kInstr && a.timing && (int)blockIdx.x == a.timing_block && tid == a.timing_lane) a.timing[63] = ins.n;
 }
 
 bool make_layout(const CrfDev &c, const KernelDev *kds, const int *maxV, const int *maxRow, FusedLayout *lay)
@@ -219,6 +219,7 @@ void launch_inference_fused(const CrfDev &c, const KernelDev *kds, const int *ma
     a.timing = want_timing ? timing_buf : nullptr;
     a.timing_block = want_timing ? std::max(atoi(getenv("LCCRF_FUSED_TIMING")) - 1, 0) : 0;
     if (a.timing_block >= c.F) a.timing_block = 0;
+    a.timing_lane = (want_timing && getenv("LCCRF_FUSED_TIMING_LANE")) ? atoi(getenv("LCCRF_FUSED_TIMING_LANE")) & (kNT - 1) : 0;
     static const int dbg = (kInstr && getenv("LCCRF_FUSED_DBG")) ? atoi(getenv("LCCRF_FUSED_DBG")) : 0;
     a.dbg = dbg;
     const int ppt = ((c.activeN > 0 ? c.activeN : c.maxN) + kNT - 1) / kNT;
