@@ -31,6 +31,10 @@ constexpr size_t kLdsLimit = 160 * 1024;  // MI355X: 160 KiB LDS per CU, one wor
 constexpr int kChainMinRow = 64;          // kernel 0 runs chain_rows when its longest splat row has at least this many products ...
 constexpr int kChainMaxV = kChainTop + 7 * 64;           // ... and it has at most this many vertices (one lane per (vertex,label) row)
 
+#ifndef LCCRF_FUSE_XP
+#define LCCRF_FUSE_XP 1
+#endif
+constexpr bool kFuseXP = LCCRF_FUSE_XP != 0;     // A/B switch (scripts/gpu_ab.sh): products written right behind each point's softmax
 #ifndef LCCRF_INSTRUMENT
 #define LCCRF_INSTRUMENT 0
 #endif
@@ -306,44 +310,52 @@ __device__ __forceinline__ ChainLane chain_setup(unsigned char *smem, const Fuse
 // ---- splat = products (P) + ordered row sums (S), then the d+1 Jacobi blur passes ---------------
 // On return val[k][kD1 & 1] holds the blurred lattice values of every kernel and every lane has passed
 // the barrier behind the last blur pass.  permutohedral_cpu.h:653-679.
+// Phase P for one point slot: the 3 products bary * Q per label of point (tid + s * 1024) into their rows of kernel k.
 template <int PPT, int K, int CH>
+__device__ __forceinline__ void point_products(unsigned char *smem, const FusedLayout &lay, const PointRegs<PPT, K> &pr, int s, int k)
+{
+    float *p0 = reinterpret_cast<float *>(smem + lay.prod[k]);
+    float *p1 = p0 + lay.Ecap[k];
+    float2 *p2 = reinterpret_cast<float2 *>(p0);
+    const unsigned s0 = pr.ix[s][k][1] >> 16, s1 = pr.ix[s][k][2] & 0xffffu, s2 = pr.ix[s][k][2] >> 16;
+    if (chain_k<CH>(lay, k)) {                             // chain kernel: one plane per label
+        p0[s0] = pr.bary[s][k][0] * pr.q[s].x;
+        p1[s0] = pr.bary[s][k][0] * pr.q[s].y;
+        p0[s1] = pr.bary[s][k][1] * pr.q[s].x;
+        p1[s1] = pr.bary[s][k][1] * pr.q[s].y;
+        p0[s2] = pr.bary[s][k][2] * pr.q[s].x;
+        p1[s2] = pr.bary[s][k][2] * pr.q[s].y;
+    } else {                                              // short rows: labels interleaved
+        p2[s0] = make_float2(pr.bary[s][k][0] * pr.q[s].x, pr.bary[s][k][0] * pr.q[s].y);
+        p2[s1] = make_float2(pr.bary[s][k][1] * pr.q[s].x, pr.bary[s][k][1] * pr.q[s].y);
+        p2[s2] = make_float2(pr.bary[s][k][2] * pr.q[s].x, pr.bary[s][k][2] * pr.q[s].y);
+    }
+}
+
+// behind a chain row: +0 up to a multiple of 4, then eight +0 (what chain_rows reads past the end of the row)
+__device__ __forceinline__ void chain_pads(unsigned char *smem, const ChainLane &cl)
+{
+    if (cl.b >> 16) {
+        float *e = reinterpret_cast<float *>(smem + (cl.a & 0x3ffffu)) + ((cl.b & 0x1fffu) * 8u - ((cl.b >> 13) & 1u) * 4u);
+        const unsigned npad = (cl.b >> 14) & 3u;
+        for (unsigned z = 1; z <= npad; ++z) e[-(int)z] = 0.0f;
+        reinterpret_cast<float4 *>(e)[0] = make_float4(0.f, 0.f, 0.f, 0.f);
+        reinterpret_cast<float4 *>(e)[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
+// WITH_P = false (own product buffers only): the products are already in place -- mean_field writes the next
+// iteration's products point by point right behind each point's softmax.
+template <int PPT, int K, int CH, bool WITH_P = true>
 __device__ __forceinline__ void splat_blur(unsigned char *smem, const FusedLayout &lay, const int (&V)[K], int N, int tid,
                                            const PointRegs<PPT, K> &pr, const ChainLane &cl, Instr &ins)
 {
     constexpr int D1 = kD1;
     auto phase_P = [&](int k) {
-        float *p0 = reinterpret_cast<float *>(smem + lay.prod[k]);
-        float *p1 = p0 + lay.Ecap[k];
-        float2 *p2 = reinterpret_cast<float2 *>(p0);
 #pragma unroll
-        for (int s = 0; s < PPT; ++s) {
-            const int i = tid + s * kNT;
-            if (i < N) {
-                const unsigned s0 = pr.ix[s][k][1] >> 16, s1 = pr.ix[s][k][2] & 0xffffu, s2 = pr.ix[s][k][2] >> 16;
-                if (chain_k<CH>(lay, k)) {                             // chain kernel: one plane per label
-                    p0[s0] = pr.bary[s][k][0] * pr.q[s].x;
-                    p1[s0] = pr.bary[s][k][0] * pr.q[s].y;
-                    p0[s1] = pr.bary[s][k][1] * pr.q[s].x;
-                    p1[s1] = pr.bary[s][k][1] * pr.q[s].y;
-                    p0[s2] = pr.bary[s][k][2] * pr.q[s].x;
-                    p1[s2] = pr.bary[s][k][2] * pr.q[s].y;
-                } else {                                              // short rows: labels interleaved
-                    p2[s0] = make_float2(pr.bary[s][k][0] * pr.q[s].x, pr.bary[s][k][0] * pr.q[s].y);
-                    p2[s1] = make_float2(pr.bary[s][k][1] * pr.q[s].x, pr.bary[s][k][1] * pr.q[s].y);
-                    p2[s2] = make_float2(pr.bary[s][k][2] * pr.q[s].x, pr.bary[s][k][2] * pr.q[s].y);
-                }
-            }
-        }
-        if (chain_k<CH>(lay, k)) {     // behind the row: +0 up to a multiple of 4, then eight +0 (the buffer may
-                                       // have held another kernel's products)
-            if (cl.b >> 16) {
-                float *e = reinterpret_cast<float *>(smem + (cl.a & 0x3ffffu)) + ((cl.b & 0x1fffu) * 8u - ((cl.b >> 13) & 1u) * 4u);
-                const unsigned npad = (cl.b >> 14) & 3u;
-                for (unsigned z = 1; z <= npad; ++z) e[-(int)z] = 0.0f;
-                reinterpret_cast<float4 *>(e)[0] = make_float4(0.f, 0.f, 0.f, 0.f);
-                reinterpret_cast<float4 *>(e)[1] = make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-        }
+        for (int s = 0; s < PPT; ++s)
+            if (tid + s * kNT < N) point_products<PPT, K, CH>(smem, lay, pr, s, k);
+        if (chain_k<CH>(lay, k)) chain_pads(smem, cl);    // (the buffer may have held another kernel's products)
     };
     // lanes [s_lo, kNT) share the short-row kernels; the wavefronts that own the chain kernel's
     // longest rows keep out of them
@@ -382,8 +394,10 @@ __device__ __forceinline__ void splat_blur(unsigned char *smem, const FusedLayou
         }
     };
     if (lay.prod_all) {
+        if (WITH_P) {
 #pragma unroll
-        for (int k = 0; k < K; ++k) phase_P(k);
+            for (int k = 0; k < K; ++k) phase_P(k);
+        }
         __syncthreads();
         FL_STAMP();
         const int s_lo = (K > 1 && chain_k<CH>(lay, 0)) ? 128 : 0;
@@ -477,25 +491,57 @@ __device__ __forceinline__ void mean_field(unsigned char *smem, const FusedLayou
                                            PointRegs<PPT, K> &pr, const ChainLane &cl, const float (&alpha)[K], int n_iter,
                                            float relax, Instr &ins)
 {
+    // slice + apply + softmax of point slot s (X)
+    auto point_update = [&](int s) {
+        float nx[2] = {-pr.un[s].x, -pr.un[s].y};                 // stepInit, densecrf3d.h:154-158
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const float2 t = slice_point(smem, lay, pr, s, k, alpha[k]);
+            nx[0] += pr.wn[s][k] * t.x;                           // pairwise3d.h:77
+            nx[1] += pr.wn[s][k] * t.y;
+        }
+        float out[2] = {pr.q[s].x, pr.q[s].y};
+        exp_and_normalize_reg<2>(nx, out, 1.0f, relax);
+        pr.q[s] = make_float2(out[0], out[1]);
+    };
+    if (kFuseXP && PPT <= 2 && lay.prod_all) {            // (3-4 points per lane: the fused form costs registers the loop does not have)
+        // Every kernel owns its product buffer: a point's next products go out right behind its softmax, so one
+        // point's LDS stores drain while the next point's slice and softmax occupy the VALU (X is VALU-bound, P is
+        // bound by the LDS store path; back to back they cost the sum).  The barrier that used to follow P now
+        // opens splat_blur; the pads behind the chain rows are written once (nothing else ever writes there).
+        if (n_iter > 0) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+#pragma unroll
+                for (int s = 0; s < PPT; ++s)
+                    if (tid + s * kNT < N) point_products<PPT, K, CH>(smem, lay, pr, s, k);
+                if (chain_k<CH>(lay, k)) chain_pads(smem, cl);
+            }
+        }
+        for (int it = 0; it < n_iter; ++it) {
+            opaque(pr);
+            splat_blur<PPT, K, CH, false>(smem, lay, V, N, tid, pr, cl, ins);
+            const bool more = it + 1 < n_iter;
+#pragma unroll
+            for (int s = 0; s < PPT; ++s) {
+                if (tid + s * kNT < N) {
+                    point_update(s);
+                    if (more) {
+#pragma unroll
+                        for (int k = 0; k < K; ++k) point_products<PPT, K, CH>(smem, lay, pr, s, k);
+                    }
+                }
+            }
+            FL_STAMP();
+        }
+        return;
+    }
     for (int it = 0; it < n_iter; ++it) {
         opaque(pr);
         splat_blur<PPT, K, CH>(smem, lay, V, N, tid, pr, cl, ins);
 #pragma unroll
-        for (int s = 0; s < PPT; ++s) {
-            const int i = tid + s * kNT;
-            if (i < N) {
-                float nx[2] = {-pr.un[s].x, -pr.un[s].y};                 // stepInit, densecrf3d.h:154-158
-#pragma unroll
-                for (int k = 0; k < K; ++k) {
-                    const float2 t = slice_point(smem, lay, pr, s, k, alpha[k]);
-                    nx[0] += pr.wn[s][k] * t.x;                           // pairwise3d.h:77
-                    nx[1] += pr.wn[s][k] * t.y;
-                }
-                float out[2] = {pr.q[s].x, pr.q[s].y};
-                exp_and_normalize_reg<2>(nx, out, 1.0f, relax);
-                pr.q[s] = make_float2(out[0], out[1]);
-            }
-        }
+        for (int s = 0; s < PPT; ++s)
+            if (tid + s * kNT < N) point_update(s);
         FL_STAMP();
     }
 }
