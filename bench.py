@@ -288,8 +288,8 @@ def c5_record(pkg, wl, torch, dev, steps=6, frames=8):
     return out
 
 
-def pmc_traffic(tag):
-    """HBM bytes per launch of the dominant kernel from a committed rocprofv3 --pmc profile of THIS command line
+def pmc_traffic(tag, kernel="k_fused"):
+    """HBM bytes per launch of `kernel` from a committed rocprofv3 --pmc profile of THIS command line
     (profiles/<tag>/pmc_summary.csv: FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE).  Counters
     cannot be collected inside this process; None unless such a profile is committed."""
     import csv
@@ -298,7 +298,7 @@ def pmc_traffic(tag):
         return None
     tot = 0.0
     for r in csv.DictReader(open(fn)):
-        if "k_fused" in r["kernel"] or "k_frame" in r["kernel"]:
+        if kernel in r["kernel"]:
             tot += float(r["bytes_corrected"])
     return tot or None
 
@@ -556,6 +556,7 @@ def main():
             "frames_per_s_end_to_end": (F * world / (run_ms * 1e-3)) if (run_ms and run_engine == 3) else F * world / ((build_ms + inf_ms) * 1e-3),
             "end_to_end": {"one_launch_ms_per_batch": run_ms, "one_launch_engine": (run_engine if run_ms else None),
                            "two_kernel_ms_per_batch": build_ms + inf_ms,
+                           "one_launch_hbm_bytes_per_frame": (pmc_traffic("r2_fused_c2", "k_frame") / F) if ((name, F) == ("c2", 4096) and pmc_traffic("r2_fused_c2", "k_frame")) else None,
                            "note": "per frame: both PottsPotential3D ctors (lattice + norm) + inference(n, true); one_launch = "
                                    "lccrf_batch_run (frame_engine.hip), wall clock over back-to-back batches; two_kernel = HIP "
                                    "events of lccrf_batch_build + lccrf_batch_inference"},
