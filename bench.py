@@ -380,15 +380,16 @@ def main():
     # backend that tolerates that.  The driver's runs never set them.
     if "LCCRF_BENCH_DEVICE" in os.environ:
         local_rank = int(os.environ["LCCRF_BENCH_DEVICE"])
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(os.environ.get("LCCRF_BENCH_BACKEND", "nccl"),   # "nccl" is RCCL on ROCm
-                                rank=rank, world_size=world)
-        assert dist.get_world_size() == args.gpus
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    torch.cuda.set_device(local_rank)                 # before the process group: RCCL binds the rank to this device
     dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend = os.environ.get("LCCRF_BENCH_BACKEND", "nccl")                # "nccl" is RCCL on ROCm
+        kw = {"device_id": dev} if backend == "nccl" else {}
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+        assert dist.get_world_size() == args.gpus
 
     pkg = importlib.import_module("lc-crf-slam_amd")
     wl = importlib.import_module("lc-crf-slam_amd.workloads")

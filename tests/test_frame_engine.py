@@ -212,3 +212,26 @@ np.save(sys.argv[1], np.concatenate([o.ravel() for o in out]))
         subprocess.run([sys.executable, "-c", code, path], check=True, env=dict(os.environ, **env), timeout=600)
         res.append(np.load(path))
     assert cc.same_bits(res[0], res[1])
+
+
+def test_frame_kernel_many_copies_are_identical(wl):
+    """Race hunt: 1536 frames in flight (6 per CU), three distinct frames tiled, three runs -- every copy must equal its
+    original bit for bit, every time (workgroups of different frames share nothing but the kernel's code)."""
+    F, N = 1536, 2000
+    base = [wl.slam_problem(N, seed=1200 + i) for i in range(3)]
+    feats = [np.stack([base[f % 3]["kernels"][k][0] for f in range(F)]) for k in range(2)]
+    label = np.stack([base[f % 3]["label"] for f in range(F)])
+    b = pkg.BatchCRF(F, N, 2, [2, 2], [10.0, 30.0])
+    b.set_inputs_host([N] * F, feats, label=label, conf=0.7)
+    ref = None
+    for _ in range(3):
+        b.run(5, True)
+        Q, M = b.probability(), b.map()
+        assert b.engine() == 3
+        for f in range(3, F):
+            assert cc.same_bits(Q[f], Q[f % 3]) and np.array_equal(M[f], M[f % 3]), f
+        if ref is None:
+            ref = (Q[:3].copy(), M[:3].copy())
+        else:
+            assert cc.same_bits(Q[:3], ref[0]) and np.array_equal(M[:3], ref[1])
+    b.close()
