@@ -39,6 +39,8 @@ N_CU, CLK_HZ = 256, 2.4e9
 LDS_RATE = {"read_b64": 256.0, "read_b128": 256.0, "read_b32": 128.0, "read_u16": 64.0,
             "write_b32": 64.0, "write_b64": 85.0}
 
+DEFAULT_FRAMES = 8192          # sized for 288 GB of HBM: throughput still grows with frames in flight (4096: -4 %, 16384: +1 %)
+
 WORKLOADS = {
     # name: (N, n_iter, obs_cap, description)
     "c1": (1000, 5, None, "C1: 1000 keypoints, 5 iters, two 2-D kernels (TUM3.yaml), L=2"),
@@ -397,7 +399,7 @@ def main():
 
     name = args.workload
     N, n_iter, _, desc = WORKLOADS[name]
-    F = args.frames or (1 if name == "c5" else 4096)   # frames in flight per GPU: 16 full waves of workgroups on 256 CUs
+    F = args.frames or (1 if name == "c5" else DEFAULT_FRAMES)   # frames in flight per GPU: 32 full waves of workgroups on 256 CUs, ~5.6 GB
     distinct = 1 if name == "c5" else min(F, args.distinct)
     pbs, idx, feats, label, dims, weights = make_batch(wl, name, F, rank, distinct)
     L = 2
@@ -514,7 +516,7 @@ def main():
             t_floor = lds_clocks * n_iter * F / N_CU / CLK_HZ       # every CU streaming at the per-instruction peak
             achieved = lds_launch / launch_s / 1e9
             peak = lds_launch / t_floor / 1e9
-            traffic = pmc_traffic("r2_fused_c2" if (name, F) == ("c2", 4096) else None)
+            traffic = pmc_traffic("r2_fused_c2" if (name, F) == ("c2", DEFAULT_FRAMES) else None)
             roof = {"bound": "lds", "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": achieved / peak,
                     "traffic": traffic,
                     "kernel": "inference launch (start + %d mean-field iterations + map), HIP events" % n_iter,
@@ -557,7 +559,7 @@ def main():
             "frames_per_s_end_to_end": (F * world / (run_ms * 1e-3)) if (run_ms and run_engine == 3) else F * world / ((build_ms + inf_ms) * 1e-3),
             "end_to_end": {"one_launch_ms_per_batch": run_ms, "one_launch_engine": (run_engine if run_ms else None),
                            "two_kernel_ms_per_batch": build_ms + inf_ms,
-                           "one_launch_hbm_bytes_per_frame": (pmc_traffic("r2_fused_c2", "k_frame") / F) if ((name, F) == ("c2", 4096) and pmc_traffic("r2_fused_c2", "k_frame")) else None,
+                           "one_launch_hbm_bytes_per_frame": (pmc_traffic("r2_fused_c2", "k_frame") / F) if ((name, F) == ("c2", DEFAULT_FRAMES) and pmc_traffic("r2_fused_c2", "k_frame")) else None,
                            "note": "per frame: both PottsPotential3D ctors (lattice + norm) + inference(n, true); one_launch = "
                                    "lccrf_batch_run (frame_engine.hip), wall clock over back-to-back batches; two_kernel = HIP "
                                    "events of lccrf_batch_build + lccrf_batch_inference"},

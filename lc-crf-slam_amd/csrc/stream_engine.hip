@@ -23,6 +23,26 @@ namespace {
 
 constexpr int kBlock = 256;
 
+// XCD-aware grids for the mean-field iteration of many frames in flight.  The chip's eight XCDs have private 4 MB L2s and
+// workgroup L of a launch runs on XCD L % 8 (observed dispatch order; used for speed only, never for correctness).  With the
+// frame in blockIdx.y every XCD touches every frame's lattice values; here workgroup L = 8 (g nb + x) + r handles block x of
+// frame 8 g + r, so ONE XCD owns a frame and that frame's value array (4.7 MB at C5) is what its L2 sees in the blur
+// gathers.  Used when there are at least 8 frames; `nb` = 0 selects the plain (x, frame) grid.
+struct FrameBlock { int f, bx; };
+__device__ __forceinline__ FrameBlock frame_block(int nb)
+{
+    if (nb == 0) return FrameBlock{(int)blockIdx.y, (int)blockIdx.x};
+    const int L = blockIdx.x, q = L >> 3, g = q / nb;
+    return FrameBlock{g * 8 + (L & 7), q - g * nb};
+}
+inline dim3 grid_xcd(long work, int F, int *nb)
+{
+    const long n = (work + 256 - 1) / 256;
+    if (F < 8 || n < 1) { *nb = 0; return dim3((unsigned)(n > 0 ? n : 1), (unsigned)F); }
+    *nb = (int)n;
+    return dim3((unsigned)(8L * ((F + 7) / 8) * n));
+}
+
 inline dim3 grid_for(long work, int F)
 {
     const long nb = (work + kBlock - 1) / kBlock;
@@ -449,10 +469,12 @@ __global__ void __launch_bounds__(kBlock) k_slice(KernelDev kd, CrfDev c, const 
 
 // ---- two-label specialisations (the SLAM configuration, L = 2): one thread per vertex / point,
 // both labels in a float2.  Same operations per label as the generic kernels above.
-__global__ void __launch_bounds__(kBlock) k_splat2(KernelDev kd, const float2 *__restrict__ in, int in_stride)
+__global__ void __launch_bounds__(kBlock) k_splat2(KernelDev kd, const float2 *__restrict__ in, int in_stride, int F, int nb)
 {
-    const int f = blockIdx.y;
-    const int v = blockIdx.x * kBlock + threadIdx.x;
+    const FrameBlock fb = frame_block(nb);
+    const int f = fb.f;
+    if (f >= F) return;
+    const int v = fb.bx * kBlock + threadIdx.x;
     if (v >= kd.V[f]) return;
     const size_t fe = (size_t)f * kd.Epad, f1 = (size_t)f * (kd.Epad + 1);
     const int s = kd.rowptr[f1 + v], t = kd.rowptr[f1 + v + 1];
@@ -470,11 +492,13 @@ __global__ void __launch_bounds__(kBlock) k_splat2(KernelDev kd, const float2 *_
 // Two vertices per thread: the neighbour pairs (int4), the centres (float4) and the results (float4) move as 16-byte
 // accesses (the frame's value array is laid out so that vertex 2t is 16-byte aligned, see Engine::add_kernel).
 __global__ void __launch_bounds__(kBlock) k_blur2(KernelDev kd, const float *__restrict__ src,
-                                                  float *__restrict__ dst, int j)
+                                                  float *__restrict__ dst, int j, int F, int nb)
 {
-    const int f = blockIdx.y;
+    const FrameBlock fb = frame_block(nb);
+    const int f = fb.f;
+    if (f >= F) return;
     const int V = kd.V[f];
-    const int v = 2 * (blockIdx.x * kBlock + threadIdx.x);
+    const int v = 2 * (fb.bx * kBlock + threadIdx.x);
     if (v >= V) return;
     const float2 *o = reinterpret_cast<const float2 *>(src + (size_t)f * kd.vstride + kd.vbase);   // o[-1] = absent
     float2 *d = reinterpret_cast<float2 *>(dst + (size_t)f * kd.vstride + kd.vbase);
@@ -495,10 +519,12 @@ __global__ void __launch_bounds__(kBlock) k_blur2(KernelDev kd, const float *__r
 // slice + apply for L = 2; the LAST kernel of the step also does the softmax (saves a pass over next).
 template <int D1>
 __global__ void __launch_bounds__(kBlock) k_slice2(KernelDev kd, CrfDev c, const float *__restrict__ val,
-                                                   int first, int last, float relax)
+                                                   int first, int last, float relax, int nb)
 {
-    const int f = blockIdx.y;
-    const int i = blockIdx.x * kBlock + threadIdx.x;
+    const FrameBlock fb = frame_block(nb);
+    const int f = fb.f;
+    if (f >= c.F) return;
+    const int i = fb.bx * kBlock + threadIdx.x;
     if (i >= c.n_points[f]) return;
     const size_t fe = (size_t)f * kd.Epad;
     const float2 *vf = reinterpret_cast<const float2 *>(val + (size_t)f * kd.vstride + kd.vbase);
@@ -678,26 +704,29 @@ void launch_step_stream(const CrfDev &c, const KernelDev *kds, const int *maxV, 
     if (L == 2) {
         for (int k = 0; k < c.K; ++k) {
             const KernelDev &kd = kds[k];
-            k_splat2<<<grid_for(maxV[k], c.F), kBlock, 0, s>>>(kd, reinterpret_cast<const float2 *>(c.Q), c.maxN);
+            int nb;
+            dim3 g = grid_xcd(maxV[k], c.F, &nb);
+            k_splat2<<<g, kBlock, 0, s>>>(kd, reinterpret_cast<const float2 *>(c.Q), c.maxN, c.F, nb);
             const float *src = kd.val0;
             float *dst = kd.val1;
+            g = grid_xcd((maxV[k] + 1) / 2, c.F, &nb);
             for (int j = 0; j < kd.D1; ++j) {
-                k_blur2<<<grid_for((maxV[k] + 1) / 2, c.F), kBlock, 0, s>>>(kd, src, dst, j);
+                k_blur2<<<g, kBlock, 0, s>>>(kd, src, dst, j, c.F, nb);
                 const float *t = src;
                 src = dst;
                 dst = const_cast<float *>(t);
             }
             const int first = k == 0, last = k == c.K - 1;
-            const dim3 g = grid_for(c.maxN, c.F);
+            g = grid_xcd(c.maxN, c.F, &nb);
             switch (kd.D1) {
-            case 2: k_slice2<2><<<g, kBlock, 0, s>>>(kd, c, src, first, last, relax); break;
-            case 3: k_slice2<3><<<g, kBlock, 0, s>>>(kd, c, src, first, last, relax); break;
-            case 4: k_slice2<4><<<g, kBlock, 0, s>>>(kd, c, src, first, last, relax); break;
-            case 5: k_slice2<5><<<g, kBlock, 0, s>>>(kd, c, src, first, last, relax); break;
-            case 6: k_slice2<6><<<g, kBlock, 0, s>>>(kd, c, src, first, last, relax); break;
-            case 7: k_slice2<7><<<g, kBlock, 0, s>>>(kd, c, src, first, last, relax); break;
-            case 8: k_slice2<8><<<g, kBlock, 0, s>>>(kd, c, src, first, last, relax); break;
-            default: k_slice2<9><<<g, kBlock, 0, s>>>(kd, c, src, first, last, relax); break;
+            case 2: k_slice2<2><<<g, kBlock, 0, s>>>(kd, c, src, first, last, relax, nb); break;
+            case 3: k_slice2<3><<<g, kBlock, 0, s>>>(kd, c, src, first, last, relax, nb); break;
+            case 4: k_slice2<4><<<g, kBlock, 0, s>>>(kd, c, src, first, last, relax, nb); break;
+            case 5: k_slice2<5><<<g, kBlock, 0, s>>>(kd, c, src, first, last, relax, nb); break;
+            case 6: k_slice2<6><<<g, kBlock, 0, s>>>(kd, c, src, first, last, relax, nb); break;
+            case 7: k_slice2<7><<<g, kBlock, 0, s>>>(kd, c, src, first, last, relax, nb); break;
+            case 8: k_slice2<8><<<g, kBlock, 0, s>>>(kd, c, src, first, last, relax, nb); break;
+            default: k_slice2<9><<<g, kBlock, 0, s>>>(kd, c, src, first, last, relax, nb); break;
             }
         }
         return;
@@ -725,7 +754,9 @@ hipError_t time_blur_pass(const KernelDev &kd, int F, int maxV, int L, int reps,
     auto pass = [&](int i) {
         const float *src = (i & 1) ? kd.val1 : kd.val0;
         float *dst = (i & 1) ? kd.val0 : kd.val1;
-        if (L == 2) k_blur2<<<grid_for((maxV + 1) / 2, F), kBlock, 0, s>>>(kd, src, dst, i % kd.D1);
+        int nb;
+        const dim3 g = grid_xcd((maxV + 1) / 2, F, &nb);
+        if (L == 2) k_blur2<<<g, kBlock, 0, s>>>(kd, src, dst, i % kd.D1, F, nb);
         else k_blur<<<grid_for((long)maxV * L, F), kBlock, 0, s>>>(kd, src, dst, i % kd.D1, L);
     };
     for (int i = 0; i < 3; ++i) pass(i);

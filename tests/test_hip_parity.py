@@ -501,3 +501,30 @@ def test_streaming_build_with_very_long_rows(po, wl, N, d, L):
     o.inference_native(3, True)
     h.inference(3, True)
     assert cc.same_bits(o.probability(), h.probability()) and np.array_equal(o.map(), h.map())
+
+
+def test_streaming_engine_xcd_aware_grid_with_many_frames(po, wl):
+    """With >= 8 frames in flight the streaming iteration kernels use the XCD-aware 1-D grid (one XCD per frame): 11 ragged
+    frames (a partial last group of eight, an empty frame) on engine 1 against the oracle."""
+    sizes = [700, 0, 1, 333, 699, 5, 512, 700, 64, 257, 700]
+    maxN = 700
+    pbs = [wl.slam_problem(n, seed=140 + i) for i, n in enumerate(sizes)]
+    F = len(sizes)
+    feats = [np.zeros((F, maxN, 2), np.float32) for _ in range(2)]
+    label = np.full((F, maxN), -1, np.int16)
+    for f, pb in enumerate(pbs):
+        n = pb["N"]
+        label[f, :n] = pb["label"]
+        for k in range(2):
+            feats[k][f, :n] = pb["kernels"][k][0]
+    b = pkg.BatchCRF(F, maxN, 2, [2, 2], [10.0, 30.0])
+    b.set_engine(1)
+    b.set_inputs_host(sizes, feats, label=label, conf=0.7)
+    b.build()
+    b.inference(4, True)
+    assert b.engine() == 1
+    Q, M = b.probability(), b.map()
+    for f, pb in enumerate(pbs):
+        o = cc.setup(po.OracleCRF, pb)
+        o.inference_native(4, True)
+        assert cc.same_bits(Q[f, :pb["N"]], o.probability()) and np.array_equal(M[f, :pb["N"]], o.map()), f
