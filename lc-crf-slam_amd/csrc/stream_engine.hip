@@ -489,6 +489,19 @@ __global__ void __launch_bounds__(kBlock) k_splat2(KernelDev kd, const float2 *_
     reinterpret_cast<float2 *>(kd.val0 + (size_t)f * kd.vstride + kd.vbase)[v] = make_float2(a0, a1);
 }
 
+#ifndef LCCRF_NT_NBR
+#define LCCRF_NT_NBR 1
+#endif
+typedef int lccrf_v4i __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ int4 load_nbr_pair(const int *p)
+{
+#if LCCRF_NT_NBR
+    const lccrf_v4i x = __builtin_nontemporal_load(reinterpret_cast<const lccrf_v4i *>(p));
+#else
+    const lccrf_v4i x = *reinterpret_cast<const lccrf_v4i *>(p);
+#endif
+    return make_int4(x.x, x.y, x.z, x.w);
+}
 // Two vertices per thread: the neighbour pairs (int4), the centres (float4) and the results (float4) move as 16-byte
 // accesses (the frame's value array is laid out so that vertex 2t is 16-byte aligned, see Engine::add_kernel).
 __global__ void __launch_bounds__(kBlock) k_blur2(KernelDev kd, const float *__restrict__ src,
@@ -504,7 +517,7 @@ __global__ void __launch_bounds__(kBlock) k_blur2(KernelDev kd, const float *__r
     float2 *d = reinterpret_cast<float2 *>(dst + (size_t)f * kd.vstride + kd.vbase);
     const int *nbp = kd.nbr + (((size_t)f * kd.D1 + j) * kd.Epad + v) * 2;
     if (v + 1 < V) {
-        const int4 nb = *reinterpret_cast<const int4 *>(nbp);
+        const int4 nb = load_nbr_pair(nbp);               // read once per pass: non-temporal, out of the value array's way in L2
         const float4 c = *reinterpret_cast<const float4 *>(o + v);
         const float2 x0 = o[nb.x], y0 = o[nb.y], x1 = o[nb.z], y1 = o[nb.w];
         *reinterpret_cast<float4 *>(d + v) = make_float4(c.x + 0.5f * (x0.x + y0.x), c.y + 0.5f * (x0.y + y0.y),
