@@ -305,16 +305,22 @@ __global__ void __launch_bounds__(kBlock) k_csr_count(KernelDev kd, const int *_
     atomicAdd(&kd.flag[(size_t)f * (kd.Epad + 1) + kd.offset[(size_t)f * kd.Epad + e]], 1);
 }
 
-// rowmax[f] = longest CSR row of the frame (lets the fused engine pick its splat strategy).
+// rowmax[f] = longest CSR row of the frame (lets the fused engine pick its splat strategy): one atomic per workgroup.
 __global__ void __launch_bounds__(kBlock) k_row_max(KernelDev kd)
 {
+    __shared__ int wave_max[kBlock / 64];
     const int f = blockIdx.y;
     const int v = blockIdx.x * kBlock + threadIdx.x;
     const int *rp = kd.rowptr + (size_t)f * (kd.Epad + 1);
     int m = v < kd.V[f] ? rp[v + 1] - rp[v] : 0;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o, 64));      // one atomic per wavefront, not per vertex
-    if ((threadIdx.x & 63) == 0 && m > 0) atomicMax(&kd.rowmax[f], m);
+    for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) wave_max[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kBlock / 64; ++w) m = max(m, wave_max[w]);
+        if (m > 0) atomicMax(&kd.rowmax[f], m);
+    }
 }
 
 __global__ void __launch_bounds__(kBlock) k_csr_fill(KernelDev kd, const int *__restrict__ n_points)
@@ -654,7 +660,7 @@ void build_kernel_d(const KernelDev &kd, const CrfDev &c, hipStream_t s)
     k_csr_order<<<grid_for(kd.Epad, F), kBlock, 0, s>>>(kd, c.n_points);
     k_csr_sort_long<<<dim3(64, F), kBlock, 0, s>>>(kd);                     // rows of more than kLongRow entries, if any
     (void)hipMemsetAsync(kd.rowmax, 0, (size_t)F * sizeof(int), s);
-    k_row_max<<<grid_for(kd.Epad, F), kBlock, 0, s>>>(kd);
+    if (kd.Epad < 65535) k_row_max<<<grid_for(kd.Epad, F), kBlock, 0, s>>>(kd);   // only the one-workgroup engines ask (u16 ids)
 }
 
 }  // namespace

@@ -19,3 +19,12 @@ print("bf_match 2000 x 2000: median %.1f us" % (np.median(t) * 1e6))
 sys.path.insert(0, "oracle"); import pyoracle as po
 t0 = time.perf_counter(); po.oracle_bf_match(q, tr); print("oracle bf_match: %.1f ms" % ((time.perf_counter() - t0) * 1e3))
 t0 = time.perf_counter(); po.oracle_unary_build(*args); print("oracle unary_build: %.1f us" % ((time.perf_counter() - t0) * 1e6))
+s = wl.pose_scene(2000, seed=3, n_invalid=300)
+pargs = (s["Xw"], s["kp"], s["u_right"], s["inv_sigma2"], s["K4"], s["bf"], s["T_init"])
+for _ in range(5): pkg.pose_optimization(*pargs, valid=s["valid"])
+t = []
+for _ in range(50):
+    t0 = time.perf_counter(); pkg.pose_optimization(*pargs, valid=s["valid"]); t.append(time.perf_counter() - t0)
+print("pose_optimization N=2000 (1700 edges): median %.1f us" % (np.median(t) * 1e6))
+t0 = time.perf_counter(); po.oracle_pose_optimization(s["Xw"], s["kp"], s["u_right"], s["inv_sigma2"], s["valid"], s["K4"], s["bf"], s["T_init"])
+print("oracle pose_optimization: %.1f us" % ((time.perf_counter() - t0) * 1e6))
