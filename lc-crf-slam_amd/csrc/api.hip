@@ -540,6 +540,17 @@ struct HandleCache {
 } g_cache;
 
 int capacity_for(int n) { return std::max(1024, ((n + n / 4 + 511) / 512) * 512); }
+
+// lccrf_pose_optimization's staging area (device + pinned host + stream), one per device, kept between calls: the
+// reference calls Optimizer::PoseOptimization once per frame (src/Tracking.cc:1002) and an allocation costs more than the solve.
+struct PoseStage {
+    std::mutex m;
+    char *d = nullptr, *h = nullptr;
+    size_t cap = 0;
+    hipStream_t stream = nullptr;
+};
+constexpr int kMaxDevices = 64;
+PoseStage g_pose_stage[kMaxDevices];
 }  // namespace
 
 struct lccrf_batch {
@@ -1343,41 +1354,52 @@ int lccrf_pose_optimization(int device_id, int n_points, const float *Xw, const 
     if (n_points && (!Xw || !kp || !u_right || !inv_sigma2 || !outlier_out)) return fail(LCCRF_E_INVALID, "NULL array");
     int rc = use_device(device_id);
     if (rc) return rc;
-    const size_t n = (size_t)std::max(n_points, 1);
-    struct Bufs {                                         // one device arena per call: [Xw | kp | ur | is2 | Tin | Tout | label | valid | outlier | ints]
-        void *p = nullptr;
-        ~Bufs() { if (p) (void)hipFree(p); }
-    } bufs;
+    if (device_id >= kMaxDevices) return fail(LCCRF_E_INVALID, "device_id %d beyond the staging table", device_id);
+    const size_t n = (size_t)std::max(n_points, 1), n16 = (n + 15) & ~(size_t)15;
+    // one staging area per call, laid out the same in pinned host memory and in device memory:
+    //   [Xw | kp | ur | is2 | Tin | Tout | ints (n_points, n_inliers, n_initial, -) | outlier | label | valid]
+    // one copy in (everything), one copy out ([Tout | ints | outlier]), on the context's own stream.
     const size_t off_kp = n * 12, off_ur = off_kp + n * 8, off_is2 = off_ur + n * 4, off_tin = off_is2 + n * 4, off_tout = off_tin + 64,
-                 off_lab = off_tout + 64, off_val = off_lab + ((n * 2 + 15) & ~(size_t)15), off_out = off_val + ((n + 15) & ~(size_t)15),
-                 off_int = off_out + ((n + 15) & ~(size_t)15), total = off_int + 16;
-    HIP_TRY(hipMalloc(&bufs.p, total));
-    char *d = static_cast<char *>(bufs.p);
-    if (n_points) {
-        HIP_TRY(hipMemcpy(d, Xw, (size_t)n_points * 12, hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(d + off_kp, kp, (size_t)n_points * 8, hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(d + off_ur, u_right, (size_t)n_points * 4, hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(d + off_is2, inv_sigma2, (size_t)n_points * 4, hipMemcpyHostToDevice));
-        if (label) HIP_TRY(hipMemcpy(d + off_lab, label, (size_t)n_points * 2, hipMemcpyHostToDevice));
-        if (valid) HIP_TRY(hipMemcpy(d + off_val, valid, (size_t)n_points, hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(d + off_out, outlier_out, (size_t)n_points, hipMemcpyHostToDevice));   // entries of invalid points pass through
+                 off_int = off_tout + 64, off_out = off_int + 16, off_lab = off_out + n16, off_val = off_lab + 2 * n16, total = off_val + n16;
+    PoseStage &ps = g_pose_stage[device_id];
+    std::lock_guard<std::mutex> guard(ps.m);
+    if (ps.cap < total) {
+        if (ps.d) (void)hipFree(ps.d);
+        if (ps.h) (void)hipHostFree(ps.h);
+        ps.d = ps.h = nullptr; ps.cap = 0;
+        const size_t want = std::max<size_t>(total + total / 2, 1 << 16);
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&ps.d), want));
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&ps.h), want));
+        if (!ps.stream) HIP_TRY(hipStreamCreateWithFlags(&ps.stream, hipStreamNonBlocking));
+        ps.cap = want;
     }
-    HIP_TRY(hipMemcpy(d + off_tin, Tcw_in, 64, hipMemcpyHostToDevice));
-    int *ints = reinterpret_cast<int *>(d + off_int);     // n_points, n_inliers, n_initial
-    HIP_TRY(hipMemcpy(ints, &n_points, sizeof(int), hipMemcpyHostToDevice));
+    char *d = ps.d, *h = ps.h;
+    if (n_points) {
+        memcpy(h, Xw, (size_t)n_points * 12);
+        memcpy(h + off_kp, kp, (size_t)n_points * 8);
+        memcpy(h + off_ur, u_right, (size_t)n_points * 4);
+        memcpy(h + off_is2, inv_sigma2, (size_t)n_points * 4);
+        if (label) memcpy(h + off_lab, label, (size_t)n_points * 2);
+        if (valid) memcpy(h + off_val, valid, (size_t)n_points);
+        memcpy(h + off_out, outlier_out, (size_t)n_points);                      // entries of invalid points pass through
+    }
+    memcpy(h + off_tin, Tcw_in, 64);
+    int *hints = reinterpret_cast<int *>(h + off_int);
+    hints[0] = n_points; hints[1] = hints[2] = hints[3] = 0;
+    HIP_TRY(hipMemcpyAsync(d, h, total, hipMemcpyHostToDevice, ps.stream));
+    int *ints = reinterpret_cast<int *>(d + off_int);
     hipError_t er = launch_pose_optimization(1, (int)n, ints, reinterpret_cast<float *>(d), reinterpret_cast<float *>(d + off_kp),
                                              reinterpret_cast<float *>(d + off_ur), reinterpret_cast<float *>(d + off_is2),
                                              valid ? reinterpret_cast<uint8_t *>(d + off_val) : nullptr,
                                              label ? reinterpret_cast<int16_t *>(d + off_lab) : nullptr, K4, bf,
                                              reinterpret_cast<float *>(d + off_tin), reinterpret_cast<float *>(d + off_tout),
-                                             reinterpret_cast<uint8_t *>(d + off_out), ints + 1, ints + 2, nullptr);
+                                             reinterpret_cast<uint8_t *>(d + off_out), ints + 1, ints + 2, ps.stream);
     if (er != hipSuccess) return fail(LCCRF_E_HIP, "pose optimisation: %s", hipGetErrorString(er));
-    HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(Tcw_out, d + off_tout, 64, hipMemcpyDeviceToHost));
-    if (n_points) HIP_TRY(hipMemcpy(outlier_out, d + off_out, (size_t)n_points, hipMemcpyDeviceToHost));
-    int res[3];
-    HIP_TRY(hipMemcpy(res, ints, sizeof(res), hipMemcpyDeviceToHost));
-    if (n_inliers_out) *n_inliers_out = res[1];
+    HIP_TRY(hipMemcpyAsync(h + off_tout, d + off_tout, 64 + 16 + (size_t)n_points, hipMemcpyDeviceToHost, ps.stream));
+    HIP_TRY(hipStreamSynchronize(ps.stream));
+    memcpy(Tcw_out, h + off_tout, 64);
+    if (n_points) memcpy(outlier_out, h + off_out, (size_t)n_points);
+    if (n_inliers_out) *n_inliers_out = hints[1];
     return LCCRF_OK;
 }
 
