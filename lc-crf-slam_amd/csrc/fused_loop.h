@@ -476,9 +476,7 @@ __device__ __forceinline__ void start_inference(PointRegs<PPT, K> &pr, int N, in
     for (int s = 0; s < PPT; ++s) {
         pr.q[s] = make_float2(0.f, 0.f);
         if (tid + s * kNT < N) {
-            float in[2] = {pr.un[s].x, pr.un[s].y}, out[2] = {0.f, 0.f};
-            exp_and_normalize_reg<2>(in, out, -1.0f, 1.0f);
-            pr.q[s] = make_float2(out[0], out[1]);
+            pr.q[s] = softmax2(-pr.un[s].x, -pr.un[s].y, make_float2(0.f, 0.f), 1.0f);   // scale = -1 is an exact negation
         }
     }
 }
@@ -500,9 +498,7 @@ __device__ __forceinline__ void mean_field(unsigned char *smem, const FusedLayou
             nx[0] += pr.wn[s][k] * t.x;                           // pairwise3d.h:77
             nx[1] += pr.wn[s][k] * t.y;
         }
-        float out[2] = {pr.q[s].x, pr.q[s].y};
-        exp_and_normalize_reg<2>(nx, out, 1.0f, relax);
-        pr.q[s] = make_float2(out[0], out[1]);
+        pr.q[s] = softmax2(nx[0], nx[1], pr.q[s], relax);        // densecrf3d.h:70-98 with L = 2: one exp, not two
     };
     if (kFuseXP && PPT <= 2 && lay.prod_all) {            // (3-4 points per lane: the fused form costs registers the loop does not have)
         // Every kernel owns its product buffer: a point's next products go out right behind its softmax, so one
