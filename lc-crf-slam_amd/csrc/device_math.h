@@ -165,13 +165,17 @@ __device__ __forceinline__ float fast_exp(float x)          // densecrf3d.h:55-6
 //   * the reference then squares `mult` (<= 5) times.
 __device__ __forceinline__ float fast_exp_nonpos(float x)
 {
+    // The cascade "a > 5.52 ? a/8, a > 2.76 ? a/4, a > 0.69 ? a/2, a > 0.69 ? a/2" only ever scales by exact powers of two
+    // and kFe4 == 4 kFe1, kFe8 == 8 kFe1 exactly (rounding commutes with scaling by 2^n), so every one of its compares is a
+    // compare of the ORIGINAL a against a power-of-two multiple of kFe1, and for a <= 20 the number of halvings is
+    //     mult = [a > kFe1] + [a > 2 kFe1] + [a > 4 kFe1] + [a > 8 kFe1] + [a > 16 kFe1]
+    // (0.69 | 1.38 | 2.76 | 5.52 | 11.04: e.g. 5.52 < a <= 11.04 takes /8, not /4 since a/8 <= 1.38, then one /2),
+    // the reduced argument a * 2^-mult: five compares and one v_ldexp_f32 instead of four compare-select-multiply rounds.
+    static_assert(kFe4 == 4.0f * kFe1 && kFe8 == 8.0f * kFe1, "thresholds are power-of-two multiples of one another");
     float a = -x;
     const bool cut = a > 20;
-    int mult = 0;
-    { const bool c = a > kFe8; a = c ? a * 0.125f : a; mult += c ? 3 : 0; }
-    { const bool c = a > kFe4; a = c ? a * 0.25f : a;  mult += c ? 2 : 0; }
-    { const bool c = a > kFe1; a = c ? a * 0.5f : a;   mult += c ? 1 : 0; }
-    { const bool c = a > kFe1; a = c ? a * 0.5f : a;   mult += c ? 1 : 0; }
+    const int mult = (a > kFe1 ? 1 : 0) + (a > 2.0f * kFe1 ? 1 : 0) + (a > kFe4 ? 1 : 0) + (a > kFe8 ? 1 : 0) + (a > 16.0f * kFe1 ? 1 : 0);
+    a = __builtin_amdgcn_ldexpf(a, -mult);
     float r = very_fast_exp(a);
 #pragma unroll
     for (int i = 0; i < 5; ++i) r = (i < mult) ? r * r : r;
@@ -226,9 +230,20 @@ __device__ __forceinline__ float2 softmax2(float a, float b, float2 old, float r
 {
     const bool lt = a < b;                            // mx = b iff a < b (densecrf3d.h:76-79)
     const float e = fast_exp_nonpos(lt ? a - b : b - a);
-    const float v0 = lt ? e : 1.0f, v1 = lt ? 1.0f : e;
-    const float tt = v0 + v1;
-    const float p0 = v0 / tt, p1 = v1 / tt;
+    const float tt = 1.0f + e;                        // v0 + v1 with one of them exactly 1 (fp32 addition commutes)
+    // The two IEEE divisions 1/tt and e/tt, written out: tt is in [1, 2] and e in {0} U [2^-29, 1], a range in which
+    // hipcc's own expansion of x/y (v_div_scale, v_rcp, Newton step, quotient + two residual corrections, v_div_fmas,
+    // v_div_fixup) scales nothing and fixes nothing up -- what is left is this sequence, with the refined reciprocal
+    // shared by both quotients (13 instructions instead of 22; same bits, tests compare Q bit for bit).
+    const float r0 = __builtin_amdgcn_rcpf(tt);
+    const float r = __builtin_fmaf(__builtin_fmaf(-tt, r0, 1.0f), r0, r0);
+    auto quot = [&](float n) {
+        const float q = n * r;
+        const float q2 = __builtin_fmaf(__builtin_fmaf(-tt, q, n), r, q);
+        return __builtin_fmaf(__builtin_fmaf(-tt, q2, n), r, q2);
+    };
+    const float pm = quot(1.0f), pe = quot(e);
+    const float p0 = lt ? pe : pm, p1 = lt ? pm : pe;
     if (relax == 1) return make_float2(p0, p1);
     return make_float2((1 - relax) * old.x + relax * p0, (1 - relax) * old.y + relax * p1);
 }

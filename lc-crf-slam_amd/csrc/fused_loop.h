@@ -445,8 +445,9 @@ __device__ __forceinline__ float2 slice_point(const unsigned char *smem, const F
     const float2 *val = reinterpret_cast<const float2 *>(smem + lay.val[k][kD1 & 1]);
     const float2 x0 = val[pr.ix[s][k][0] & 0xffffu], x1 = val[pr.ix[s][k][0] >> 16], x2 = val[pr.ix[s][k][1] & 0xffffu];
     const float w0 = pr.bary[s][k][0] * alpha, w1 = pr.bary[s][k][1] * alpha, w2 = pr.bary[s][k][2] * alpha;   // permutohedral_cpu.h:689
-    float t0 = 0.0f, t1 = 0.0f;
-    t0 += w0 * x0.x; t1 += w0 * x0.y;
+    // permutohedral_cpu.h:686-693 starts its sum at 0.  0 + x == x bit for bit unless x is -0, and a -0 here could only turn
+    // the sign of a sum that is zero anyway -- which neither the energies nor the softmax downstream can tell apart
+    float t0 = w0 * x0.x, t1 = w0 * x0.y;
     t0 += w1 * x1.x; t1 += w1 * x1.y;
     t0 += w2 * x2.x; t1 += w2 * x2.y;
     return make_float2(t0, t1);
