@@ -235,3 +235,49 @@ def test_frame_kernel_many_copies_are_identical(wl):
         else:
             assert cc.same_bits(Q[:3], ref[0]) and np.array_equal(M[:3], ref[1])
     b.close()
+
+
+@pytest.mark.parametrize("N", [2000, 4096])
+def test_two_label_softmax_dense_sweep(po, wl, N):
+    """The loop's two-label softmax (one polynomial exp, range reduction by compares + ldexp, two divisions sharing a
+    refined reciprocal -- csrc/device_math.h: softmax2, fast_exp_nonpos) against the restatement of expAndNormalize
+    (densecrf3d.h:51-98) on ~10^6 energy pairs: every fast_exp threshold (0.69 * 2^k) and the cut-off at 20 to within
+    +-8 ulp, denormal and zero differences, log-uniform differences up to 25, both orders, random common offsets.
+    A pairwise kernel of weight 0 makes next = -unary exactly, so Q after any number of iterations is that softmax --
+    through the one-launch kernel and through the inference kernel on built lattices."""
+    rng = np.random.default_rng(N)
+    F = 256
+    total = F * N
+    special = []
+    for t in [0.69 * 2 ** k for k in range(0, 6)] + [20.0, 1.0, 2.0, 0.5]:
+        c = np.float32(t)
+        ulps = np.arange(-8, 9)
+        special.append((c.view(np.int32) + ulps).astype(np.int32).view(np.float32))
+        special.append((np.float32(np.float64(t)).view(np.int32) + ulps + 1).astype(np.int32).view(np.float32))
+    special.append(np.float32([0.0, 1e-45, 1e-40, 1e-38, 1.1754944e-38, 1e-30, 1e-20, 19.999999, 20.000002, 21.0, 25.0, 80.0]))
+    special = np.concatenate(special).astype(np.float32)
+    d = np.exp(rng.uniform(np.log(1e-8), np.log(25.0), total)).astype(np.float32)
+    d[:special.size] = special
+    d[special.size:2 * special.size] = special
+    base = rng.uniform(0.0, 3.0, total).astype(np.float32)
+    base[:special.size] = 0.0                               # the differences themselves, exactly
+    flip = rng.integers(0, 2, total).astype(bool)
+    flip[:special.size] = False
+    flip[special.size:2 * special.size] = True
+    un = np.empty((total, 2), np.float32)
+    un[:, 0] = np.where(flip, base + d, base)
+    un[:, 1] = np.where(flip, base, base + d)
+    expect = np.zeros_like(un)
+    po.oracle_lib().orc_exp_and_normalize(expect.ctypes.data_as(po._f32p), un.ctypes.data_as(po._f32p), total, 2, -1.0, 1.0)
+    feats = rng.uniform(0.0, 30.0, (F, N, 2)).astype(np.float32)
+    b = pkg.BatchCRF(F, N, 2, [2], [0.0])
+    b.set_inputs_host([N] * F, [feats], unary=un.reshape(F, N, 2))
+    b.run(2, True)
+    assert b.engine() == 3
+    assert cc.same_bits(b.probability().reshape(total, 2), expect)
+    assert np.array_equal(b.map().reshape(total), (expect[:, 1] > expect[:, 0]).astype(np.int16))
+    b.build()
+    b.inference(3, True)
+    assert b.engine() == 2
+    assert cc.same_bits(b.probability().reshape(total, 2), expect)
+    b.close()
