@@ -275,7 +275,9 @@ int  lccrf_bf_match(int device_id, int n_query, const uint8_t *desc_query, int n
  *                     Tracking::DynamicDetectionWithCRF (Tracking.cc:1945-1955) and contributes no edge
  *   K4                fx fy cx cy;  bf = mbf;  Tcw row-major 4x4 float (pFrame->mTcw in, SetPose out)
  *   outlier_out [n]   mvbOutlier (entries of points without an edge are left as they were)
- *   n_inliers_out     the return value nInitialCorrespondences - nBad (0 with < 3 correspondences: pose untouched)  */
+ *   n_inliers_out     the return value nInitialCorrespondences - nBad (0 with < 3 correspondences: pose untouched)
+ * Synchronous, host arrays in and out; thread-safe (calls on one device share a cached staging area and take turns);
+ * at most 16384 keypoints (up to 4096 the frame's edges are staged in LDS).                                        */
 int  lccrf_pose_optimization(int device_id, int n_points, const float *Xw, const float *kp, const float *u_right,
                              const float *inv_sigma2, const uint8_t *valid, const int16_t *label, const float *K4,
                              float bf, const float *Tcw_in, float *Tcw_out, uint8_t *outlier_out,
