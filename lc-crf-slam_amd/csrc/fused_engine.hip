@@ -142,13 +142,17 @@ __global__ void __launch_bounds__(kNT) k_fused(CrfDev c, FusedArgs a)
             reinterpret_cast<float2 *>(smem + lay.val[k][1])[0] = make_float2(0.f, 0.f);
         }
     }
-    start_inference(pr, N, tid);
     __syncthreads();
     FL_PSTAMP();
 
-    place_products<PPT, K, CH>(smem, lay, N, tid, pk, pr);
+    // The lattice tables were requested first and are in LDS now; the per-point records (unary, pk, bary, norm) are still
+    // on their way.  Rank the chain rows (four barriers, LDS atomics -- needs the row table only) before anything touches
+    // a point record, so that this work runs under the tail of the loads instead of behind it.
     ChainLane cl{0u, 0u};
     if (CH != 0 && chain_k<CH>(lay, 0)) cl = chain_setup(smem, lay, V[0], tid);
+    FL_PSTAMP();
+    start_inference(pr, N, tid);
+    place_products<PPT, K, CH>(smem, lay, N, tid, pk, pr);
     FL_STAMP();
 
     float alpha[K];
