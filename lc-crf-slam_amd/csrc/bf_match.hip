@@ -10,9 +10,9 @@
 // apart from the one double comparison, so results are exact.  PARITY UNPINNED against a real OpenCV
 // build; checked against the oracle's scalar restatement (oracle/lccrf_oracle.c: orc_bf_match).
 //
-// Layout: 4 lanes per query, each scanning a quarter of the train descriptors staged in LDS in
-// tiles; candidates are (distance << 22 | train index) keys, so "lexicographically smaller" is one
-// unsigned compare and the four partial top-2 lists merge with two shuffles.
+// Layout: 16 lanes per query (2000 queries fill 125 workgroups instead of 32), each scanning a sixteenth of the train
+// descriptors staged in LDS in tiles; candidates are (distance << 22 | train index) keys, so "lexicographically
+// smaller" is one unsigned compare and the sixteen partial top-2 lists merge with four shuffles.
 #include "engine.h"
 
 #include <cstring>
@@ -22,7 +22,8 @@ namespace lccrf {
 
 namespace {
 
-constexpr int kQPB = 64;                  // queries per block (x 4 lanes)
+constexpr int kLPQ = 16;                  // lanes per query
+constexpr int kQPB = 16;                  // queries per block (x kLPQ lanes)
 constexpr int kTile = 1024;               // train descriptors per LDS tile (32 KB)
 constexpr unsigned kNone = 0xffffffffu;
 
@@ -32,31 +33,31 @@ __device__ __forceinline__ void top2_insert(unsigned key, unsigned &k0, unsigned
     else if (key < k1) k1 = key;
 }
 
-__global__ void __launch_bounds__(kQPB * 4) k_bf_match(const uint4 *__restrict__ query, int n_query,
+__global__ void __launch_bounds__(kQPB * kLPQ) k_bf_match(const uint4 *__restrict__ query, int n_query,
                                                         const uint4 *__restrict__ train, int n_train, double ratio,
                                                         int *__restrict__ out, int *__restrict__ n_matches)
 {
     __shared__ uint4 tile[kTile * 2];
-    const int tid = threadIdx.x, sub = tid & 3;
-    const int q = blockIdx.x * kQPB + (tid >> 2);
+    const int tid = threadIdx.x, sub = tid & (kLPQ - 1);
+    const int q = blockIdx.x * kQPB + tid / kLPQ;
     uint4 qa = make_uint4(0, 0, 0, 0), qb = qa;
     if (q < n_query) { qa = query[2 * (size_t)q]; qb = query[2 * (size_t)q + 1]; }
     unsigned k0 = kNone, k1 = kNone;
     for (int t0 = 0; t0 < n_train; t0 += kTile) {
         const int nt = min(kTile, n_train - t0);
         __syncthreads();
-        for (int i = tid; i < 2 * nt; i += kQPB * 4) tile[i] = train[2 * (size_t)t0 + i];
+        for (int i = tid; i < 2 * nt; i += kQPB * kLPQ) tile[i] = train[2 * (size_t)t0 + i];
         __syncthreads();
-        for (int t = sub; t < nt; t += 4) {
+        for (int t = sub; t < nt; t += kLPQ) {
             const uint4 a = tile[2 * t], b = tile[2 * t + 1];
             const int d = __popc(qa.x ^ a.x) + __popc(qa.y ^ a.y) + __popc(qa.z ^ a.z) + __popc(qa.w ^ a.w) +
                           __popc(qb.x ^ b.x) + __popc(qb.y ^ b.y) + __popc(qb.z ^ b.z) + __popc(qb.w ^ b.w);
             top2_insert(((unsigned)d << 22) | (unsigned)(t0 + t), k0, k1);
         }
     }
-    // merge the four lanes of a query (xor 1, xor 2)
+    // merge the lanes of a query (xor 1, 2, 4, 8)
 #pragma unroll
-    for (int o = 1; o <= 2; o <<= 1) {
+    for (int o = 1; o < kLPQ; o <<= 1) {
         const unsigned p0 = (unsigned)__shfl_xor((int)k0, o), p1 = (unsigned)__shfl_xor((int)k1, o);
         top2_insert(p0, k0, k1);
         top2_insert(p1, k0, k1);
@@ -123,7 +124,7 @@ hipError_t run_bf_match(int device_id, int n_query, const uint8_t *desc_query, i
     int *out = reinterpret_cast<int *>(g_bf.host + total_in);
     out[n_query] = 0;                                     // the match counter (host write, visible to the kernel launched below)
     if ((e = hipMemcpyAsync(g_bf.dev, g_bf.host, total_in, hipMemcpyHostToDevice, s)) != hipSuccess) return e;
-    k_bf_match<<<dim3((n_query + kQPB - 1) / kQPB), dim3(kQPB * 4), 0, s>>>(
+    k_bf_match<<<dim3((n_query + kQPB - 1) / kQPB), dim3(kQPB * kLPQ), 0, s>>>(
         reinterpret_cast<const uint4 *>(g_bf.dev), n_query, reinterpret_cast<const uint4 *>(g_bf.dev + bq), n_train, ratio,
         out, out + n_query);
     if ((e = hipGetLastError()) != hipSuccess) return e;
