@@ -664,6 +664,16 @@ int lccrf_trim_cache(void)
         h->eng.destroy();
         delete h;
     }
+    for (int d = 0; d < kMaxDevices; ++d) {               // the pose-optimisation staging areas
+        PoseStage &ps = g_pose_stage[d];
+        std::lock_guard<std::mutex> g(ps.m);
+        if (!ps.d && !ps.h && !ps.stream) continue;
+        (void)hipSetDevice(d);
+        if (ps.stream) { (void)hipStreamSynchronize(ps.stream); (void)hipStreamDestroy(ps.stream); }
+        if (ps.d) (void)hipFree(ps.d);
+        if (ps.h) (void)hipHostFree(ps.h);
+        ps.d = ps.h = nullptr; ps.stream = nullptr; ps.cap = 0;
+    }
     return (int)v.size();
 }
 

@@ -110,3 +110,19 @@ def test_hip_pose_optimization_reads_the_crf_labels_on_the_device(po, wl):
         assert int(dn0[f]) == n0 == int(static.sum()) and int(dni[f]) == no
         assert np.array_equal(dout[f].cpu().numpy()[static == 1], oo[static == 1])
         assert np.abs(dTo[f].cpu().numpy().reshape(4, 4) - To).max() < 1e-6
+
+
+@pytest.mark.gpu
+def test_hip_pose_optimization_survives_trim_and_growth(po, wl):
+    """The single-frame entry point keeps a staging area between calls: growing it, freeing it (lccrf_trim_cache) and calling
+    again must give the same answers."""
+    out = []
+    for n in (300, 3000, 300):
+        s = wl.pose_scene(n, seed=77)
+        out.append(pkg.pose_optimization(s["Xw"], s["kp"], s["u_right"], s["inv_sigma2"], s["K4"], s["bf"], s["T_init"], valid=s["valid"]))
+        if n == 3000:
+            pkg.lib().lccrf_trim_cache()
+    assert np.array_equal(out[0][0], out[2][0]) and np.array_equal(out[0][1], out[2][1]) and out[0][2] == out[2][2]
+    s = wl.pose_scene(3000, seed=77)
+    To, oo, no, _ = _run_oracle(po, s)
+    assert out[1][2] == no and np.array_equal(out[1][1][s["valid"] == 1], oo[s["valid"] == 1])
