@@ -357,6 +357,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the c5 and single-frame-latency records")
+    ap.add_argument("--serial-gather", action="store_true",
+                    help="N > 1: wait for each step's label gather before the next launch instead of overlapping them")
     ap.add_argument("--distinct", type=int, default=64, help="distinct synthetic frames tiled into the batch")
     ap.add_argument("--rehearse-cpu", action="store_true", help="launcher test: gloo, no GPU, no compute, no metric")
     args = ap.parse_args()
@@ -424,11 +426,23 @@ def main():
 
     bits_ptr, words = b.device_label_bits()
     bits_view = torch.as_tensor(CudaView(bits_ptr, (F, words), "<i8"), device=dev)
-    gathered = torch.empty((world * F, words), dtype=torch.int64, device=dev)
-    # the library's kernels and the collective share torch's current stream: ordering without host round trips
+    # The label gather of step i overlaps the inference of step i+1: the bits a launch wrote are copied (2 MB, device to
+    # device) into one of two staging buffers on the compute stream, and the all_gather of that buffer runs asynchronously
+    # on the collective's own stream -- the next launch may overwrite the library's bit buffer meanwhile.  A staging
+    # buffer is reused only after the gather that read it has been waited for (stream-side wait, no host round trip).
+    n_stage = 2 if (world > 1 and not args.serial_gather) else 1
+    stage = [torch.empty((F, words), dtype=torch.int64, device=dev) for _ in range(n_stage)]
+    gathered_bufs = [torch.empty((world * F, words), dtype=torch.int64, device=dev) for _ in range(n_stage)]
+    pending = [None] * n_stage
+    # the library's kernels, the staging copy and the collective's wait all go through torch's current stream
     stream = torch.cuda.current_stream(dev).cuda_stream
+    step_no = [0]
 
     def barrier():
+        for k, w in enumerate(pending):             # every gather of the timed region has finished when the clock stops
+            if w is not None:
+                w.wait()
+                pending[k] = None
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -436,7 +450,15 @@ def main():
     def step():
         b.inference(n_iter, True, stream=stream)
         if world > 1:                               # the one collective of the path: the label gather, every batch (RCCL)
-            sh.gather_label_bits(bits_view, out=gathered)
+            if args.serial_gather:
+                sh.gather_label_bits(bits_view, out=gathered_bufs[0])
+            else:
+                k = step_no[0] % n_stage
+                if pending[k] is not None:
+                    pending[k].wait()
+                stage[k].copy_(bits_view, non_blocking=True)
+                pending[k] = dist.all_gather_into_tensor(gathered_bufs[k], stage[k], async_op=True)
+        step_no[0] += 1
 
     for _ in range(args.warmup):                    # (RCCL sets its rings up on first use)
         step()
@@ -446,6 +468,7 @@ def main():
         step()
     barrier()
     t1 = time.perf_counter()
+    gathered = gathered_bufs[(step_no[0] - 1) % n_stage]
     dt = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(dt, op=dist.ReduceOp.MAX)
@@ -553,7 +576,7 @@ def main():
                        "n_iters": n_iter, "n_labels": L, "kernel_dims": dims, "mean_lattice_vertices": Vs,
                        "engine": {1: "streaming", 2: "fused"}.get(engine, str(engine)),
                        "sharding": "frames over ranks, no data-path collective; one RCCL all_gather of the bit-packed "
-                                   "labels per step (%d bytes per rank)" % (F * words * 8)},
+                                   "labels per step (%d bytes per rank), %s" % (F * words * 8, "serial" if args.serial_gather else "overlapped with the next step's launch (double-buffered)")},
             "roofline": roof,
             "build_ms_per_batch": build_ms,
             "frames_per_s_end_to_end": (F * world / (run_ms * 1e-3)) if (run_ms and run_engine == 3) else F * world / ((build_ms + inf_ms) * 1e-3),
