@@ -39,7 +39,7 @@ N_CU, CLK_HZ = 256, 2.4e9
 LDS_RATE = {"read_b64": 256.0, "read_b128": 256.0, "read_b32": 128.0, "read_u16": 64.0,
             "write_b32": 64.0, "write_b64": 85.0}
 
-DEFAULT_FRAMES = 8192          # sized for 288 GB of HBM: throughput still grows with frames in flight (4096: -4 %, 16384: +1 %)
+DEFAULT_FRAMES = 16384         # sized for 288 GB of HBM: throughput still grows with frames in flight (4096: -5 %, 8192: -2 %, 32768: +1 %)
 
 WORKLOADS = {
     # name: (N, n_iter, obs_cap, description)
@@ -401,7 +401,7 @@ def main():
 
     name = args.workload
     N, n_iter, _, desc = WORKLOADS[name]
-    F = args.frames or (1 if name == "c5" else DEFAULT_FRAMES)   # frames in flight per GPU: 32 full waves of workgroups on 256 CUs, ~5.6 GB
+    F = args.frames or (1 if name == "c5" else DEFAULT_FRAMES)   # frames in flight per GPU: 64 full waves of workgroups on 256 CUs, ~11 GB
     distinct = 1 if name == "c5" else min(F, args.distinct)
     pbs, idx, feats, label, dims, weights = make_batch(wl, name, F, rank, distinct)
     L = 2
