@@ -528,3 +528,41 @@ def test_streaming_engine_xcd_aware_grid_with_many_frames(po, wl):
         o = cc.setup(po.OracleCRF, pb)
         o.inference_native(4, True)
         assert cc.same_bits(Q[f, :pb["N"]], o.probability()) and np.array_equal(M[f, :pb["N"]], o.map()), f
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("d_list,L", [([6], 2), ([3, 2], 3), ([1, 4], 2)])
+def test_large_ragged_batch_matches_oracle(po, wl, d_list, L):
+    """A ragged batch of large frames (up to 9000 points: hash tables, scans and CSR far beyond the one-workgroup engines)
+    with mixed feature dimensions and label counts on the streaming engine: lattice sizes, Q and labels against the oracle,
+    bit for bit.  (Written for an experiment that numbered vertices along a Z-order curve -- notes/r2_experiments.md --
+    and kept: results must not depend on how a build numbers its vertices.)"""
+    sizes = [9000, 8192, 0, 4097, 9000]
+    F, maxN = len(sizes), 9000
+    pbs = [wl.generic_problem(n, d_list, L, seed=300 + i, spread=3.0) for i, n in enumerate(sizes)]
+    feats = [np.zeros((F, maxN, d), np.float32) for d in d_list]
+    unary = np.zeros((F, maxN, L), np.float32)
+    for f, pb in enumerate(pbs):
+        n = pb["N"]
+        unary[f, :n] = pb["unary"]
+        for k in range(len(d_list)):
+            feats[k][f, :n] = pb["kernels"][k][0]
+    ws = [float(pbs[0]["kernels"][k][1]) for k in range(len(d_list))]
+    b = pkg.BatchCRF(F, maxN, L, d_list, ws)
+    b.set_inputs_host(sizes, feats, unary=unary)
+    b.build()
+    b.inference(3, True, relax=0.9)
+    Q, M = b.probability(), b.map()
+    for f, pb in enumerate(pbs):
+        n = pb["N"]
+        if n == 0:
+            continue
+        pbw = dict(pb, kernels=[(pb["kernels"][k][0], np.float32(ws[k])) for k in range(len(d_list))])
+        o = cc.setup(po.OracleCRF, pbw)
+        o.inference_native(3, True, 0.9)
+        for k in range(len(d_list)):
+            assert int(b.lattice_sizes(k)[f]) == o.kernel(k)["V"], (f, k)
+        assert cc.same_bits(Q[f, :n], o.probability()), f
+        assert np.array_equal(M[f, :n], o.map()), f
+        o.close()
+    b.close()
