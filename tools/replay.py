@@ -65,8 +65,11 @@ def replay(path, batch=256, device=0, engine=0):
         b = pkg.BatchCRF(F, maxn, 2, [2, 2], [float(p0["w1"]), float(p0["w2"])], device=device)
         b.set_engine(engine)
         b.set_inputs_host(sizes, feats, label=label, conf=float(p0["confidence"]))
-        b.build()
-        b.inference(int(group[0]["n_iterations"]), True)
+        if engine == 0:
+            b.run(int(group[0]["n_iterations"]), True)          # one launch per frame (lattice build + inference)
+        else:
+            b.build()
+            b.inference(int(group[0]["n_iterations"]), True)
         M, Q = b.map(), b.probability()
         t_gpu += time.perf_counter() - t0
         b.close()
