@@ -48,7 +48,10 @@ WORKLOADS = {
     "c3": (2000, 10, 10, "C3: 2000 keypoints, 10 iters, <=10 observations/point, L=2"),
     "c4": (3000, 5, None, "C4: 3000 keypoints, 5 iters, frames in flight, L=2"),
     "c5": (100000, 20, None, "C5: 100k points, one 6-D bilateral kernel, 20 iters, L=2"),
+    # not a BASELINE.json config: the size live SLAM mostly sees (N = matched, observed map points, "typically hundreds")
+    "n500": (500, 5, None, "N500: 500 keypoints (live-SLAM-typical), 5 iters, two 2-D kernels (TUM3.yaml), L=2"),
 }
+SUB_FRAMES = {"c1": 16384, "c3": 8192, "c4": 8192, "n500": 32768}    # frames in flight of the sub-records of the default line
 
 
 def algorithmic_bytes_per_iter(N, L, dims, Vs):
@@ -193,35 +196,133 @@ def single_frame_latency(pkg, pbs, n_iter, reps=240):
     """The plug-in surface as Tracking::DynamicDetectionWithCRF uses it (src/Tracking.cc:1920-1930):
     construct, setUnaryEnergyFromLabel, two kernels, inference(5, true), getMap, destroy -- host buffers in,
     host buffers out, one frame at a time.  Median over `reps` frames, through the ctypes binding, for this
-    library and for the reference's CPU path."""
+    library and for the reference's CPU path; for this library also where the time goes: host time of every call
+    (`api`: everything that only stages inputs; `launch`: inference(), which queues the one kernel; `wait`: getMap(),
+    i.e. launch latency + kernel + completion signal as seen by the host) and the kernel's own duration by HIP events."""
     import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import pyoracle as po
 
-    def one(cls, pb, native):
+    def one(cls, pb, native, stamps=None):
         t0 = time.perf_counter()
         c = cls(pb["N"], pb["L"])
         c.set_unary_from_label(pb["label"], pb["conf"])
         for f, w in pb["kernels"]:
             c.add_pairwise(f, w)
+        t1 = time.perf_counter()
         (c.inference_native if native else c.inference)(n_iter, True)
+        t2 = time.perf_counter()
         m = c.map()
+        t3 = time.perf_counter()
         c.close()
-        return (time.perf_counter() - t0) * 1e6, m
+        t4 = time.perf_counter()
+        if stamps is not None:
+            stamps.append((t1 - t0, t2 - t1, t3 - t2, t4 - t3))
+        return (t4 - t0) * 1e6, m
 
     out = {"n_points": pbs[0]["N"], "n_iters": n_iter, "reps": reps,
            "what": "construct + unary + 2 kernels (lattice + norm) + inference + getMap + destroy, host to host, via ctypes"}
     ref_cls = po.RefCRF if po.have_ref() else po.OracleCRF
     for key, cls, native in (("hip", pkg.DenseCRFHIP, False), ("cpu_reference", ref_cls, True)):
-        ts = []
+        ts, stamps = [], []
         for r in range(reps + 10):
-            t, m = one(cls, pbs[r % len(pbs)], native)
+            t, m = one(cls, pbs[r % len(pbs)], native, stamps if key == "hip" else None)
             if r >= 10:
                 ts.append(t)
         out[key] = float(np.median(ts))
         out[key + "_p90"] = float(np.percentile(ts, 90))
+        if key == "hip":
+            st = np.array(stamps[10:]) * 1e6
+            med = np.median(st, axis=0)
+            out["hip_breakdown_us"] = {"api_create_unary_kernels": float(med[0]), "launch_inference_call": float(med[1]),
+                                       "wait_getMap": float(med[2]), "api_destroy": float(med[3])}
+    # the kernel alone: the same frame as a 1-frame batch through lccrf_batch_run, HIP events around the launch
+    pb = pbs[0]
+    b = pkg.BatchCRF(1, pb["N"], 2, [f.shape[1] for f, _ in pb["kernels"]], [float(w) for _, w in pb["kernels"]])
+    b.set_inputs_host([pb["N"]], [f[None] for f, _ in pb["kernels"]], label=pb["label"][None], conf=pb["conf"])
+    ks = []
+    for r in range(30):
+        b.run(n_iter, True)
+        ks.append(b.last_timing()["inference_ms"] * 1e3)
+    b.close()
+    out["hip_breakdown_us"]["kernel_k_frame_hip_events"] = float(np.median(ks[5:]))
     out["cpu_reference_kind"] = "reference" if po.have_ref() else "port"
     return out
+
+
+def slam_subrecord(pkg, wl, torch, dev, name, steps=10, warmup=3, distinct=32):
+    """One more SLAM-shaped configuration, timed exactly like the headline (lccrf_batch_inference over F frames resident
+    in HBM, wall clock over `steps` back-to-back batches, HIP events for the launch) -- the default line's C1 / C3 / C4 /
+    N500 sub-records, so that every configuration of BASELINE.json is driver-timed."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pyoracle as po
+    N, n_iter, _, desc = WORKLOADS[name]
+    F = SUB_FRAMES[name]
+    pbs, idx, feats, label, dims, weights = make_batch(wl, name, F, 0, distinct)
+    d_feats = [torch.from_numpy(f).to(dev) for f in feats]
+    d_label = torch.from_numpy(label).to(dev)
+    d_np = torch.full((F,), N, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    b = pkg.BatchCRF(F, N, 2, dims, weights, device=dev.index)
+    b.bind_inputs_device(F, d_np.data_ptr(), [t.data_ptr() for t in d_feats], d_label=d_label.data_ptr(), conf=pbs[0]["conf"])
+    b.build(); b.synchronize(); b.build(); b.synchronize()
+    build_ms = b.last_timing()["build_ms"]
+    engine = b.engine()
+    Vs = [float(b.lattice_sizes(k).astype(np.float64).mean()) for k in range(len(dims))]
+    for _ in range(warmup):
+        b.inference(n_iter, True)
+    b.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        b.inference(n_iter, True)
+    b.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    ms = []
+    for _ in range(5):
+        b.inference(n_iter, True)
+        ms.append(b.last_timing()["inference_ms"])
+    inf_ms = float(np.median(ms))
+    M, Q = b.map(), b.probability()
+    same = tot = 0
+    max_dq = 0.0
+    for i in range(2):
+        pb = pbs[i]
+        o = po.OracleCRF(pb["N"], pb["L"])
+        o.set_unary_from_label(pb["label"], pb["conf"])
+        for f, w in pb["kernels"]:
+            o.add_pairwise(f, w)
+        o.inference_native(n_iter, True)
+        same += int((M[idx.index(i)] == o.map()).sum())
+        tot += pb["N"]
+        max_dq = max(max_dq, float(np.abs(Q[idx.index(i)] - o.probability()).max()))
+        o.close()
+    for _ in range(2):
+        b.run(n_iter, True)
+    b.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(max(steps // 2, 3)):
+        b.run(n_iter, True)
+    b.synchronize()
+    run_ms = (time.perf_counter() - t0) / max(steps // 2, 3) * 1e3
+    run_engine, fb = b.engine(), b.fallback_frames()
+    lds_bytes, lds_clocks, _ = fused_lds_model(N, dims, Vs, True)
+    t_floor = lds_clocks * n_iter * F / N_CU / CLK_HZ
+    achieved = lds_bytes * n_iter * F / (inf_ms * 1e-3) / 1e9
+    peak = lds_bytes * n_iter * F / t_floor / 1e9
+    rec = {"workload": desc, "frames_in_flight": F, "value": F * n_iter / dt, "unit": "iters/s", "ms_per_step": dt * 1e3,
+           "engine": {1: "streaming", 2: "fused"}.get(engine, str(engine)), "mean_lattice_vertices": Vs,
+           "roofline": {"bound": "lds" if engine == 2 else "hbm", "achieved": achieved, "peak": peak, "unit": "GB/s",
+                        "frac": achieved / peak, "launch_ms": inf_ms, "lds_bytes_per_iteration_frame": lds_bytes,
+                        "algorithmic_hbm_bytes_per_iteration_frame": algorithmic_bytes_per_iter(N, 2, dims, Vs)},
+           "build_ms_per_batch": build_ms,
+           "end_to_end": {"one_launch_ms_per_batch": run_ms, "one_launch_engine": run_engine, "fallback_frames": fb,
+                          "frames_per_s": F / (run_ms * 1e-3), "two_kernel_ms_per_batch": build_ms + inf_ms},
+           "label_match_vs_cpu_reference": same / tot, "max_abs_dQ_vs_cpu_reference": max_dq}
+    b.close()
+    del d_feats, d_label, d_np
+    torch.cuda.empty_cache()
+    return rec
 
 
 def c5_record(pkg, wl, torch, dev, steps=6, frames=8):
@@ -268,11 +369,25 @@ def c5_record(pkg, wl, torch, dev, steps=6, frames=8):
                                                     "inference (9 launches per iteration: splat, 7 blur passes, slice + softmax)"}}
         if F == frames:
             blur_ms, nv = b.time_blur_pass(0, 40)
-            blur_bytes = 40.0 * nv                      # (d+1) x (8 V L + 8 V) per iteration = 40 B per vertex and pass at L = 2
+            # (d+1) x (8 V L + 8 V) per iteration = 24 B per vertex and pass at L = 2 (values read + written once,
+            # the neighbour pair read once; "gathers assumed cached").  What the lanes REQUEST is 40 B per vertex and pass
+            # (centre, two neighbour values, the pair, the store): kept beside it, never as `frac`.
+            blur_bytes = 24.0 * nv
+            tag = latest_profile("stream_c5")
+            traffic = pmc_traffic(tag, "k_blur2") if F == 8 else None
+            traffic_raw = pmc_traffic(tag, "k_blur2", corrected=False) if F == 8 else None
+            gbs = blur_bytes / (blur_ms * 1e-3) / 1e9
             rec["roofline"] = {"bound": "hbm", "kernel": "k_blur2 (one Jacobi blur pass over every frame), HIP events, 40 launches",
-                               "achieved": blur_bytes / (blur_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": blur_bytes / (blur_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                               "launch_ms": blur_ms, "algorithmic_bytes_per_launch": blur_bytes}
+                               "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                               "traffic": traffic, "traffic_fetch_as_reported": traffic_raw,
+                               "traffic_over_algorithmic": (traffic / blur_bytes) if traffic else None,
+                               "traffic_source": ("profiles/%s/pmc_summary.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                                                  "`bench.py --workload c5 --frames 8`; FETCH_SIZE x2 per the guide's gfx950 "
+                                                  "correction, calibration of that factor for this access mix: profiles/%s/fetch_calibration.md)"
+                                                  % (tag, tag)) if traffic else None,
+                               "launch_ms": blur_ms, "algorithmic_bytes_per_launch": blur_bytes,
+                               "requested_bytes_per_launch_gathers_included": 40.0 * nv,
+                               "requested_gbs_gathers_included": 40.0 * nv / (blur_ms * 1e-3) / 1e9}
             M, Q = b.map(), b.probability()
             o = po.OracleCRF(N, 2)
             o.set_unary_from_label(pbs[0]["label"], pbs[0]["conf"])
@@ -290,10 +405,22 @@ def c5_record(pkg, wl, torch, dev, steps=6, frames=8):
     return out
 
 
-def pmc_traffic(tag, kernel="k_fused"):
+def latest_profile(suffix):
+    """profiles/r<NN>_<suffix> of the latest round that committed one (e.g. 'fused_c2' -> 'r3_fused_c2'), or None."""
+    import re
+    best = None
+    pdir = os.path.join(ROOT, "profiles")
+    for d in os.listdir(pdir) if os.path.isdir(pdir) else []:
+        m = re.fullmatch(r"r(\d+)_" + re.escape(suffix), d)
+        if m and os.path.exists(os.path.join(pdir, d, "pmc_summary.csv")) and (best is None or int(m.group(1)) > best[0]):
+            best = (int(m.group(1)), d)
+    return best[1] if best else None
+
+
+def pmc_traffic(tag, kernel="k_fused", corrected=True):
     """HBM bytes per launch of `kernel` from a committed rocprofv3 --pmc profile of THIS command line
-    (profiles/<tag>/pmc_summary.csv: FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE).  Counters
-    cannot be collected inside this process; None unless such a profile is committed."""
+    (profiles/<tag>/pmc_summary.csv: FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE; corrected=False:
+    FETCH_SIZE as reported).  Counters cannot be collected inside this process; None unless such a profile is committed."""
     import csv
     fn = os.path.join(ROOT, "profiles", tag or "", "pmc_summary.csv")
     if not tag or not os.path.exists(fn):
@@ -301,7 +428,7 @@ def pmc_traffic(tag, kernel="k_fused"):
     tot = 0.0
     for r in csv.DictReader(open(fn)):
         if kernel in r["kernel"]:
-            tot += float(r["bytes_corrected"])
+            tot += float(r["bytes_corrected" if corrected else "bytes_per_dispatch"])
     return tot or None
 
 
@@ -539,7 +666,8 @@ def main():
             t_floor = lds_clocks * n_iter * F / N_CU / CLK_HZ       # every CU streaming at the per-instruction peak
             achieved = lds_launch / launch_s / 1e9
             peak = lds_launch / t_floor / 1e9
-            traffic = pmc_traffic("r2_fused_c2" if (name, F) == ("c2", DEFAULT_FRAMES) else None)
+            ptag = latest_profile("fused_c2") if (name, F) == ("c2", DEFAULT_FRAMES) else None
+            traffic = pmc_traffic(ptag)
             roof = {"bound": "lds", "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": achieved / peak,
                     "traffic": traffic,
                     "kernel": "inference launch (start + %d mean-field iterations + map), HIP events" % n_iter,
@@ -549,7 +677,7 @@ def main():
                                  "from MI355X_MICROARCH.md (ds_read_b64/b128 256, ds_read_b32 128, ds_write_b32 64, "
                                  "ds_write_b64 85 B/clk), 256 CUs at 2.4 GHz",
                     "hbm_counter_frac": (traffic / launch_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
-                    "traffic_source": "profiles/r2_fused_c2 (rocprofv3 --pmc of this command line)" if traffic else None,
+                    "traffic_source": ("profiles/%s (rocprofv3 --pmc of this command line)" % ptag) if traffic else None,
                     "algorithmic_hbm_bytes_per_launch": alg_launch,
                     "note": "SURVEY 8(d)'s byte model counts arrays that this engine keeps in LDS/registers; against HBM "
                             "the honest figure is hbm_counter_frac"}
@@ -582,7 +710,7 @@ def main():
             "frames_per_s_end_to_end": (F * world / (run_ms * 1e-3)) if (run_ms and run_engine == 3) else F * world / ((build_ms + inf_ms) * 1e-3),
             "end_to_end": {"one_launch_ms_per_batch": run_ms, "one_launch_engine": (run_engine if run_ms else None),
                            "two_kernel_ms_per_batch": build_ms + inf_ms,
-                           "one_launch_hbm_bytes_per_frame": (pmc_traffic("r2_fused_c2", "k_frame") / F) if ((name, F) == ("c2", DEFAULT_FRAMES) and pmc_traffic("r2_fused_c2", "k_frame")) else None,
+                           "one_launch_hbm_bytes_per_frame": (pmc_traffic(latest_profile("fused_c2"), "k_frame") / F) if ((name, F) == ("c2", DEFAULT_FRAMES) and pmc_traffic(latest_profile("fused_c2"), "k_frame")) else None,
                            "note": "per frame: both PottsPotential3D ctors (lattice + norm) + inference(n, true); one_launch = "
                                    "lccrf_batch_run (frame_engine.hip), wall clock over back-to-back batches; two_kernel = HIP "
                                    "events of lccrf_batch_build + lccrf_batch_inference"},
@@ -595,10 +723,14 @@ def main():
             b.close()
             del d_feats, d_label
             torch.cuda.empty_cache()
+            if name == "c2":                            # every other configuration of BASELINE.json (+ the live-SLAM size) in the same line
+                for sub in ("c1", "c3", "c4", "n500"):
+                    out[sub] = slam_subrecord(pkg, wl, torch, dev, sub)
             if name != "c5":
                 out["c5"] = c5_record(pkg, wl, torch, dev)
-            lat_pbs = pbs[:8] if name != "c5" else [wl.slam_problem(2000, s) for s in range(1, 9)]
-            out["single_frame_latency_us"] = single_frame_latency(pkg, lat_pbs, 5 if name == "c5" else n_iter)
+            lat_pbs = pbs[:8] if name not in ("c5", "n500") else [wl.slam_problem(2000, s) for s in range(1, 9)]
+            out["single_frame_latency_us"] = single_frame_latency(pkg, lat_pbs, 5)
+            out["single_frame_latency_us_n500"] = single_frame_latency(pkg, [wl.slam_problem(500, s) for s in range(1, 9)], 5, reps=160)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(pbs, n_iter)
         print(json.dumps(out))

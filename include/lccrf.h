@@ -157,7 +157,9 @@ void lccrf_batch_destroy(lccrf_batch_handle b);
 int  lccrf_batch_set_inputs_host(lccrf_batch_handle b, int n_frames, const int32_t *n_points,
                                  const float *unary, const int16_t *label, const float *conf,
                                  const float *const *features /* [n_kernels] */);
-/* Device inputs (bound, not copied; must stay valid until the batch finished).          */
+/* Device inputs (bound, not copied; must stay valid until the batch finished).  d_n_points must be COMPLETE when
+ * this is called (it is validated and clamped into a private copy on the batch's own stream right here, unordered
+ * with any other stream); an entry outside [0, max_points] raises LCCRF_E_CAPACITY at the next synchronisation point. */
 int  lccrf_batch_bind_inputs_device(lccrf_batch_handle b, int n_frames, const int32_t *d_n_points,
                                     const float *d_unary, const int16_t *d_label, const float *conf,
                                     const float *const *d_features /* host array of device ptrs */);
@@ -173,8 +175,14 @@ int  lccrf_batch_inference(lccrf_batch_handle b, int n_iterations, int with_map,
  * sequence src/Tracking.cc:1920-1929.  Needs inputs only (no lccrf_batch_build); the lattices never reach
  * HBM, so the parity probes (norm, lattice arrays) rebuild them on demand.  Frames the one-launch kernel
  * cannot take (n_labels != 2, a kernel with d != 2, more than two kernels, > 4096 points, or lattices too
- * large for one workgroup's LDS) run on the build + inference kernels instead: same results either way.   */
+ * large for one workgroup's LDS) run on the build + inference kernels instead: same results either way.  The
+ * decision is PER FRAME: the kernel flags the frames whose lattices did not fit and, at the next synchronisation
+ * point (lccrf_batch_synchronize, any getter, the next call that continues from the results), exactly those frames
+ * are gathered, re-run on the two-kernel path and scattered back -- a batch with one outlier pays for one frame.
+ * The device buffers of lccrf_batch_device_buffers / _label_bits are complete behind that synchronisation point.  */
 int  lccrf_batch_run(lccrf_batch_handle b, int n_iterations, int with_map, float relax, void *stream);
+/* How many frames of the last lccrf_batch_run had to be re-run on the two-kernel path (0 = every frame fitted). */
+int  lccrf_batch_get_fallback_frames(lccrf_batch_handle b, int *n_frames);
 int  lccrf_batch_synchronize(lccrf_batch_handle b);
 
 /* Results: copy to host, or borrow the device buffers ([n_frames][max_points](xL)).     */
@@ -284,11 +292,22 @@ int  lccrf_pose_optimization(int device_id, int n_points, const float *Xw, const
                              int32_t *n_inliers_out);
 /* The same for every frame of a batch, on DEVICE arrays strided by the batch's max_points ([F][max_points][..],
  * Tcw [F][16], counts [F]), with the labels of the batch's last inference read where the kernel left them: the
- * labels never visit the host between the CRF and the pose.  Asynchronous on `stream` (NULL: the batch's own).   */
+ * labels never visit the host between the CRF and the pose.  Asynchronous on `stream` (NULL: the batch's own);
+ * behind a lccrf_batch_run whose fallback is still unresolved it first settles that (one synchronisation).
+ * LCCRF_E_STATE if the last inference ran with with_map = 0 (no labels).
+ * CRF-ORDER CONTRACT: arrays are indexed by CRF point index i (the order in which DynamicDetectionWithCRF pushed
+ * its candidates, Tracking.cc:1849-1870), label i gates edge i.  The reference's PoseOptimization instead walks all
+ * pFrame->N keypoints with a non-null map point (Optimizer.cc:281-360): that includes map points the CRF skipped
+ * because observs == 0 (Tracking.cc:1857-1859), which still contribute an edge there.  Append those as extra points
+ * behind a frame's CRF points -- rows [n_crf, n_points) with d_valid = 1 -- and say how many CRF points each frame
+ * has through lccrf_batch_pose_set_crf_counts(); points beyond that count are treated as static (label 1).          */
 int  lccrf_batch_pose_optimization(lccrf_batch_handle b, const float *d_Xw, const float *d_kp, const float *d_u_right,
                                    const float *d_inv_sigma2, const uint8_t *d_valid, const float *K4, float bf,
                                    const float *d_Tcw_in, float *d_Tcw_out, uint8_t *d_outlier,
                                    int32_t *d_n_inliers, int32_t *d_n_initial, void *stream);
+/* Optional: d_n_total[f] >= the CRF's n_points[f] (device array [F], bound, not copied) = CRF points + the extra
+ * non-CRF edges of the contract above; NULL (default) = only the CRF's points carry edges.                          */
+int  lccrf_batch_pose_set_crf_counts(lccrf_batch_handle b, const int32_t *d_n_total);
 
 #ifdef __cplusplus
 }

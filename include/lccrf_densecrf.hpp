@@ -32,7 +32,11 @@
 //     no error path at all); there is no CPU fallback behind these classes;
 //   * the unary energies live on the device: the base's unary_ stays null;
 //   * getMap() is refreshed by inference(n, true) / buildMap(); getProbability() by this class's own (const)
-//     getter -- a caller that reads probabilities through a DenseCRF* base pointer calls syncProbability() first;
+//     getter.  DenseCRF::getProbability() is NOT virtual in the reference (densecrf_base.h:75): through a DenseCRF*
+//     it returns the host buffer current_ as it stands.  An object that is going to be used that way keeps that
+//     buffer fresh itself -- inference() / startInference() / stepInference() end with a download of Q (16 KB at
+//     N = 2000) when syncThroughBase(true) is set; CreateDenseCRF<M>() sets it, because a base pointer is all its
+//     caller holds.  Objects used by their own type (the call site of Tracking.cc:1920-1930) skip the download;
 //   * a potential is a feature carrier until it is added or applied: the lattice is built on the GPU then
 //     (the reference builds it in the potential's constructor).
 #pragma once
@@ -131,16 +135,29 @@ protected:
     mutable lccrf_handle h_ = nullptr;              // the CRF this term belongs to, or a private one-term CRF (own_)
     mutable int k_ = -1;
     mutable bool own_ = false;
+    int device_id_ = 0;                             // where a potential that is applied on its own builds its private CRF
 public:
     // pairwise3d.h:20 -- features are [N][F] AoS
-    PottsPotentialHIP(const float *features, int N, float w)
-        : PairwisePotential(N), w_(w), feat_(features, features + (size_t)N * F) {}
+    PottsPotentialHIP(const float *features, int N, float w, int device_id = 0)
+        : PairwisePotential(N), w_(w), feat_(features, features + (size_t)N * F), device_id_(device_id) {}
     PottsPotentialHIP(const PottsPotentialHIP &) = delete;
     ~PottsPotentialHIP() override
     {
         if (own_) lccrf_destroy(h_);
     }
 
+    // GPU of the private one-term CRF behind a stand-alone apply(); irrelevant once the potential belongs to a DenseCRFHIP
+    void setDevice(int device_id)
+    {
+        if (own_ && device_id != device_id_) {
+            lccrf_destroy(h_);
+            h_ = nullptr;
+            own_ = false;
+            k_ = -1;
+        }
+        device_id_ = device_id;
+    }
+    int device() const { return device_id_; }
     int dims() const override { return F; }
     float weight() const override { return w_; }
     const float *features() const override { return feat_.data(); }
@@ -157,7 +174,7 @@ public:
     void apply(float *out_values, const float *in_values, float * /*tmp*/) const override
     {
         if (!h_) {                                   // not part of a DenseCRFHIP (yet): a private one-term CRF carries the lattice
-            lccrf_check(lccrf_create(&h_, 0, N_, M), "lccrf_create");
+            lccrf_check(lccrf_create(&h_, device_id_, N_, M), "lccrf_create");
             own_ = true;
             k_ = 0;
             lccrf_check(lccrf_add_pairwise(h_, feat_.data(), F, w_), "lccrf_add_pairwise");
@@ -203,6 +220,7 @@ protected:
     size_t adopted_ = 0;                  // pairwise_[0, adopted_) have been looked at
     int n_hip_ = 0;                       // ... of which this many are terms of the handle
     bool mixed_ = false;                  // some potential is not ours: host-array stepping (densecrf_base.h:82-91)
+    bool base_sync_ = false;              // keep current_ fresh for readers that only hold a DenseCRF* (non-virtual getProbability)
     mutable std::vector<short> map_buf_;
     mutable std::vector<float> cur_buf_, next_buf_, tmp_buf_;
 
@@ -287,6 +305,7 @@ public:
         }
         lccrf_check(lccrf_inference(h_, n_iterations, with_map ? 1 : 0, relax), "lccrf_inference");
         if (with_map) lccrf_check(lccrf_get_map(h_, map_), "lccrf_get_map");
+        if (base_sync_) syncProbability();
     }
     void startInference() override                                             // densecrf_base.h:78
     {
@@ -296,13 +315,18 @@ public:
             expAndNormalize(current_, next_, 1.0, 1.0);                         // ... so softmax(-unary) is expAndNormalize(next, scale 1)
         } else {
             lccrf_check(lccrf_start_inference(h_), "lccrf_start_inference");
+            if (base_sync_) syncProbability();
         }
     }
     void stepInference(float relax = 1.0) override                             // densecrf_base.h:82
     {
         adopt();
-        if (mixed_) DenseCRF::stepInference(relax);
-        else lccrf_check(lccrf_step_inference(h_, relax), "lccrf_step_inference");
+        if (mixed_) {
+            DenseCRF::stepInference(relax);
+        } else {
+            lccrf_check(lccrf_step_inference(h_, relax), "lccrf_step_inference");
+            if (base_sync_) syncProbability();
+        }
     }
 
     // densecrf_base.h:74-75.  Pointers into object-owned host buffers, valid until destruction.
@@ -325,6 +349,9 @@ public:
         lccrf_check(lccrf_get_lattice_size(h_, kernel, &V), "lccrf_get_lattice_size");
         return V;
     }
+    // see the header comment: true = every inference call ends with Q in the buffer DenseCRF::getProbability() returns
+    void syncThroughBase(bool on) { base_sync_ = on; }
+    bool syncsThroughBase() const { return base_sync_; }
     bool mixed() const { return mixed_; }
     lccrf_handle handle() const { return h_; }
 };
@@ -335,7 +362,9 @@ template <int M>
 inline DenseCRF *CreateDenseCRF(int N, Device device = GPU, int device_id = 0)
 {
     if (device != GPU) throw std::runtime_error("CreateDenseCRF: this library has no CPU implementation (use the reference's DenseCRF3D)");
-    return new DenseCRFHIP<M>(N, device_id);
+    DenseCRFHIP<M> *crf = new DenseCRFHIP<M>(N, device_id);
+    crf->syncThroughBase(true);           // the caller holds a DenseCRF*: its getProbability() must see every result (densecrf_base.h:75)
+    return crf;
 }
 
 }  // namespace DenseCRF

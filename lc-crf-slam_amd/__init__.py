@@ -115,6 +115,8 @@ def lib():
     L.lccrf_batch_device_label_bits.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_int)]
     L.lccrf_batch_set_engine.argtypes = [vp, C.c_int]
     L.lccrf_batch_get_engine.argtypes = [vp, C.POINTER(C.c_int)]
+    L.lccrf_batch_get_fallback_frames.argtypes = [vp, C.POINTER(C.c_int)]
+    L.lccrf_batch_pose_set_crf_counts.argtypes = [vp, vp]
     L.lccrf_batch_last_timing.argtypes = [vp, _f32p, _f32p]
     L.lccrf_batch_time_blur_pass.argtypes = [vp, C.c_int, C.c_int, _f32p, C.POINTER(C.c_int64)]
     L.lccrf_bf_match.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_double, _i32p, _i32p]
@@ -351,6 +353,16 @@ class BatchCRF:
         e = C.c_int(0)
         _check(lib().lccrf_batch_get_engine(self.h, C.byref(e)))
         return e.value
+
+    def fallback_frames(self):
+        """Frames of the last run() that did not fit the one-launch kernel and were re-run on the two-kernel path."""
+        n = C.c_int(0)
+        _check(lib().lccrf_batch_get_fallback_frames(self.h, C.byref(n)))
+        return n.value
+
+    def pose_set_crf_counts(self, d_n_total):
+        """lccrf_batch_pose_set_crf_counts: device int32[F] of CRF points + extra non-CRF edges per frame (None: off)."""
+        _check(lib().lccrf_batch_pose_set_crf_counts(self.h, C.c_void_p(int(d_n_total)) if d_n_total else None))
 
     def map(self):
         out = np.empty((self.n_frames, self.maxN), np.int16)

@@ -128,7 +128,9 @@ struct Engine {
     std::vector<int> maxV, maxRow;
     bool unary_set = false, built = false, sizes_known = false, started = false;
     int built_upto = 0;                // kernels [0, built_upto) have their lattice
-    int engine_pref = 0, engine_used = 1;
+    int engine_pref = 0, engine_used = 1;   // engine_used is REPORT-only state (lccrf_batch_get_engine): 1 streaming, 2 fused, 3 one launch per frame
+    int sized_engine = 1;              // what learn_sizes() chose for inference on lattices that sit in HBM (1 or 2)
+    int last_with_map = 0;             // did the last inference produce MAP labels?
     size_t fused_lds = 0;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   // build begin/end, inference begin/end
     hipEvent_t ev_order = nullptr;     // orders a caller-supplied stream against the engine's own (StreamScope)
@@ -157,6 +159,15 @@ struct Engine {
     UnaryTable deferred_tbl{};
     bool late_ok = false;              // set by the object API: single frame, automatic engine choice
     bool late_pending = false;
+    // Per-frame fallback of the one-launch kernel: k_frame leaves 1 in frame_status[f] for a frame whose lattices do not
+    // fit its LDS plan; resolve_late() gathers exactly those frames into the sub-engine `fb`, runs the two-kernel path
+    // there and scatters Q / labels / V back.
+    int *frame_status = nullptr;       // device [Fcap]
+    int *frame_status_host = nullptr;  // pinned [Fcap]
+    int *fb_list = nullptr;            // device [Fcap]: frames being re-run
+    int *fb_list_host = nullptr;       // pinned [Fcap]
+    Engine *fb = nullptr;
+    int fallback_frames = 0;           // frames the last one-launch run had to re-run (report only)
     int late_iter = 0, late_map = 0;
     float late_relax = 1.0f;
     bool timed_build = false, timed_inf = false;
@@ -186,6 +197,10 @@ struct Engine {
         if ((rc = mem.alloc_pinned(&row_host, (size_t)LCCRF_MAX_KERNELS * Fcap))) return rc;
         if ((rc = mem.alloc_pinned(&late_status, 1))) return rc;
         *late_status = 0;
+        if ((rc = mem.alloc(&frame_status, Fcap))) return rc;
+        if ((rc = mem.alloc(&fb_list, Fcap))) return rc;
+        if ((rc = mem.alloc_pinned(&frame_status_host, Fcap))) return rc;
+        if ((rc = mem.alloc_pinned(&fb_list_host, Fcap))) return rc;
         if ((rc = mem.alloc_pinned(&npoints_bad, 1))) return rc;
         *npoints_bad = 0;
         crf.F = F;
@@ -200,6 +215,11 @@ struct Engine {
     void destroy()
     {
         if (stream) (void)hipStreamSynchronize(stream);
+        if (fb) {
+            fb->destroy();
+            delete fb;
+            fb = nullptr;
+        }
         mem.release();
         for (auto &e : ev)
             if (e) (void)hipEventDestroy(e);
@@ -377,9 +397,9 @@ struct Engine {
         }
         sync_views();
         sizes_known = true;
-        engine_used = 1;
-        if (engine_pref != 1 && fused_supported(crf, kdevs.data(), maxV.data(), maxRow.data(), &fused_lds)) engine_used = 2;
-        if (engine_pref == 2 && engine_used != 2)
+        sized_engine = 1;
+        if (engine_pref != 1 && fused_supported(crf, kdevs.data(), maxV.data(), maxRow.data(), &fused_lds)) sized_engine = 2;
+        if (engine_pref == 2 && sized_engine != 2)
             return fail(LCCRF_E_CAPACITY, "fused engine requested but the problem does not fit one workgroup's LDS");
         return LCCRF_OK;
     }
@@ -447,7 +467,7 @@ struct Engine {
     {
         *late_status = 0;
         const bool from_label = unary_deferred && L == 2;
-        launch_frame(crf, kdevs.data(), n_iter, with_map, relax, late_status, from_label ? deferred_label : nullptr,
+        launch_frame(crf, kdevs.data(), n_iter, with_map, relax, late_status, frame_status, from_label ? deferred_label : nullptr,
                      deferred_tbl.v, stream);
         HIP_TRY(hipGetLastError());
         late_pending = true;
@@ -456,6 +476,8 @@ struct Engine {
         late_relax = relax;
         started = true;
         engine_used = 3;
+        last_with_map = with_map;
+        fallback_frames = 0;
         return LCCRF_OK;
     }
 
@@ -490,7 +512,9 @@ struct Engine {
         if (rc) return rc;
         rc = learn_sizes();
         if (rc) return rc;
-        if (engine_used == 2) {
+        engine_used = sized_engine;
+        last_with_map = with_map;
+        if (sized_engine == 2) {
             launch_inference_fused(crf, kdevs.data(), maxV.data(), maxRow.data(), n_iter, with_map, relax, stream);
             started = true;
         } else {
@@ -508,11 +532,99 @@ struct Engine {
         if (!late_pending) return LCCRF_OK;
         late_pending = false;
         HIP_TRY(hipStreamSynchronize(stream));
+        if (*npoints_bad) {                                // (the one-launch path never passes through learn_sizes())
+            *npoints_bad = 0;
+            return fail(LCCRF_E_CAPACITY, "a bound n_points[f] lies outside [0, max_points=%d] (the kernels clamped it)", maxN);
+        }
         if (*late_status == 0) return LCCRF_OK;
-        *late_status = 0;                                  // a frame did not fit the one-launch kernel: two-kernel path
-        built_upto = 0;
-        sizes_known = false;
-        return inference_sized(late_iter, late_map, late_relax);
+        *late_status = 0;                                  // some frame did not fit the one-launch kernel
+        HIP_TRY(hipMemcpy(frame_status_host, frame_status, sizeof(int) * F, hipMemcpyDeviceToHost));
+        int n = 0;
+        for (int f = 0; f < F; ++f)
+            if (frame_status_host[f]) fb_list_host[n++] = f;
+        fallback_frames = n;
+        int rc = LCCRF_OK;
+        if (n >= F || n == 0) {                            // every frame (always so for the object API): two-kernel path in place
+            built_upto = 0;
+            sizes_known = false;
+            rc = inference_sized(late_iter, late_map, late_relax);
+        } else {
+            rc = rerun_frames(n);                          // the batch stays a one-launch batch; only the flagged frames pay twice
+            engine_used = 3;
+        }
+        if (rc) return rc;
+        if (timed_inf) HIP_TRY(hipEventRecord(ev[3], stream));   // the timed region now ends behind the re-run
+        HIP_TRY(hipStreamSynchronize(stream));             // callers read borrowed device buffers right behind a synchronisation point
+        return LCCRF_OK;
+    }
+
+    // Two-kernel path for the frames fb_list_host[0, n) only, in a compact sub-engine; results scattered back.
+    int rerun_frames(int n)
+    {
+        if (fb && fb->Fcap < n) {
+            fb->destroy();
+            delete fb;
+            fb = nullptr;
+        }
+        if (!fb) {
+            fb = new (std::nothrow) Engine;
+            if (!fb) return fail(LCCRF_E_NOMEM, "host allocation failed");
+            int rc = fb->init(device, std::min(Fcap, std::max(8, next_pow2(n))), maxN, L);
+            for (size_t k = 0; k < kernels.size() && !rc; ++k) rc = fb->add_kernel(kernels[k].dev.d, kernels[k].dev.w, true, false);
+            if (!rc && hipStreamSynchronize(fb->stream) != hipSuccess) rc = fail(LCCRF_E_HIP, "hipStreamSynchronize after allocation failed");
+            if (rc) {
+                fb->destroy();
+                delete fb;
+                fb = nullptr;
+                return rc;
+            }
+        }
+        Engine &g = *fb;
+        const hipStream_t g_own = g.stream;
+        g.stream = stream;                                 // everything below is ordered on this engine's stream
+        struct Restore { Engine &g; hipStream_t s; ~Restore() { g.stream = s; } } restore{g, g_own};
+        g.F = n;
+        g.activeN = activeN;
+        g.engine_pref = engine_pref == 1 ? 1 : 0;
+        HIP_TRY(hipMemcpyAsync(fb_list, fb_list_host, sizeof(int) * n, hipMemcpyHostToDevice, stream));
+        launch_copy_frames(g.npoints_own, 4, crf.n_points, 4, fb_list, n, 4, 1, stream);
+        g.crf.n_points = g.npoints_own;
+        for (size_t k = 0; k < kernels.size(); ++k) {
+            const size_t row = (size_t)maxN * kernels[k].dev.d * sizeof(float);
+            launch_copy_frames(g.kernels[k].feat_own, row, kernels[k].dev.feat, row, fb_list, n, row, 1, stream);
+            g.kernels[k].dev.feat = g.kernels[k].feat_own;
+            g.kernels[k].dev.w = kernels[k].dev.w;
+        }
+        g.crf.unary = g.unary_own;
+        if (unary_deferred) {
+            launch_copy_frames(g.label_own, (size_t)maxN * 2, deferred_label, (size_t)maxN * 2, fb_list, n, (size_t)maxN * 2, 1, stream);
+            g.unary_deferred = true;
+            g.deferred_label = g.label_own;
+            g.deferred_tbl = deferred_tbl;
+        } else {
+            const size_t row = (size_t)maxN * L * sizeof(float);
+            launch_copy_frames(g.unary_own, row, crf.unary, row, fb_list, n, row, 1, stream);
+            g.unary_deferred = false;
+        }
+        g.unary_set = true;
+        g.built_upto = 0;
+        g.sizes_known = false;
+        g.sync_views();
+        HIP_TRY(hipGetLastError());
+        int rc = g.inference_sized(late_iter, late_map, late_relax);
+        if (rc) return rc;
+        const size_t qrow = (size_t)maxN * L * sizeof(float);
+        launch_copy_frames(crf.Q, qrow, g.crf.Q, qrow, fb_list, n, qrow, 0, stream);
+        if (late_map) {
+            launch_copy_frames(crf.map, (size_t)maxN * 2, g.crf.map, (size_t)maxN * 2, fb_list, n, (size_t)maxN * 2, 0, stream);
+            if (crf.map_bits && g.crf.map_bits)
+                launch_copy_frames(crf.map_bits, (size_t)crf.bits_stride * 8, g.crf.map_bits, (size_t)crf.bits_stride * 8, fb_list, n,
+                                   (size_t)crf.bits_stride * 8, 0, stream);
+        }
+        for (size_t k = 0; k < kernels.size(); ++k)
+            launch_copy_frames(kernels[k].dev.V, 4, g.kernels[k].dev.V, 4, fb_list, n, 4, 0, stream);
+        HIP_TRY(hipGetLastError());
+        return LCCRF_OK;
     }
 };
 
@@ -558,6 +670,7 @@ struct lccrf_batch {
     lccrf_batch_desc desc{};
     bool inputs_set = false, labels_bound = false;
     const int16_t *d_label = nullptr;
+    const int32_t *d_pose_total = nullptr;   // lccrf_batch_pose_set_crf_counts
 };
 
 extern "C" {
@@ -1279,9 +1392,22 @@ int lccrf_batch_get_engine(lccrf_batch_handle b, int *engine_in_use)
     CHECK_H(b);
     if (!engine_in_use) return fail(LCCRF_E_INVALID, "engine_in_use is NULL");
     { int rl = b->eng.resolve_late(); if (rl) return rl; }   // a one-launch run may have fallen back
-    int rc = b->eng.built ? b->eng.learn_sizes() : LCCRF_OK;
-    if (rc) return rc;
-    *engine_in_use = b->eng.engine_used;
+    Engine &e = b->eng;
+    if (e.built && e.engine_used != 3) {                     // lattices in HBM: what an inference on them runs (or ran) on
+        int rc = e.learn_sizes();
+        if (rc) return rc;
+        e.engine_used = e.sized_engine;
+    }
+    *engine_in_use = e.engine_used;
+    return LCCRF_OK;
+}
+
+int lccrf_batch_get_fallback_frames(lccrf_batch_handle b, int *n_frames)
+{
+    CHECK_H(b);
+    if (!n_frames) return fail(LCCRF_E_INVALID, "n_frames is NULL");
+    { int rl = b->eng.resolve_late(); if (rl) return rl; }
+    *n_frames = b->eng.fallback_frames;
     return LCCRF_OK;
 }
 
@@ -1423,14 +1549,26 @@ int lccrf_batch_pose_optimization(lccrf_batch_handle b, const float *d_Xw, const
         return fail(LCCRF_E_INVALID, "NULL array");
     Engine &e = b->eng;
     if (!e.started) return fail(LCCRF_E_STATE, "no inference has produced labels yet");
+    if (!e.last_with_map) return fail(LCCRF_E_STATE, "the last inference ran with with_map = 0: there are no labels to consume");
     if (e.maxN > 16384) return fail(LCCRF_E_CAPACITY, "at most 16384 keypoints per frame");
+    // a one-launch run may still owe the labels of frames that did not fit its kernel (they are written by the
+    // re-run): settle that first -- one synchronisation, and only when lccrf_batch_run is still pending
+    { int rl = e.resolve_late(); if (rl) return rl; }
     StreamScope scope(e, stream);
     int rc = scope.enter();
     if (rc) return rc;
     // the labels are read where the inference kernel wrote them: no host round trip between the CRF and the pose
-    hipError_t er = launch_pose_optimization(e.F, e.maxN, e.crf.n_points, d_Xw, d_kp, d_u_right, d_inv_sigma2, d_valid, e.crf.map, K4, bf,
-                                             d_Tcw_in, d_Tcw_out, d_outlier, d_n_inliers, d_n_initial, e.stream);
+    hipError_t er = launch_pose_optimization(e.F, e.maxN, b->d_pose_total ? b->d_pose_total : e.crf.n_points, d_Xw, d_kp, d_u_right,
+                                             d_inv_sigma2, d_valid, e.crf.map, K4, bf, d_Tcw_in, d_Tcw_out, d_outlier, d_n_inliers,
+                                             d_n_initial, e.stream, b->d_pose_total ? e.crf.n_points : nullptr);
     if (er != hipSuccess) return fail(LCCRF_E_HIP, "pose optimisation: %s", hipGetErrorString(er));
+    return LCCRF_OK;
+}
+
+int lccrf_batch_pose_set_crf_counts(lccrf_batch_handle b, const int32_t *d_n_total)
+{
+    CHECK_H(b);
+    b->d_pose_total = d_n_total;
     return LCCRF_OK;
 }
 

@@ -104,9 +104,14 @@ void launch_inference_fused(const CrfDev &c, const KernelDev *kds, const int *ma
 bool frame_supported(const CrfDev &c, const KernelDev *kds);
 // label != nullptr (L = 2): the unary energies are derived in the kernel from the labels and the 5 table entries
 // {u, n0, n1, p0, p1}; otherwise read from c.unary.  `status` (pinned host word, zeroed by the caller) reads 1
-// afterwards if some frame did not fit the kernel's LDS plan; the caller then runs the two-kernel path.
-void launch_frame(const CrfDev &c, const KernelDev *kds, int n_iter, int with_map, float relax, int *status,
+// afterwards if some frame did not fit the kernel's LDS plan; `frame_status` (device [F], or null) then holds 1 for
+// exactly those frames and the caller runs them -- and only them -- on the two-kernel path.
+void launch_frame(const CrfDev &c, const KernelDev *kds, int n_iter, int with_map, float relax, int *status, int *frame_status,
                   const int16_t *label, const float *tbl5, hipStream_t s);
+// rows of `bytes` bytes each between a frame-strided array and a compact one: dst[i] = src[list[i]] (gather = 1) or
+// dst[list[i]] = src[i] (gather = 0); strides in bytes, everything 4-byte aligned
+void launch_copy_frames(void *dst, size_t dst_stride, const void *src, size_t src_stride, const int *list, int n_list,
+                        size_t bytes, int gather, hipStream_t s);
 
 // ---- unary builder (the step before the CRF) ------------------------
 hipError_t run_unary_build(int device_id, int n_points, const float *Xw, const int32_t *obs_ptr, const int32_t *obs_kf,
@@ -122,6 +127,6 @@ hipError_t run_bf_match(int device_id, int n_query, const uint8_t *desc_query, i
 hipError_t launch_pose_optimization(int F, int maxN, const int *n_points, const float *Xw, const float *kp, const float *ur,
                                     const float *is2, const uint8_t *valid, const int16_t *label, const float *K4, float bf,
                                     const float *Tcw_in, float *Tcw_out, uint8_t *outlier, int *n_inliers, int *n_initial,
-                                    hipStream_t s);
+                                    hipStream_t s, const int *n_crf = nullptr);
 
 }  // namespace lccrf

@@ -59,6 +59,7 @@ struct FrameArgs {
     int lds_total;                        // dynamic LDS bytes of the launch
     int *V_out[kMaxFusedK];               // [F] vertices per kernel (reference M_), or null
     int *status;                          // pinned host word: set to 1 when a frame does not fit this kernel's LDS plan
+    int *frame_status;                    // device [F] or null: 1 for exactly the frames that did not fit (they alone are re-run), else 0
     long long *timing;                    // instrumented builds only
     int timing_block, timing_lane;
 };
@@ -126,6 +127,7 @@ __global__ void __launch_bounds__(kNT) k_frame(CrfDev c, FrameArgs a)
     FL_STAMP();
     if (N <= 0) {                                         // an empty frame has no lattice (V = 0) and nothing to infer
         if (tid < K && a.V_out[tid]) a.V_out[tid][f] = 0;
+        if (tid == 0 && a.frame_status) a.frame_status[f] = 0;
         return;
     }
     const int Npad = (N + 3) & ~3;                       // blocks of four, permutohedral_cpu.h:294 (quirk Q1)
@@ -242,7 +244,10 @@ __global__ void __launch_bounds__(kNT) k_frame(CrfDev c, FrameArgs a)
         const int list_cap = (E + 7 * Vk + 8) & ~7;
         const int vs_end = bitmap ? pre_off + Vk * W / 2 : list_off + list_cap * 2;
         if (vs_end > ido_off || Vk >= 32767 || E + 7 * Vk >= 65535 || hdr->fail) {   // does not fit: leave the frame to the fallback path
-            if (tid == 0 && a.status) *a.status = 1;
+            if (tid == 0) {
+                if (a.status) *a.status = 1;
+                if (a.frame_status) a.frame_status[f] = 1;
+            }
             return;                                       // uniform: every lane read the same V and the same flag
         }
         unsigned *vkey = reinterpret_cast<unsigned *>(smem + vkey_off);
@@ -495,7 +500,10 @@ __global__ void __launch_bounds__(kNT) k_frame(CrfDev c, FrameArgs a)
             ok = o <= a.lds_total;
         }
         if (!ok) {
-            if (tid == 0 && a.status) *a.status = 1;
+            if (tid == 0) {
+                if (a.status) *a.status = 1;
+                if (a.frame_status) a.frame_status[f] = 1;
+            }
             return;
         }
     }
@@ -528,6 +536,7 @@ __global__ void __launch_bounds__(kNT) k_frame(CrfDev c, FrameArgs a)
     mean_field<PPT, K, 2>(smem, lay, V, N, tid, pr, cl, alpha, a.n_iter, a.relax, ins);
     store_results(c, f, N, tid, pr, a.with_map);
     if (tid < K && a.V_out[tid]) a.V_out[tid][f] = tid == 0 ? V[0] : V[K - 1];
+    if (tid == 0 && a.frame_status) a.frame_status[f] = 0;
     FL_STAMP();
     if (kInstr && a.timing && (int)blockIdx.x == a.timing_block && tid == a.timing_lane) a.timing[63] = ins.n;
 }
@@ -559,7 +568,7 @@ bool frame_supported(const CrfDev &c, const KernelDev *kds)
     return true;
 }
 
-void launch_frame(const CrfDev &c, const KernelDev *kds, int n_iter, int with_map, float relax, int *status,
+void launch_frame(const CrfDev &c, const KernelDev *kds, int n_iter, int with_map, float relax, int *status, int *frame_status,
                   const int16_t *label, const float *tbl5, hipStream_t s)
 {
     FrameArgs a{};
@@ -583,6 +592,7 @@ void launch_frame(const CrfDev &c, const KernelDev *kds, int n_iter, int with_ma
     a.hcap = frame_hcap(NA);
     a.lds_total = (int)kLdsLimit;
     a.status = status;
+    a.frame_status = frame_status;
     static long long *timing_buf = nullptr;
     static const bool want_timing = kInstr && getenv("LCCRF_FRAME_TIMING") != nullptr;
     if (want_timing && !timing_buf) (void)hipMalloc(&timing_buf, 64 * sizeof(long long));

@@ -57,6 +57,8 @@ struct PoseArgs {
     const float *Xw, *kp, *ur, *is2;      // [F][maxN][3], [F][maxN][2], [F][maxN], [F][maxN]
     const uint8_t *valid;                 // [F][maxN] mvpMapPoints[i] != NULL, or null (all valid)
     const int16_t *label;                 // [F][maxN] CRF labels (0 = moving: no edge), or null
+    const int *n_crf;                     // [F] or null: labels gate points [0, n_crf[f]) only; the points behind them are edges of map
+                                          //   points the CRF never saw (observs == 0, Tracking.cc:1857-1859) and count as static
     float fx, fy, cx, cy, bf;
     const float *Tcw_in;                  // [F][16]
     float *Tcw_out;                       // [F][16]
@@ -362,7 +364,8 @@ __global__ void __launch_bounds__(kPT) k_pose_opt(PoseArgs a)
     __shared__ double red[kRedDoubles];
     extern __shared__ float4 dyn[];                       // STAGED: recA[cap] | recB[cap] | edge_chi2[cap]; else edge_chi2[maxN]
     const int f = blockIdx.x, tid = threadIdx.x;
-    const int n = a.n_points[f];
+    const int n = min(a.n_points[f], a.maxN);
+    const int ncrf = a.n_crf ? a.n_crf[f] : n;
     const size_t fo = (size_t)f * a.maxN;
     float4 *recA = dyn, *recB = dyn + (STAGED ? a.maxN : 0);
     float *edge_chi2 = reinterpret_cast<float *>(dyn + (STAGED ? 2 * a.maxN : 0));   // chi2 of every edge's stored _error (as `const float chi2`)
@@ -370,7 +373,7 @@ __global__ void __launch_bounds__(kPT) k_pose_opt(PoseArgs a)
     __shared__ int wave_cnt[kWaves];
     long long prof_t = kInstr ? clock64() : 0;
 
-    auto has_edge = [&](int i) { return (!a.valid || a.valid[fo + i]) && (!a.label || a.label[fo + i] != 0); };
+    auto has_edge = [&](int i) { return (!a.valid || a.valid[fo + i]) && (!a.label || i >= ncrf || a.label[fo + i] != 0); };
     auto fetch = [&](int i) {
         Edge in;
         if (STAGED) {
@@ -581,9 +584,10 @@ __global__ void __launch_bounds__(kPT) k_pose_opt(PoseArgs a)
 hipError_t launch_pose_optimization(int F, int maxN, const int *n_points, const float *Xw, const float *kp, const float *ur,
                                     const float *is2, const uint8_t *valid, const int16_t *label, const float *K4, float bf,
                                     const float *Tcw_in, float *Tcw_out, uint8_t *outlier, int *n_inliers, int *n_initial,
-                                    hipStream_t s)
+                                    hipStream_t s, const int *n_crf)
 {
     PoseArgs a{};
+    a.n_crf = n_crf;
     a.maxN = maxN; a.n_points = n_points; a.Xw = Xw; a.kp = kp; a.ur = ur; a.is2 = is2; a.valid = valid; a.label = label;
     a.fx = K4[0]; a.fy = K4[1]; a.cx = K4[2]; a.cy = K4[3]; a.bf = bf;
     a.Tcw_in = Tcw_in; a.Tcw_out = Tcw_out; a.outlier = outlier; a.n_inliers = n_inliers; a.n_initial = n_initial;

@@ -17,6 +17,8 @@
 #include "device_math.h"
 #include "lattice_device.h"
 
+#include <algorithm>
+
 namespace lccrf {
 
 namespace {
@@ -788,6 +790,33 @@ hipError_t time_blur_pass(const KernelDev &kd, int F, int maxV, int L, int reps,
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     return rc;
+}
+
+// dst[i][:] = src[list[i]][:] (gather) or dst[list[i]][:] = src[i][:] (scatter), rows of `units` elements of type T
+template <typename T>
+__global__ void __launch_bounds__(kBlock) k_copy_frames(T *__restrict__ dst, size_t dst_stride, const T *__restrict__ src,
+                                                        size_t src_stride, const int *__restrict__ list, size_t units, int gather)
+{
+    const int i = blockIdx.y, f = list[i];
+    const T *sp = src + (gather ? (size_t)f : (size_t)i) * src_stride;
+    T *dp = dst + (gather ? (size_t)i : (size_t)f) * dst_stride;
+    for (size_t w = (size_t)blockIdx.x * kBlock + threadIdx.x; w < units; w += (size_t)gridDim.x * kBlock) dp[w] = sp[w];
+}
+
+void launch_copy_frames(void *dst, size_t dst_stride, const void *src, size_t src_stride, const int *list, int n_list,
+                        size_t bytes, int gather, hipStream_t s)
+{
+    if (n_list <= 0 || bytes == 0) return;
+    const bool w4 = ((bytes | dst_stride | src_stride | (size_t)(uintptr_t)dst | (size_t)(uintptr_t)src) & 3) == 0;
+    const size_t units = bytes / (w4 ? 4 : 2);                                 // (every per-frame array is at least int16-aligned)
+    const unsigned gx = (unsigned)std::min<size_t>((units + kBlock - 1) / kBlock, 64);
+    const dim3 g(gx, (unsigned)n_list);
+    if (w4)
+        k_copy_frames<unsigned><<<g, kBlock, 0, s>>>(static_cast<unsigned *>(dst), dst_stride / 4, static_cast<const unsigned *>(src),
+                                                     src_stride / 4, list, units, gather);
+    else
+        k_copy_frames<unsigned short><<<g, kBlock, 0, s>>>(static_cast<unsigned short *>(dst), dst_stride / 2,
+                                                           static_cast<const unsigned short *>(src), src_stride / 2, list, units, gather);
 }
 
 void launch_validate_npoints(const int *in, int *out, int F, int maxN, int *bad, hipStream_t s)

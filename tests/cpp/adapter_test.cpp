@@ -69,8 +69,21 @@ int main(int argc, char **argv)
             orc_crf_inference(o, 5, 1, 1.0f);
             const short *m = crf->getMap();          // the base class's getter: refreshed by inference(.., true)
             for (int i = 0; i < N; ++i) bad += m[i] != o->map[i];
-            static_cast<const DenseCRFHIP<M> *>(crf)->syncProbability();
+            // densecrf_base.h:75 is non-virtual: a factory-made object keeps the base's buffer fresh by itself
             bad += !same(crf->getProbability(), o->current, (size_t)N * M);
+            bad += !static_cast<const DenseCRFHIP<M> *>(crf)->syncsThroughBase();
+            crf->startInference();                   // stepwise through the base pointer: Q visible after every call
+            crf->stepInference();
+            {
+                orc_crf *o2 = orc_crf_create(N, M);
+                orc_crf_set_unary_from_label(o2, label.data(), cf);
+                orc_crf_add_pairwise(o2, fa.data(), 2, w1);
+                orc_crf_add_pairwise(o2, fs.data(), 2, w2);
+                orc_crf_inference(o2, 1, 0, 1.0f);
+                bad += !same(crf->getProbability(), o2->current, (size_t)N * M);
+                orc_crf_destroy(o2);
+            }
+            crf->inference(5, true);
             const DenseCRFHIP<M> &cref = *static_cast<DenseCRFHIP<M> *>(crf);
             bad += !same(cref.getProbability(), o->current, (size_t)N * M);    // const getters
             bad += cref.getMap()[0] != o->map[0];
@@ -84,7 +97,8 @@ int main(int argc, char **argv)
             out[i] = ref[i] = (float)((i * 40503u) % 97) / 10.0f - 4.0f;
         }
         {
-            PottsPotentialHIP<M, 2> pot(fs.data(), N, w2);
+            PottsPotentialHIP<M, 2> pot(fs.data(), N, w2, /*device_id=*/0);
+            pot.setDevice(0);
             const PairwisePotential &base = pot;
             base.apply(out.data(), in.data(), tmp.data());
             orc_pairwise_apply(o, 1, ref.data(), in.data());

@@ -113,6 +113,67 @@ def test_hip_pose_optimization_reads_the_crf_labels_on_the_device(po, wl):
 
 
 @pytest.mark.gpu
+def test_batch_pose_after_a_run_with_a_fallback_frame_and_extra_edges(po, wl):
+    """(1) lccrf_batch_pose_optimization right behind an asynchronous lccrf_batch_run in which one frame did
+    not fit the one-launch kernel -- the pose must be computed from that frame's REAL labels (the re-run's), not from
+    stale ones; (2) with_map = 0 leaves no labels: LCCRF_E_STATE; (3) the CRF-order contract's extra edges: map points the
+    CRF skipped (observs == 0, Tracking.cc:1857-1859) ride behind the CRF's points and count as static."""
+    import torch
+    import crf_cases as cc
+    from test_hip_parity import _shaped_problem
+    F, N, NX = 3, 1200, 100                               # NX extra non-CRF edges per frame
+    dev = torch.device("cuda", 0)
+    pbs = [wl.slam_problem(N, seed=400), _shaped_problem(wl, N, "sparse", seed=5), wl.slam_problem(N, seed=402)]
+    scenes = [wl.pose_scene(N + NX, seed=650 + f) for f in range(F)]
+    maxN = N + NX
+    feats = [np.zeros((F, maxN, 2), np.float32) for _ in range(2)]
+    label = np.full((F, maxN), -1, np.int16)
+    for f, pb in enumerate(pbs):
+        for k in range(2):
+            feats[k][f, :N] = pb["kernels"][k][0]
+        label[f, :N] = pb["label"]
+    b = pkg.BatchCRF(F, maxN, 2, [2, 2], [float(pbs[0]["kernels"][k][1]) for k in range(2)])
+    b.set_inputs_host([N] * F, feats, label=label, conf=0.7)
+    t = lambda key, dt: torch.from_numpy(np.stack([np.ascontiguousarray(s[key]) for s in scenes]).astype(dt)).to(dev)
+    dX, dk, du, di, dTi = t("Xw", np.float32), t("kp", np.float32), t("u_right", np.float32), t("inv_sigma2", np.float32), t("T_init", np.float32)
+    dTo = torch.zeros((F, 16), dtype=torch.float32, device=dev)
+    dout = torch.zeros((F, maxN), dtype=torch.uint8, device=dev)
+    dni, dn0 = torch.zeros(F, dtype=torch.int32, device=dev), torch.zeros(F, dtype=torch.int32, device=dev)
+    args = (dX.data_ptr(), dk.data_ptr(), du.data_ptr(), di.data_ptr(), scenes[0]["K4"], scenes[0]["bf"], dTi.data_ptr(),
+            dTo.data_ptr(), dout.data_ptr(), dni.data_ptr(), dn0.data_ptr())
+    b.run(5, False)
+    with pytest.raises(pkg.LccrfError) as ei:
+        b.pose_optimization(*args)
+    assert ei.value.code == -5
+    refs = []
+    for pb in pbs:
+        o = cc.setup(po.OracleCRF, pb)
+        o.inference_native(5, True)
+        refs.append(o.map().copy())
+        o.close()
+    for extra in (False, True):
+        dtot = torch.full((F,), N + NX, dtype=torch.int32, device=dev)
+        b.pose_set_crf_counts(dtot.data_ptr() if extra else None)
+        b.run(5, True)                                    # asynchronous; frame 1 is flagged for the re-run
+        b.pose_optimization(*args)                        # no synchronisation in between by the caller
+        b.synchronize()
+        assert b.fallback_frames() == 1
+        labels = b.map()
+        for f in range(F):
+            assert np.array_equal(labels[f, :N], refs[f])
+            s = scenes[f]
+            n = N + NX if extra else N
+            gate = np.ones(n, np.uint8)
+            gate[:N] = refs[f] != 0
+            To, oo, no, n0 = po.oracle_pose_optimization(s["Xw"][:n], s["kp"][:n], s["u_right"][:n], s["inv_sigma2"][:n], gate,
+                                                         s["K4"], s["bf"], s["T_init"])
+            assert int(dn0[f]) == n0 == int(gate.sum()) and int(dni[f]) == no, (extra, f)
+            assert np.array_equal(dout[f].cpu().numpy()[:n][gate == 1], oo[gate == 1])
+            assert np.abs(dTo[f].cpu().numpy().reshape(4, 4) - To).max() < 1e-6
+    b.close()
+
+
+@pytest.mark.gpu
 def test_hip_pose_optimization_survives_trim_and_growth(po, wl):
     """The single-frame entry point keeps a staging area between calls: growing it, freeing it (lccrf_trim_cache) and calling
     again must give the same answers."""
