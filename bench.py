@@ -553,39 +553,24 @@ def main():
 
     bits_ptr, words = b.device_label_bits()
     bits_view = torch.as_tensor(CudaView(bits_ptr, (F, words), "<i8"), device=dev)
-    # The label gather of step i overlaps the inference of step i+1: the bits a launch wrote are copied (2 MB, device to
-    # device) into one of two staging buffers on the compute stream, and the all_gather of that buffer runs asynchronously
-    # on the collective's own stream -- the next launch may overwrite the library's bit buffer meanwhile.  A staging
-    # buffer is reused only after the gather that read it has been waited for (stream-side wait, no host round trip).
-    n_stage = 2 if (world > 1 and not args.serial_gather) else 1
-    stage = [torch.empty((F, words), dtype=torch.int64, device=dev) for _ in range(n_stage)]
-    gathered_bufs = [torch.empty((world * F, words), dtype=torch.int64, device=dev) for _ in range(n_stage)]
-    pending = [None] * n_stage
+    # The label gather of step i overlaps the inference of step i+1 (lc-crf-slam_amd/sharding.py: OverlappedLabelGather):
+    # the bits a launch wrote are copied (device to device) into one of two staging buffers on the compute stream and the
+    # all_gather of that buffer runs asynchronously on the collective's own stream.
+    gather = sh.OverlappedLabelGather(bits_view, world, serial=args.serial_gather) if world > 1 else None
     # the library's kernels, the staging copy and the collective's wait all go through torch's current stream
     stream = torch.cuda.current_stream(dev).cuda_stream
-    step_no = [0]
 
     def barrier():
-        for k, w in enumerate(pending):             # every gather of the timed region has finished when the clock stops
-            if w is not None:
-                w.wait()
-                pending[k] = None
+        if gather is not None:                      # every gather of the timed region has finished when the clock stops
+            gather.wait_all()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
     def step():
         b.inference(n_iter, True, stream=stream)
-        if world > 1:                               # the one collective of the path: the label gather, every batch (RCCL)
-            if args.serial_gather:
-                sh.gather_label_bits(bits_view, out=gathered_bufs[0])
-            else:
-                k = step_no[0] % n_stage
-                if pending[k] is not None:
-                    pending[k].wait()
-                stage[k].copy_(bits_view, non_blocking=True)
-                pending[k] = dist.all_gather_into_tensor(gathered_bufs[k], stage[k], async_op=True)
-        step_no[0] += 1
+        if gather is not None:                      # the one collective of the path: the label gather, every batch (RCCL)
+            gather.push()
 
     for _ in range(args.warmup):                    # (RCCL sets its rings up on first use)
         step()
@@ -595,7 +580,6 @@ def main():
         step()
     barrier()
     t1 = time.perf_counter()
-    gathered = gathered_bufs[(step_no[0] - 1) % n_stage]
     dt = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(dt, op=dist.ReduceOp.MAX)
@@ -603,7 +587,7 @@ def main():
 
     gather_ok = None
     if world > 1:                                   # every rank's slot of the gathered buffer holds that rank's labels
-        mine = sh.unpack_label_bits(gathered.view(world, F, words)[rank], N)
+        mine = sh.unpack_label_bits(gather.last()[rank], N)
         map_ptr, _ = b.device_buffers()
         gather_ok = bool(torch.equal(mine, torch.as_tensor(CudaView(map_ptr, (F, N), "<i2"), device=dev)))
 

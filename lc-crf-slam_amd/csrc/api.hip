@@ -171,6 +171,38 @@ struct Engine {
     int late_iter = 0, late_map = 0;
     float late_relax = 1.0f;
     bool timed_build = false, timed_inf = false;
+    // Locality mode (batch engines, frames of >= kPermMinPoints points on the streaming engine): the lattices are built
+    // with the points in an internal Z-order of their lattice cells (stream_engine.hip: launch_sort_points); Q, next and
+    // the unaries of the iteration live in that order (Qp, unary_p / unary_own) and Q is un-permuted on the way out.
+    static constexpr int kPermMinPoints = 8192;
+    bool allow_perm = false;           // set by lccrf_batch_create
+    bool perm_on = false;              // the lattices now in HBM were built in locality mode
+    bool unary_is_label = false;       // the unaries come from labels (re-derivable in any order) rather than from a raw array
+    bool unary_p_valid = false;        // unary_p holds the raw unaries in the current internal order
+    SortScratch sort{};
+    float *Qp = nullptr, *unary_p = nullptr;   // [Fcap][maxN][L]
+
+    int ensure_sort_scratch()
+    {
+        if (sort.perm) return LCCRF_OK;
+        int bits = 8;
+        while (bits < 16 && (1 << bits) < 2 * maxN) ++bits;
+        sort.bits = bits;
+        const size_t nbk = ((size_t)1 << bits) + 1, Fz = (size_t)Fcap;
+        int rc;
+        if ((rc = mem.alloc(&sort.cells, Fz * maxNpad * kMaxD))) return rc;
+        if ((rc = mem.alloc(&sort.partial, Fz * ((maxNpad + 255) / 256 + 1) * 2 * kMaxD))) return rc;
+        if ((rc = mem.alloc(&sort.plan, Fz * 3 * kMaxD))) return rc;
+        if ((rc = mem.alloc(&sort.code, Fz * maxNpad))) return rc;
+        if ((rc = mem.alloc(&sort.hist, Fz * nbk))) return rc;
+        if ((rc = mem.alloc(&sort.start, Fz * nbk))) return rc;
+        if ((rc = mem.alloc(&sort.tiles, Fz * ((nbk + 4095) / 4096 + 1)))) return rc;
+        if ((rc = mem.alloc(&sort.perm, Fz * maxNpad))) return rc;
+        if ((rc = mem.alloc(&sort.iperm, Fz * maxNpad))) return rc;
+        if ((rc = mem.alloc(&Qp, Fz * maxN * L))) return rc;
+        if ((rc = mem.alloc(&unary_p, Fz * maxN * L))) return rc;
+        return LCCRF_OK;
+    }
 
     int init(int device_id, int frames, int max_points, int n_labels)
     {
@@ -285,6 +317,13 @@ struct Engine {
         if ((rc = mem.alloc(&k.csr_pos, Fz * E))) return rc;
         if ((rc = mem.alloc(&k.pk, Fz * E))) return rc;
         if ((rc = mem.alloc(&k.nbr16, Fz * k.D1 * E))) return rc;
+        if (L == 2 && maxN > 4096 && !getenv("LCCRF_NO_NBR_COMPRESS")) {   // frames beyond the one-workgroup engines iterate on the streaming engine
+            const size_t G = E / 64 + 1;
+            if ((rc = mem.alloc(&k.nflag, Fz * k.D1 * (E / 16 + 4)))) return rc;
+            if ((rc = mem.alloc(&k.nbase, Fz * k.D1 * G))) return rc;
+            if ((rc = mem.alloc(&k.ncount, Fz * k.D1 * G))) return rc;
+            if ((rc = mem.alloc(&k.nlist, Fz * k.D1 * E * 2))) return rc;
+        }
         if ((rc = mem.alloc(&k.norm, Fz * maxN))) return rc;
         if ((rc = mem.alloc(&k.val0, Fz * k.vstride))) return rc;
         if ((rc = mem.alloc(&k.val1, Fz * k.vstride))) return rc;
@@ -326,6 +365,8 @@ struct Engine {
         for (size_t i = 0; i < kernels.size(); ++i) {
             kernels[i].dev.V_host = V_host + i * Fcap;
             kernels[i].dev.rowmax_host = row_host + i * Fcap;
+            kernels[i].dev.perm = perm_on ? sort.perm : nullptr;
+            kernels[i].dev.iperm = perm_on ? sort.iperm : nullptr;
             kdevs[i] = kernels[i].dev;
             maxV[i] = kernels[i].maxV;
             maxRow[i] = kernels[i].maxRow;
@@ -333,6 +374,8 @@ struct Engine {
         crf.K = (int)kernels.size();
         crf.F = F;
         crf.activeN = activeN;
+        crf.perm = perm_on ? sort.perm : nullptr;
+        crf.perm_stride = maxNpad;
     }
 
     // Lattice + normalisation of kernels [k0, k0+n) for every frame (PottsPotential3D ctor).
@@ -341,6 +384,27 @@ struct Engine {
     int build_kernels(int k0, int n)
     {
         for (int k = k0; k < k0 + n; ++k) kernels[k].maxV = kernels[k].dev.Epad;
+        if (k0 == 0) {                                     // a build of every kernel decides the internal point order afresh
+            static const bool no_perm = getenv("LCCRF_NO_PERM") != nullptr;   // A/B and cross-check switch: same results either way
+            const int NAp = activeN > 0 ? activeN : maxN;
+            const bool want = allow_perm && !no_perm && n > 0 && n == (int)kernels.size() && NAp >= kPermMinPoints;
+            if (want || perm_on) {                         // whatever was derived in the old order is stale
+                if (unary_is_label) unary_deferred = true;
+                unary_p_valid = false;
+            }
+            perm_on = false;
+            sync_views();
+            if (want) {
+                int rcs = ensure_sort_scratch();
+                if (rcs) return rcs;
+                int src = 0;                               // one order for the whole CRF (Q is shared): the kernel with most dimensions decides
+                for (int k = 1; k < n; ++k)
+                    if (kernels[k].dev.d > kernels[src].dev.d) src = k;
+                launch_sort_points(kdevs[src], crf, sort, stream);
+                HIP_TRY(hipGetLastError());
+                perm_on = true;
+            }
+        }
         sync_views();
         const bool no_small = getenv("LCCRF_NO_FUSED_BUILD") != nullptr;   // debug / cross-check switch
         int k = k0;
@@ -398,7 +462,7 @@ struct Engine {
         sync_views();
         sizes_known = true;
         sized_engine = 1;
-        if (engine_pref != 1 && fused_supported(crf, kdevs.data(), maxV.data(), maxRow.data(), &fused_lds)) sized_engine = 2;
+        if (engine_pref != 1 && !perm_on && fused_supported(crf, kdevs.data(), maxV.data(), maxRow.data(), &fused_lds)) sized_engine = 2;
         if (engine_pref == 2 && sized_engine != 2)
             return fail(LCCRF_E_CAPACITY, "fused engine requested but the problem does not fit one workgroup's LDS");
         return LCCRF_OK;
@@ -419,6 +483,7 @@ struct Engine {
         }
         crf.unary = unary_own;
         unary_deferred = true;
+        unary_is_label = true;
         deferred_label = label;
         deferred_tbl = tb;
         unary_set = true;
@@ -508,13 +573,27 @@ struct Engine {
 
     int inference_sized(int n_iter, int with_map, float relax)
     {
-        int rc = ensure_unary();
+        int rc = learn_sizes();                            // (builds what is pending: the internal point order is known after this)
         if (rc) return rc;
-        rc = learn_sizes();
+        rc = ensure_unary();
         if (rc) return rc;
         engine_used = sized_engine;
         last_with_map = with_map;
-        if (sized_engine == 2) {
+        if (perm_on) {
+            // locality mode: iterate on the internal-order view, un-permute Q on the way out (densecrf_base.h:65-73 otherwise)
+            CrfDev cp = crf;
+            cp.Q = Qp;
+            if (!unary_is_label) {
+                if (!unary_p_valid) launch_permute_rows(crf, unary_p, crf.unary, L, 1, stream);
+                unary_p_valid = true;
+                cp.unary = unary_p;
+            }
+            launch_start(cp, stream);
+            for (int it = 0; it < n_iter; ++it) launch_step_stream(cp, kdevs.data(), maxV.data(), relax, stream);
+            launch_permute_rows(crf, crf.Q, Qp, L, 0, stream);
+            if (with_map) launch_map(crf, stream);
+            started = true;
+        } else if (sized_engine == 2) {
             launch_inference_fused(crf, kdevs.data(), maxV.data(), maxRow.data(), n_iter, with_map, relax, stream);
             started = true;
         } else {
@@ -816,6 +895,7 @@ int lccrf_set_unary(lccrf_handle h, const float *unary)
     }
     e.crf.unary = e.unary_own;
     e.unary_deferred = false;
+    e.unary_is_label = false;
     e.unary_set = true;
     return LCCRF_OK;
 }
@@ -1113,6 +1193,7 @@ int lccrf_batch_create(lccrf_batch_handle *out, int device_id, const lccrf_batch
     lccrf_batch *b = new (std::nothrow) lccrf_batch;
     if (!b) return fail(LCCRF_E_NOMEM, "host allocation failed");
     b->desc = *desc;
+    b->eng.allow_perm = true;
     rc = b->eng.init(device_id, desc->max_frames, desc->max_points, desc->n_labels);
     for (int k = 0; k < desc->n_kernels && !rc; ++k) rc = b->eng.add_kernel(desc->feat_dims[k], desc->weights[k], true, false);
     if (!rc && hipStreamSynchronize(b->eng.stream) != hipSuccess)      // every allocation is zeroed before the handle is handed out
@@ -1172,6 +1253,8 @@ int lccrf_batch_set_inputs_host(lccrf_batch_handle b, int n_frames, const int32_
     if (unary) {
         HIP_TRY(hipMemcpy(e.unary_own, unary, sizeof(float) * n_frames * per * e.L, hipMemcpyHostToDevice));
         e.unary_deferred = false;
+        e.unary_is_label = false;
+        e.unary_p_valid = false;
     } else {
         HIP_TRY(hipMemcpy(e.label_own, label, sizeof(int16_t) * n_frames * per, hipMemcpyHostToDevice));
         e.defer_unary_from_label(e.label_own, conf);
@@ -1205,6 +1288,8 @@ int lccrf_batch_bind_inputs_device(lccrf_batch_handle b, int n_frames, const int
     if (d_unary) {
         e.crf.unary = const_cast<float *>(d_unary);   // read-only use
         e.unary_deferred = false;
+        e.unary_is_label = false;
+        e.unary_p_valid = false;
     } else {
         e.defer_unary_from_label(d_label, conf);
     }
@@ -1355,8 +1440,17 @@ int lccrf_batch_get_norm_host(lccrf_batch_handle b, int kernel, float *norm_out)
     Engine &e = b->eng;
     { int rl = b->eng.resolve_late(); if (rl) return rl; }
     { int rf = b->eng.flush_builds(); if (rf) return rf; }   // lccrf_batch_run builds nothing in HBM
+    const float *src = e.kernels[kernel].dev.norm;
+    if (e.perm_on) {                                  // the lattice's point arrays are in the internal order: undo it for the caller
+        int rc = e.need_io();
+        if (rc) return rc;
+        HIP_TRY(hipMemsetAsync(e.io_a, 0, sizeof(float) * (size_t)e.F * e.maxN, e.stream));
+        launch_permute_rows(e.crf, e.io_a, src, 1, 0, e.stream);
+        HIP_TRY(hipGetLastError());
+        src = e.io_a;
+    }
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(norm_out, e.kernels[kernel].dev.norm, sizeof(float) * (size_t)e.F * e.maxN, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(norm_out, src, sizeof(float) * (size_t)e.F * e.maxN, hipMemcpyDeviceToHost));
     return LCCRF_OK;
 }
 

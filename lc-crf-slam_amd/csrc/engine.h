@@ -38,7 +38,7 @@ struct KernelDev {
     uint8_t *rank;        // [F][maxNpad][d]   rank of each coordinate
     float *bary;          // [F][Epad]         barycentric weight of every entry
     int *offset;          // [F][Epad]         vertex id of every entry (reference offset_)
-    int *slot;            // [F][cap]          hash slots: lowest entry id with that key, or -1
+    unsigned long long *slot;   // [F][cap]    hash slots: (32-bit fingerprint of the key) << 32 | lowest entry id with that key; ~0 = empty
     int *slot_of;         // [F][Epad]         slot index each entry landed in
     int *flag;            // [F][Epad+1]       scratch: first-occurrence flags / row counts / unsorted rows
     int *prefix;          // [F][Epad+1]       exclusive scan of flag == dense vertex id of a first entry
@@ -53,9 +53,22 @@ struct KernelDev {
     // compact copies for the fused engine's prologue (frames with Epad < 65535 only; undefined otherwise)
     unsigned *pk;         // [F][Epad]         (offset + 1) | csr_pos << 16 of every real entry
     unsigned *nbr16;      // [F][D1][Epad]     (n1 + 1) | (n2 + 1) << 16 per (axis, vertex), 0 = absent
+    // compressed blur-neighbour table of the two-label streaming iteration (large frames; null otherwise).  Two thirds of
+    // the neighbour slots of a sparse lattice are absent: 2 presence bits per (axis, vertex) + the present ids in vertex
+    // order (n1 before n2) + a running count per 64 vertices replace the 8-byte pair (~3 B instead of 8 B per vertex and pass)
+    unsigned *nflag;      // [F][D1][Epad/16 + 4]   bit 2i = n1 of vertex 16w+i present, bit 2i+1 = its n2
+    int *nbase;           // [F][D1][Epad/64 + 1]   list entries before vertex 64g
+    int *ncount;          // [F][D1][Epad/64 + 1]   list entries of group g (build scratch: nbase = its exclusive scan)
+    int *nlist;           // [F][D1][2*Epad]        the present neighbour ids
     int *V_host, *rowmax_host;   // [F] pinned host mirrors of V / rowmax written by the fused build (or null)
     float *norm;          // [F][maxN]         1/(K*1 + 1e-20)  (PottsPotential3D::norm_)
     float *val0, *val1;   // [F][vstride]      lattice values (see vbase)
+    // Locality mode (large frames on the streaming engine): the points of a frame are processed in an internal order --
+    // position i holds original point perm[i] -- chosen so that points of neighbouring lattice cells sit next to each
+    // other; every point-indexed array above (rem0, rank, bary, offset, norm, csr_pt ...) is in that order.  Results do
+    // not depend on it: CSR rows stay ordered by ORIGINAL point index (quirk Q6), vertices are matched by key.  Null = off.
+    const int *perm;      // [F][maxNpad]      position -> original point (identity on the phantom lanes)
+    const int *iperm;     // [F][maxNpad]      original point -> position
 };
 
 // Device view of the CRF state of a batch.
@@ -69,9 +82,28 @@ struct CrfDev {
     int16_t *map;         // [F][maxN]
     unsigned long long *map_bits;   // [F][bits_stride] or null: the MAP labels of a binary CRF, one bit per point (bit i%64 of
     int bits_stride;                //   word i/64) -- the wire format of the multi-GPU label gather; bits_stride = ceil(maxN/64)
+    const int *perm;      // [F][perm_stride] or null: locality mode (see KernelDev::perm); unary / Q / next of THIS view are then
+    int perm_stride;      //   in permuted order and the caller un-permutes Q on the way out
+};
+
+// scratch of the point sort (locality mode), owned by the engine
+struct SortScratch {
+    int bits;             // bucket bits of the counting sort (8..16)
+    int *cells;           // [F][maxNpad][kMaxD] lattice cell of every point (int32); later the unordered buckets
+    int *partial;         // [F][ceil(maxNpad/256)][2*kMaxD] per-workgroup min / max of the cells
+    int *plan;            // [F][3*kMaxD]        per dimension: lowest cell, span, code bits
+    int *code;            // [F][maxNpad]        Z-order bucket of every point
+    int *hist;            // [F][2^bits + 1]     bucket counts
+    int *start;           // [F][2^bits + 1]     exclusive scan of hist, advanced to the bucket ends by the scatter
+    int *tiles;           // [F][ceil((2^bits+1)/4096)] scan scratch
+    int *perm, *iperm;    // [F][maxNpad]        the result
 };
 
 // ---- streaming engine (any size; every array in HBM) ---------------------------------
+// locality mode: Z-order buckets of the points' lattice cells under kernel kd -> ss.perm / ss.iperm
+void launch_sort_points(const KernelDev &kd, const CrfDev &c, const SortScratch &ss, hipStream_t s);
+// dst[f][i][0..width) = src[f][perm[i]][0..width) (gather = 1) or dst[f][perm[i]][..] = src[f][i][..] (gather = 0), i < n_points[f]
+void launch_permute_rows(const CrfDev &c, float *dst, const float *src, int width, int gather, hipStream_t s);
 void launch_build_kernel(const KernelDev &kd, const CrfDev &c, int maxV_hint, hipStream_t s);
 void launch_norm(const KernelDev &kd, const CrfDev &c, int maxV, hipStream_t s);
 // unary[i][:] from labels (densecrf3d.h:116-129); the 2L+1 energies {u, n[L], p[L]} are passed by value (no table

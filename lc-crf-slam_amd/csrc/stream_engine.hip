@@ -18,12 +18,34 @@
 #include "lattice_device.h"
 
 #include <algorithm>
+#include <cstdlib>
 
 namespace lccrf {
 
 namespace {
 
 constexpr int kBlock = 256;
+constexpr unsigned long long kEmptySlot = ~0ull;
+
+// A/B switches of the streaming build (scripts/gpu_ab_build.sh); the defaults are what measured fastest
+#ifndef LCCRF_LOCAL_HASH
+#define LCCRF_LOCAL_HASH 1
+#endif
+#ifndef LCCRF_BUILD_XCD
+#define LCCRF_BUILD_XCD 1
+#endif
+#ifndef LCCRF_NBR_VERTEX_MAJOR
+#define LCCRF_NBR_VERTEX_MAJOR 1
+#endif
+template <int D>
+__device__ __forceinline__ unsigned table_slot(const int16_t (&key)[D], unsigned mask)
+{
+#if LCCRF_LOCAL_HASH
+    return hash_key_local<D>(key, mask);
+#else
+    return hash_key<D>(key) & mask;
+#endif
+}
 
 // XCD-aware grids for the mean-field iteration of many frames in flight.  The chip's eight XCDs have private 4 MB L2s and
 // workgroup L of a launch runs on XCD L % 8 (observed dispatch order; used for speed only, never for correctness).  With the
@@ -68,7 +90,8 @@ __global__ void __launch_bounds__(kBlock) k_points(KernelDev kd, const int *__re
     if (n >= Npad) return;
 
     float feat[D];
-    const float *fp = kd.feat + ((size_t)f * kd.maxN + n) * D;
+    const int src = (kd.perm && n < N) ? kd.perm[(size_t)f * kd.maxNpad + n] : n;   // locality mode: position n holds point perm[n]
+    const float *fp = kd.feat + ((size_t)f * kd.maxN + src) * D;
 #pragma unroll
     for (int j = 0; j < D; ++j) feat[j] = (n < N) ? fp[j] : 0.0f;   // phantom lanes, :299
 
@@ -90,28 +113,35 @@ __global__ void __launch_bounds__(kBlock) k_points(KernelDev kd, const int *__re
 // holding the LOWEST entry id carrying that key, i.e. the entry at which the reference's
 // sequential HashTableCPU::find(create=true) would have created the vertex (:134-161,371-377).
 template <int D>
-__global__ void __launch_bounds__(kBlock) k_insert(KernelDev kd, const int *__restrict__ n_points)
+__global__ void __launch_bounds__(kBlock) k_insert(KernelDev kd, const int *__restrict__ n_points, int F, int nb)
 {
     constexpr int D1 = D + 1;
-    const int f = blockIdx.y;
+    const FrameBlock fb = frame_block(nb);               // many frames: one XCD per frame, its table stays in that L2
+    const int f = fb.f;
+    if (f >= F) return;
     const int Npad = (n_points[f] + 3) & ~3;
-    const int e = blockIdx.x * kBlock + threadIdx.x;
+    const int e = fb.bx * kBlock + threadIdx.x;
     if (e >= Npad * D1) return;
 
     int16_t key[D];
     load_entry_key<D>(kd, f, e, key);
     const unsigned mask = (unsigned)kd.cap - 1u;
-    unsigned h = hash_key<D>(key) & mask;
-    int *slot = kd.slot + (size_t)f * kd.cap;
+    unsigned h = table_slot<D>(key, mask);
+    // a slot carries a fingerprint of its key: a probe that runs into other keys rejects them from the slot word alone
+    // (the key itself -- two more loads from the owner's point record -- is read only when the fingerprints agree)
+    const unsigned long long me = ((unsigned long long)hash_key<D>(key) << 32) | (unsigned)e;
+    unsigned long long *slot = kd.slot + (size_t)f * kd.cap;
     for (;;) {
-        const int prev = atomicCAS(&slot[h], kEmpty, e);
-        if (prev == kEmpty || prev == e) break;
-        int16_t other[D];
-        load_entry_key<D>(kd, f, prev, other);
-        bool same = true;
+        const unsigned long long prev = atomicCAS(&slot[h], kEmptySlot, me);
+        if (prev == kEmptySlot || prev == me) break;
+        if ((prev >> 32) == (me >> 32)) {
+            int16_t other[D];
+            load_entry_key<D>(kd, f, (int)(unsigned)prev, other);
+            bool same = true;
 #pragma unroll
-        for (int i = 0; i < D; ++i) same &= (other[i] == key[i]);
-        if (same) { atomicMin(&slot[h], e); break; }
+            for (int i = 0; i < D; ++i) same &= (other[i] == key[i]);
+            if (same) { atomicMin(&slot[h], me); break; }          // same fingerprint: the lower entry id wins
+        }
         h = (h + 1u) & mask;
     }
     kd.slot_of[(size_t)f * kd.Epad + e] = (int)h;
@@ -127,7 +157,7 @@ __global__ void __launch_bounds__(kBlock) k_first_flag(KernelDev kd, const int *
     int v = 0;
     if (e < live) {
         const int s = kd.slot_of[(size_t)f * kd.Epad + e];
-        v = (kd.slot[(size_t)f * kd.cap + s] == e);
+        v = ((int)(unsigned)kd.slot[(size_t)f * kd.cap + s] == e);
     }
     kd.flag[(size_t)f * (kd.Epad + 1) + e] = v;
 }
@@ -222,6 +252,202 @@ void scan_frames(const int *in, int *out, int n, int stride, int *total, int *ti
     if (tiles > 1) k_scan_apply<<<dim3(tiles, F), 1024, 0, s>>>(out, n, stride, tile_sum, tiles);
 }
 
+// ---------------------------------------------------------------------------------------
+// locality mode: an internal ordering of a frame's points along a Z-order curve of their lattice cells
+// ---------------------------------------------------------------------------------------
+// The blur pass gathers two neighbour values per vertex; with the reference's vertex numbering (insertion order = point
+// order) the neighbours that belong to OTHER points' simplices sit anywhere in the frame's value array, and every miss
+// moves a 128-byte line for 8 useful bytes (profiles/r3_fetchcal).  Numbering follows the order in which points are
+// processed, so processing them cell by cell along a space-filling curve puts the vertices of neighbouring cells next to
+// each other.  Only locality depends on this order, never a result: it is a counting sort on a 2^bits-bucket Z-order code
+// (one pass, atomics; buckets of up to 64 points are then put in index order so the order is reproducible).
+
+// cell of every real point: the remainder-0 lattice point's first D coordinates / (D+1), permutohedral_cpu.h:304-319;
+// per-dimension min / max of every workgroup's cells go to ss.partial (reduced per frame by k_sort_plan)
+template <int D>
+__global__ void __launch_bounds__(kBlock) k_sort_cells(KernelDev kd, const int *__restrict__ n_points, SortScratch ss)
+{
+    __shared__ int red[kBlock / 64][2 * D];
+    const int f = blockIdx.y;
+    const int N = n_points[f];
+    const int n = blockIdx.x * kBlock + threadIdx.x;
+    int cell[D];
+    const bool live = n < N;
+    {
+        float feat[D];
+        const float *fp = kd.feat + ((size_t)f * kd.maxN + (live ? n : 0)) * D;
+#pragma unroll
+        for (int j = 0; j < D; ++j) feat[j] = N > 0 ? fp[j] : 0.0f;
+        float el[D + 1];
+        float sm = 0.0f;
+#pragma unroll
+        for (int j = D; j > 0; --j) {
+            const float cf = feat[j - 1] * kd.scale[j - 1];
+            el[j] = sm - (float)j * cf;
+            sm += cf;
+        }
+        el[0] = sm;
+#pragma unroll
+        for (int j = 0; j < D; ++j) cell[j] = __float2int_rn(kd.inv_dp1 * el[j]);
+    }
+    if (live) {
+        int *cp = ss.cells + ((size_t)f * kd.maxNpad + n) * kMaxD;
+#pragma unroll
+        for (int j = 0; j < D; ++j) cp[j] = cell[j];
+    }
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+        int lo = live ? cell[j] : 0x7fffffff, hi = live ? cell[j] : (int)0x80000000;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            lo = min(lo, __shfl_xor(lo, o, 64));
+            hi = max(hi, __shfl_xor(hi, o, 64));
+        }
+        if ((threadIdx.x & 63) == 0) {
+            red[threadIdx.x >> 6][2 * j] = lo;
+            red[threadIdx.x >> 6][2 * j + 1] = hi;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * D) {
+        int x = red[0][threadIdx.x];
+        for (int w = 1; w < kBlock / 64; ++w) x = (threadIdx.x & 1) ? max(x, red[w][threadIdx.x]) : min(x, red[w][threadIdx.x]);
+        ss.partial[((size_t)f * gridDim.x + blockIdx.x) * 2 * kMaxD + threadIdx.x] = x;
+    }
+}
+
+// One workgroup per frame: bounds of the frame's cells, then the plan of the Z-order code -- the `bits` code bits are
+// dealt to the dimensions by their spans (the widest remaining span gets the next bit).  plan[f] = {lo[kMaxD], span[kMaxD], nb[kMaxD]}.
+__global__ void __launch_bounds__(kBlock) k_sort_plan(int D, int nblocks, SortScratch ss)
+{
+    __shared__ int red[kBlock / 64][2 * kMaxD];
+    __shared__ int bnd[2 * kMaxD];
+    const int f = blockIdx.x;
+    for (int j = 0; j < D; ++j) {
+        int lo = 0x7fffffff, hi = (int)0x80000000;
+        for (int b = threadIdx.x; b < nblocks; b += kBlock) {
+            const int *pp = ss.partial + ((size_t)f * nblocks + b) * 2 * kMaxD;
+            lo = min(lo, pp[2 * j]);
+            hi = max(hi, pp[2 * j + 1]);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            lo = min(lo, __shfl_xor(lo, o, 64));
+            hi = max(hi, __shfl_xor(hi, o, 64));
+        }
+        if ((threadIdx.x & 63) == 0) {
+            red[threadIdx.x >> 6][2 * j] = lo;
+            red[threadIdx.x >> 6][2 * j + 1] = hi;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * D) {
+        int x = red[0][threadIdx.x];
+        for (int w = 1; w < kBlock / 64; ++w) x = (threadIdx.x & 1) ? max(x, red[w][threadIdx.x]) : min(x, red[w][threadIdx.x]);
+        bnd[threadIdx.x] = x;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int *plan = ss.plan + (size_t)f * 3 * kMaxD;
+        long rem[kMaxD];
+        int nb[kMaxD];
+        for (int j = 0; j < D; ++j) {
+            const int lo = bnd[2 * j], hi = bnd[2 * j + 1];
+            const int span = hi >= lo ? hi - lo + 1 : 1;   // (an empty frame has no cells)
+            plan[j] = hi >= lo ? lo : 0;
+            plan[kMaxD + j] = span;
+            rem[j] = span;
+            nb[j] = 0;
+        }
+        for (int b = 0; b < ss.bits; ++b) {
+            int best = 0;
+            for (int j = 1; j < D; ++j)
+                if (rem[j] > rem[best]) best = j;
+            ++nb[best];
+            rem[best] = (rem[best] + 1) >> 1;
+        }
+        for (int j = 0; j < D; ++j) plan[2 * kMaxD + j] = nb[j];
+    }
+}
+
+// Z-order bucket of every point: each coordinate quantised to its share of the code bits, bits interleaved level by level
+template <int D>
+__global__ void __launch_bounds__(kBlock) k_sort_code(KernelDev kd, const int *__restrict__ n_points, SortScratch ss)
+{
+    const int f = blockIdx.y;
+    const int N = n_points[f];
+    const int n = blockIdx.x * kBlock + threadIdx.x;
+    if (n >= N) return;
+    const int *plan = ss.plan + (size_t)f * 3 * kMaxD;
+    const int *cp = ss.cells + ((size_t)f * kd.maxNpad + n) * kMaxD;
+    unsigned q[D];
+    int nb[D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+        nb[j] = plan[2 * kMaxD + j];
+        q[j] = (unsigned)((((unsigned long long)(unsigned)(cp[j] - plan[j])) << nb[j]) / (unsigned)plan[kMaxD + j]);
+    }
+    unsigned code = 0;
+    int pos = 0;
+    for (int level = 0; level < ss.bits && pos < ss.bits; ++level)
+#pragma unroll
+        for (int j = 0; j < D; ++j)
+            if (nb[j] > level) code |= ((q[j] >> level) & 1u) << pos++;
+    ss.code[(size_t)f * kd.maxNpad + n] = (int)code;
+    atomicAdd(&ss.hist[(size_t)f * ((1 << ss.bits) + 1) + code], 1);
+}
+
+// arrival order of the scatter is arbitrary: ss.cells (dead by now) takes the unordered buckets ...
+__global__ void __launch_bounds__(kBlock) k_sort_scatter(int maxNpad, const int *__restrict__ n_points, SortScratch ss)
+{
+    const int f = blockIdx.y;
+    const int n = blockIdx.x * kBlock + threadIdx.x;
+    if (n >= n_points[f]) return;
+    const int code = ss.code[(size_t)f * maxNpad + n];
+    const int pos = atomicAdd(&ss.start[(size_t)f * ((1 << ss.bits) + 1) + code], 1);   // start[c] ends up at the END of bucket c
+    ss.cells[(size_t)f * maxNpad * kMaxD + pos] = n;
+}
+
+// ... and every point takes the place of its rank inside its bucket, so the order is reproducible (index order inside
+// buckets of up to 64 points; larger buckets -- everything in one cell -- keep their arrival order: locality only)
+__global__ void __launch_bounds__(kBlock) k_sort_place(int maxNpad, const int *__restrict__ n_points, SortScratch ss)
+{
+    const int f = blockIdx.y;
+    const int pos = blockIdx.x * kBlock + threadIdx.x;
+    int *p = ss.perm + (size_t)f * maxNpad, *ip = ss.iperm + (size_t)f * maxNpad;
+    if (pos >= maxNpad) return;
+    if (pos >= n_points[f]) {                            // phantom lanes and the unused tail: identity
+        p[pos] = pos;
+        ip[pos] = pos;
+        return;
+    }
+    const int *tmp = ss.cells + (size_t)f * maxNpad * kMaxD;
+    const int *end = ss.start + (size_t)f * ((1 << ss.bits) + 1);
+    const int i = tmp[pos], c = ss.code[(size_t)f * maxNpad + i];
+    const int lo = c ? end[c - 1] : 0, hi = end[c];
+    int at = pos;
+    if (hi - lo <= 64) {
+        at = lo;
+        for (int q = lo; q < hi; ++q) at += tmp[q] < i;
+    }
+    p[at] = i;
+    ip[i] = at;
+}
+
+template <int D>
+void sort_points_d(const KernelDev &kd, const CrfDev &c, const SortScratch &ss, hipStream_t s)
+{
+    const int F = c.F, nbk = (1 << ss.bits) + 1;
+    const dim3 gp = grid_for(kd.maxNpad, F);
+    (void)hipMemsetAsync(ss.hist, 0, (size_t)F * nbk * sizeof(int), s);
+    k_sort_cells<D><<<gp, kBlock, 0, s>>>(kd, c.n_points, ss);
+    k_sort_plan<<<F, kBlock, 0, s>>>(D, (int)gp.x, ss);
+    k_sort_code<D><<<gp, kBlock, 0, s>>>(kd, c.n_points, ss);
+    scan_frames(ss.hist, ss.start, nbk, nbk, nullptr, ss.tiles, F, s);
+    k_sort_scatter<<<gp, kBlock, 0, s>>>(kd.maxNpad, c.n_points, ss);
+    k_sort_place<<<gp, kBlock, 0, s>>>(kd.maxNpad, c.n_points, ss);
+}
+
 // offset[e] = dense id of e's vertex; the first entry of each vertex registers as its
 // representative.  Ids come out in first-insertion order, exactly the reference's ids.
 __global__ void __launch_bounds__(kBlock) k_offsets(KernelDev kd, const int *__restrict__ n_points)
@@ -232,7 +458,7 @@ __global__ void __launch_bounds__(kBlock) k_offsets(KernelDev kd, const int *__r
     if (e >= live) return;
     const size_t fe = (size_t)f * kd.Epad;
     const int *prefix = kd.prefix + (size_t)f * (kd.Epad + 1);
-    const int r = kd.slot[(size_t)f * kd.cap + kd.slot_of[fe + e]];
+    const int r = (int)(unsigned)kd.slot[(size_t)f * kd.cap + kd.slot_of[fe + e]];
     const int id = prefix[r];
     kd.offset[fe + e] = id;
     if (r == e) kd.rep[fe + id] = e;
@@ -242,17 +468,20 @@ template <int D>
 __device__ __forceinline__ int find_vertex(const KernelDev &kd, int f, const int16_t (&key)[D])
 {
     const unsigned mask = (unsigned)kd.cap - 1u;
-    unsigned h = hash_key<D>(key) & mask;
-    const int *slot = kd.slot + (size_t)f * kd.cap;
+    unsigned h = table_slot<D>(key, mask);
+    const unsigned fp = hash_key<D>(key);
+    const unsigned long long *slot = kd.slot + (size_t)f * kd.cap;
     for (;;) {
-        const int r = slot[h];
-        if (r == kEmpty) return -1;
-        int16_t other[D];
-        load_entry_key<D>(kd, f, r, other);
-        bool same = true;
+        const unsigned long long r = slot[h];
+        if (r == kEmptySlot) return -1;
+        if ((unsigned)(r >> 32) == fp) {
+            int16_t other[D];
+            load_entry_key<D>(kd, f, (int)(unsigned)r, other);
+            bool same = true;
 #pragma unroll
-        for (int i = 0; i < D; ++i) same &= (other[i] == key[i]);
-        if (same) return kd.prefix[(size_t)f * (kd.Epad + 1) + r];
+            for (int i = 0; i < D; ++i) same &= (other[i] == key[i]);
+            if (same) return kd.prefix[(size_t)f * (kd.Epad + 1) + (unsigned)r];
+        }
         h = (h + 1u) & mask;
     }
 }
@@ -261,14 +490,20 @@ __device__ __forceinline__ int find_vertex(const KernelDev &kd, int f, const int
 // iff A = n1_j(B) -- so one hash probe per (axis, vertex) finds n2 and fills both sides; the table was preset to
 // -1 (absent) by the caller.
 template <int D>
-__global__ void __launch_bounds__(kBlock) k_neighbors(KernelDev kd)
+__global__ void __launch_bounds__(kBlock) k_neighbors(KernelDev kd, int F, int nb)
 {
     constexpr int D1 = D + 1;
-    const int f = blockIdx.y;
+    const FrameBlock fb = frame_block(nb);
+    const int f = fb.f;
+    if (f >= F) return;
     const int V = kd.V[f];
-    const int idx = blockIdx.x * kBlock + threadIdx.x;
+    const int idx = fb.bx * kBlock + threadIdx.x;
     if (idx >= V * D1) return;
+#if LCCRF_NBR_VERTEX_MAJOR
+    const int v = idx / D1, j = idx - v * D1;            // vertex-major: the D1 probes of a vertex go to neighbouring table lines
+#else
     const int j = idx / V, v = idx - j * V;
+#endif
     int16_t key[D], n2[D];
     load_entry_key<D>(kd, f, kd.rep[(size_t)f * kd.Epad + v], key);
 #pragma unroll
@@ -278,9 +513,9 @@ __global__ void __launch_bounds__(kBlock) k_neighbors(KernelDev kd)
         if (t == j) n2[t] = (int16_t)(key[t] - D);
     const int b = find_vertex<D>(kd, f, n2);
     if (b < 0) return;
-    int *nb = kd.nbr + ((size_t)f * D1 + j) * kd.Epad * 2;
-    nb[2 * v + 1] = b;                   // my n2
-    nb[2 * b] = v;                       // its n1
+    int *nbp = kd.nbr + ((size_t)f * D1 + j) * kd.Epad * 2;
+    nbp[2 * v + 1] = b;                  // my n2
+    nbp[2 * b] = v;                      // its n1
 }
 
 // nbr16 = (n1 + 1) | (n2 + 1) << 16 per (axis, vertex) for frames whose ids fit 16 bits (the fused engine's table)
@@ -293,6 +528,49 @@ __global__ void __launch_bounds__(kBlock) k_neighbors16(KernelDev kd)
     const int j = idx / V, v = idx - j * V;
     const int2 r = reinterpret_cast<const int2 *>(kd.nbr)[((size_t)f * kd.D1 + j) * kd.Epad + v];
     kd.nbr16[((size_t)f * kd.D1 + j) * kd.Epad + v] = (unsigned)(r.x + 1) | ((unsigned)(r.y + 1) << 16);
+}
+
+// ---- compressed neighbour table (KernelDev::nflag / nbase / nlist) ---------------------------------
+__device__ __forceinline__ unsigned spread16(unsigned x)          // bit i of the low half -> bit 2i
+{
+    x &= 0xffffu;
+    x = (x | (x << 8)) & 0x00ff00ffu;
+    x = (x | (x << 4)) & 0x0f0f0f0fu;
+    x = (x | (x << 2)) & 0x33333333u;
+    x = (x | (x << 1)) & 0x55555555u;
+    return x;
+}
+
+// One lane per (axis, vertex), vertices of a wavefront = one group of 64.  pass 0: presence bits + group counts;
+// pass 1 (after the scan of the counts): the ids.
+__global__ void __launch_bounds__(kBlock) k_nbr_compress(KernelDev kd, int pass, int F, int nb)
+{
+    const FrameBlock fb = frame_block(nb);
+    const int f = fb.f;
+    if (f >= F) return;
+    const int V = kd.V[f];
+    const int G = kd.Epad / 64 + 1, W = kd.Epad / 16 + 4;
+    const int gidx = fb.bx * (kBlock / 64) + (threadIdx.x >> 6);       // (axis, group) of this wavefront
+    const int j = gidx / G, g = gidx - j * G;
+    if (j >= kd.D1 || g * 64 >= V) return;                             // (uniform per wavefront)
+    const int lane = threadIdx.x & 63, v = g * 64 + lane;
+    const size_t plane = (size_t)f * kd.D1 + j;
+    int2 nbv = make_int2(-1, -1);
+    if (v < V) nbv = reinterpret_cast<const int2 *>(kd.nbr)[plane * kd.Epad + v];
+    const unsigned long long b1 = __ballot(nbv.x >= 0), b2 = __ballot(nbv.y >= 0);
+    if (pass == 0) {
+        if ((lane & 15) == 0) {
+            const unsigned sh = lane;
+            kd.nflag[plane * W + (v >> 4)] = spread16((unsigned)(b1 >> sh)) | (spread16((unsigned)(b2 >> sh)) << 1);
+        }
+        if (lane == 0) kd.ncount[plane * G + g] = __popcll(b1) + __popcll(b2);
+    } else {
+        const unsigned long long below = (1ull << lane) - 1ull;
+        int p = kd.nbase[plane * G + g] + __popcll(b1 & below) + __popcll(b2 & below);
+        int *list = kd.nlist + plane * kd.Epad * 2;
+        if (nbv.x >= 0) list[p++] = nbv.x;
+        if (nbv.y >= 0) list[p] = nbv.y;
+    }
 }
 
 // ---- CSR of splat contributions: vertex -> (point, weight), points ascending ------------
@@ -333,7 +611,21 @@ __global__ void __launch_bounds__(kBlock) k_csr_fill(KernelDev kd, const int *__
     const size_t f1 = (size_t)f * (kd.Epad + 1);
     const int v = kd.offset[(size_t)f * kd.Epad + e];
     const int k = atomicSub(&kd.flag[f1 + v], 1) - 1;   // counts run down to zero
-    kd.slot_of[(size_t)f * kd.Epad + kd.rowptr[f1 + v] + k] = e;   // slot_of reused: unsorted rows
+    // rows are ordered by ORIGINAL point index whatever the internal order of the points: list the entry under its original id
+    int oe = e;
+    if (kd.perm) {
+        const int pt = e / kd.D1;
+        oe = kd.perm[(size_t)f * kd.maxNpad + pt] * kd.D1 + (e - pt * kd.D1);
+    }
+    kd.slot_of[(size_t)f * kd.Epad + kd.rowptr[f1 + v] + k] = oe;   // slot_of reused: unsorted rows
+}
+
+// entry id in the internal order of an entry listed under its original id
+__device__ __forceinline__ int internal_entry(const KernelDev &kd, int f, int oe)
+{
+    if (!kd.iperm) return oe;
+    const int pt = oe / kd.D1;
+    return kd.iperm[(size_t)f * kd.maxNpad + pt] * kd.D1 + (oe - pt * kd.D1);
 }
 
 // Rows come out of k_csr_fill in arrival order; the splat needs them in ascending entry order.  Short rows (the
@@ -357,8 +649,9 @@ __global__ void __launch_bounds__(kBlock) k_csr_order(KernelDev kd, const int *_
     if (p >= n_points[f] * kd.D1) return;
     const size_t fe = (size_t)f * kd.Epad, f1 = (size_t)f * (kd.Epad + 1);
     const int *rows = kd.slot_of + fe;
-    const int e = rows[p];
-    const int v = kd.offset[fe + e];
+    const int e = rows[p];                               // (original id: what the row is ordered by)
+    const int ei = internal_entry(kd, f, e);
+    const int v = kd.offset[fe + ei];
     const int s = kd.rowptr[f1 + v], t = kd.rowptr[f1 + v + 1];
     if (t - s > kLongRow) {                              // flag[] is all zero again after k_csr_fill: reuse it as the list of
         if (p == s) kd.flag[f1 + atomicAdd(&kd.flag[f1 + kd.Epad], 1)] = v;   // long rows, its last slot as their count
@@ -366,7 +659,7 @@ __global__ void __launch_bounds__(kBlock) k_csr_order(KernelDev kd, const int *_
     }
     int rank = 0;
     for (int q = s; q < t; ++q) rank += (rows[q] < e);
-    csr_emit(kd, fe, s + rank, e, v);
+    csr_emit(kd, fe, s + rank, ei, v);
 }
 
 // One workgroup per long row: bitonic sort of the row's entry ids in place (global memory, the row belongs to this
@@ -397,7 +690,7 @@ __global__ void __launch_bounds__(kBlock) k_csr_sort_long(KernelDev kd)
                 __syncthreads();
             }
         }
-        for (int i = threadIdx.x; i < n; i += kBlock) csr_emit(kd, fe, s + i, r[i], v);
+        for (int i = threadIdx.x; i < n; i += kBlock) csr_emit(kd, fe, s + i, internal_entry(kd, f, r[i]), v);
         __syncthreads();
     }
 }
@@ -510,8 +803,22 @@ __device__ __forceinline__ int4 load_nbr_pair(const int *p)
 #endif
     return make_int4(x.x, x.y, x.z, x.w);
 }
-// Two vertices per thread: the neighbour pairs (int4), the centres (float4) and the results (float4) move as 16-byte
-// accesses (the frame's value array is laid out so that vertex 2t is 16-byte aligned, see Engine::add_kernel).
+// kPairs vertex PAIRS per lane (pair p of a workgroup's tile: vertices 2p, 2p+1): the neighbour pairs (int4), the centres
+// (float4) and the results (float4) move as 16-byte accesses (the frame's value array is laid out so that vertex 2t is
+// 16-byte aligned, see Engine::add_kernel).  The pass is bound by memory LATENCY x what is in flight, not by instruction
+// count (one pair per lane: ~32 bytes per lane in flight in each of two dependent stages = half the HBM rate): every
+// lane issues the table and centre loads of all its pairs first, then all gathers, then the stores.
+#ifndef LCCRF_BLUR_PAIRS
+#define LCCRF_BLUR_PAIRS 1
+#endif
+constexpr int kPairs = LCCRF_BLUR_PAIRS;
+constexpr int kBlurTile = kBlock * kPairs;                // pairs per workgroup
+
+__device__ __forceinline__ float4 blur_pair(const float4 &c, const float2 &x0, const float2 &y0, const float2 &x1, const float2 &y1)
+{
+    return make_float4(c.x + 0.5f * (x0.x + y0.x), c.y + 0.5f * (x0.y + y0.y), c.z + 0.5f * (x1.x + y1.x), c.w + 0.5f * (x1.y + y1.y));
+}
+
 __global__ void __launch_bounds__(kBlock) k_blur2(KernelDev kd, const float *__restrict__ src,
                                                   float *__restrict__ dst, int j, int F, int nb)
 {
@@ -519,22 +826,207 @@ __global__ void __launch_bounds__(kBlock) k_blur2(KernelDev kd, const float *__r
     const int f = fb.f;
     if (f >= F) return;
     const int V = kd.V[f];
-    const int v = 2 * (fb.bx * kBlock + threadIdx.x);
-    if (v >= V) return;
+    const int p0 = fb.bx * kBlurTile + threadIdx.x;       // first pair of this lane; the others follow at a stride of kBlock
+    if (2 * (fb.bx * kBlurTile) >= V) return;
     const float2 *o = reinterpret_cast<const float2 *>(src + (size_t)f * kd.vstride + kd.vbase);   // o[-1] = absent
     float2 *d = reinterpret_cast<float2 *>(dst + (size_t)f * kd.vstride + kd.vbase);
-    const int *nbp = kd.nbr + (((size_t)f * kd.D1 + j) * kd.Epad + v) * 2;
-    if (v + 1 < V) {
-        const int4 nb = load_nbr_pair(nbp);               // read once per pass: non-temporal, out of the value array's way in L2
-        const float4 c = *reinterpret_cast<const float4 *>(o + v);
-        const float2 x0 = o[nb.x], y0 = o[nb.y], x1 = o[nb.z], y1 = o[nb.w];
-        *reinterpret_cast<float4 *>(d + v) = make_float4(c.x + 0.5f * (x0.x + y0.x), c.y + 0.5f * (x0.y + y0.y),
-                                                         c.z + 0.5f * (x1.x + y1.x), c.w + 0.5f * (x1.y + y1.y));
-    } else {
-        const int2 nb = *reinterpret_cast<const int2 *>(nbp);
-        const float2 c = o[v], x = o[nb.x], y = o[nb.y];
-        d[v] = make_float2(c.x + 0.5f * (x.x + y.x), c.y + 0.5f * (x.y + y.y));
+    const int *nbp = kd.nbr + (((size_t)f * kd.D1 + j) * kd.Epad) * 2;
+    if (2 * (fb.bx * kBlurTile + kBlurTile) <= V) {       // a full tile (every workgroup but a frame's last)
+        int4 n[kPairs];
+        float4 c[kPairs];
+#pragma unroll
+        for (int u = 0; u < kPairs; ++u) {
+            const int v = 2 * (p0 + u * kBlock);
+            n[u] = load_nbr_pair(nbp + 2 * v);            // read once per pass: non-temporal, out of the value array's way in L2
+            c[u] = *reinterpret_cast<const float4 *>(o + v);
+        }
+        float2 g[kPairs][4];
+#pragma unroll
+        for (int u = 0; u < kPairs; ++u) {
+            g[u][0] = o[n[u].x];
+            g[u][1] = o[n[u].y];
+            g[u][2] = o[n[u].z];
+            g[u][3] = o[n[u].w];
+        }
+#pragma unroll
+        for (int u = 0; u < kPairs; ++u)
+            *reinterpret_cast<float4 *>(d + 2 * (p0 + u * kBlock)) = blur_pair(c[u], g[u][0], g[u][1], g[u][2], g[u][3]);
+        return;
     }
+    for (int u = 0; u < kPairs; ++u) {
+        const int v = 2 * (p0 + u * kBlock);
+        if (v + 1 < V) {
+            const int4 n = load_nbr_pair(nbp + 2 * v);
+            const float4 c = *reinterpret_cast<const float4 *>(o + v);
+            *reinterpret_cast<float4 *>(d + v) = blur_pair(c, o[n.x], o[n.y], o[n.z], o[n.w]);
+        } else if (v < V) {
+            const int2 n = *reinterpret_cast<const int2 *>(nbp + 2 * v);
+            const float2 c = o[v], x = o[n.x], y = o[n.y];
+            d[v] = make_float2(c.x + 0.5f * (x.x + y.x), c.y + 0.5f * (x.y + y.y));
+        }
+    }
+}
+
+// The same pass on the compressed neighbour table.  A lane's pair u is pair (wavefront tile) + u * 64 + lane, so that the 64
+// pairs a wavefront handles together cover 128 consecutive vertices = two groups of the table: a lane's four presence
+// bits come from the flag word of its 16-vertex group, the position of its ids in the list from the running count of
+// the first of the two groups plus the set bits of the lanes below (four ballots).
+__global__ void __launch_bounds__(kBlock) k_blur2c(KernelDev kd, const float *__restrict__ src, float *__restrict__ dst, int j, int F,
+                                                   int nb)
+{
+    const FrameBlock fb = frame_block(nb);
+    const int f = fb.f;
+    if (f >= F) return;
+    const int V = kd.V[f];
+    if (2 * (fb.bx * kBlurTile) >= V) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int pw = fb.bx * kBlurTile + wave * (64 * kPairs);          // first pair of this wavefront's kPairs x 64 pairs
+    const int G = kd.Epad / 64 + 1, W = kd.Epad / 16 + 4;
+    const size_t plane = (size_t)f * kd.D1 + j;
+    const unsigned *flag = kd.nflag + plane * W;
+    const int *base = kd.nbase + plane * G;
+    const int *list = kd.nlist + plane * kd.Epad * 2;
+    const float2 *o = reinterpret_cast<const float2 *>(src + (size_t)f * kd.vstride + kd.vbase);   // o[-1] = absent
+    float2 *d = reinterpret_cast<float2 *>(dst + (size_t)f * kd.vstride + kd.vbase);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    unsigned bits[kPairs];
+    int at[kPairs];
+    float4 c[kPairs];
+#pragma unroll
+    for (int u = 0; u < kPairs; ++u) {                                 // stage 1: flags, running counts, centres
+        const int v = 2 * (pw + u * 64 + lane);
+        bits[u] = 0u;
+        at[u] = 0;
+        c[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (v < V) {
+            bits[u] = (__builtin_nontemporal_load(flag + (v >> 4)) >> ((v & 15) * 2)) & (v + 1 < V ? 15u : 3u);
+            at[u] = base[(v >> 7) << 1];
+            if (v + 1 < V) c[u] = *reinterpret_cast<const float4 *>(o + v);
+            else { const float2 t = o[v]; c[u].x = t.x; c[u].y = t.y; }
+        }
+    }
+    int n[kPairs][4];
+#pragma unroll
+    for (int u = 0; u < kPairs; ++u) {                                 // stage 2: the present ids
+        const unsigned long long b0 = __ballot(bits[u] & 1u), b1 = __ballot(bits[u] & 2u), b2 = __ballot(bits[u] & 4u),
+                                 b3 = __ballot(bits[u] & 8u);
+        const int *lp = list + at[u] + (__popcll(b0 & below) + __popcll(b1 & below) + __popcll(b2 & below) + __popcll(b3 & below));
+        int p = 0;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            n[u][t] = -1;
+            if (bits[u] & (1u << t)) n[u][t] = __builtin_nontemporal_load(lp + p++);
+        }
+    }
+    float2 g[kPairs][4];
+#pragma unroll
+    for (int u = 0; u < kPairs; ++u)                                   // stage 3: the gathers
+#pragma unroll
+        for (int t = 0; t < 4; ++t) g[u][t] = o[n[u][t]];
+#pragma unroll
+    for (int u = 0; u < kPairs; ++u) {
+        const int v = 2 * (pw + u * 64 + lane);
+        const float4 r = blur_pair(c[u], g[u][0], g[u][1], g[u][2], g[u][3]);
+        if (v + 1 < V) *reinterpret_cast<float4 *>(d + v) = r;
+        else if (v < V) d[v] = make_float2(r.x, r.y);
+    }
+}
+
+// ---- the LDS-tiled blur pass (locality mode) -------------------------------------------------------------------------
+// What bounds k_blur2 is not bytes but the texture-address path: an 8-byte gather is one cache-line lookup per distinct
+// line and wavefront, ~64 cycles per gather instruction on scattered addresses, four gather instructions per vertex
+// pair (profiles/r3_stream_c5).  In locality mode consecutive vertex ids belong to neighbouring lattice cells, so most
+// present neighbours of a vertex sit within a few thousand ids of it: a workgroup stages a tile of kTileVerts consecutive
+// vertices in LDS with wide coalesced loads (BASELINE north_star: "LDS-staged lattice neighbourhoods") and serves every
+// neighbour that falls inside the tile with a ds_read_b64; only the rest (~1/3 of the present ones, ~0.2 per vertex) are
+// global gathers, and absent neighbours cost nothing.  Same operations per value as k_blur2: new = old + 0.5 * (n1 + n2).
+constexpr int kTileThreads = 1024;
+constexpr int kTilePairs = 4;                                          // vertex pairs per lane
+constexpr int kTileVerts = kTileThreads * kTilePairs * 2;              // 8192 vertices = 64 KB of float2
+
+__global__ void __launch_bounds__(kTileThreads) k_blur2t(KernelDev kd, const float *__restrict__ src, float *__restrict__ dst, int j,
+                                                         int F, int nb)
+{
+    extern __shared__ __attribute__((aligned(16))) float2 tile[];      // [kTileVerts]
+    int f, bx;
+    if (nb == 0) { f = blockIdx.y; bx = blockIdx.x; }
+    else { const int L = blockIdx.x, q = L >> 3, g = q / nb; f = g * 8 + (L & 7); bx = q - g * nb; }   // one XCD per frame (see frame_block)
+    if (f >= F) return;
+    const int V = kd.V[f];
+    const int v0 = bx * kTileVerts;
+    if (v0 >= V) return;
+    const float2 *o = reinterpret_cast<const float2 *>(src + (size_t)f * kd.vstride + kd.vbase);
+    float2 *d = reinterpret_cast<float2 *>(dst + (size_t)f * kd.vstride + kd.vbase);
+    const int *nbp = kd.nbr + (((size_t)f * kd.D1 + j) * kd.Epad) * 2;
+    int4 n[kTilePairs];
+    float4 c[kTilePairs];
+#pragma unroll
+    for (int u = 0; u < kTilePairs; ++u) {                             // stage 1: everything streamed, all in flight at once
+        const int lp = u * kTileThreads + threadIdx.x, v = v0 + 2 * lp;
+        n[u] = make_int4(-1, -1, -1, -1);
+        c[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (v + 1 < V) {
+            n[u] = load_nbr_pair(nbp + 2 * v);
+            c[u] = *reinterpret_cast<const float4 *>(o + v);
+        } else if (v < V) {
+            const int2 t = *reinterpret_cast<const int2 *>(nbp + 2 * v);
+            const float2 x = o[v];
+            n[u].x = t.x; n[u].y = t.y;
+            c[u].x = x.x; c[u].y = x.y;
+        }
+        *reinterpret_cast<float4 *>(tile + 2 * lp) = c[u];
+    }
+    __syncthreads();
+    float2 g[kTilePairs][4];
+#pragma unroll
+    for (int u = 0; u < kTilePairs; ++u) {                             // stage 2: the neighbours -- LDS inside the tile, HBM/L2 outside
+        const int nn[4] = {n[u].x, n[u].y, n[u].z, n[u].w};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            g[u][t] = make_float2(0.f, 0.f);
+            const unsigned rel = (unsigned)(nn[t] - v0);
+            if (nn[t] >= 0) {
+                if (rel < (unsigned)kTileVerts) g[u][t] = tile[rel];
+                else g[u][t] = o[nn[t]];
+            }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < kTilePairs; ++u) {
+        const int v = v0 + 2 * (u * kTileThreads + threadIdx.x);
+        const float4 r = blur_pair(c[u], g[u][0], g[u][1], g[u][2], g[u][3]);
+        if (v + 1 < V) *reinterpret_cast<float4 *>(d + v) = r;
+        else if (v < V) d[v] = make_float2(r.x, r.y);
+    }
+}
+
+// grid of k_blur2t: tiles of kTileVerts vertices, frames XCD-aware like grid_xcd
+inline dim3 grid_tiles(int maxV, int F, int *nb)
+{
+    const int n = (maxV + kTileVerts - 1) / kTileVerts;
+    if (F < 8 || n < 1) { *nb = 0; return dim3((unsigned)(n > 0 ? n : 1), (unsigned)F); }
+    *nb = n;
+    return dim3((unsigned)(8L * ((F + 7) / 8) * n));
+}
+
+inline void launch_blur2(const KernelDev &kd, const float *src, float *dst, int j, int F, int maxV, hipStream_t s)
+{
+    static const bool no_tile = getenv("LCCRF_NO_BLUR_TILE") != nullptr;     // A/B switch: same results either way
+    int nb;
+    if (kd.perm && !no_tile) {
+        static const bool once = [] {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_blur2t), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      kTileVerts * (int)sizeof(float2));
+            return true;
+        }();
+        (void)once;
+        const dim3 g = grid_tiles(maxV, F, &nb);
+        k_blur2t<<<g, kTileThreads, kTileVerts * sizeof(float2), s>>>(kd, src, dst, j, F, nb);
+        return;
+    }
+    const dim3 g = grid_xcd(((maxV + 1) / 2 + kPairs - 1) / kPairs, F, &nb);
+    if (kd.nlist) k_blur2c<<<g, kBlock, 0, s>>>(kd, src, dst, j, F, nb);
+    else k_blur2<<<g, kBlock, 0, s>>>(kd, src, dst, j, F, nb);
 }
 
 // slice + apply for L = 2; the LAST kernel of the step also does the softmax (saves a pass over next).
@@ -586,7 +1078,7 @@ __global__ void __launch_bounds__(kBlock) k_unary_from_label_tbl(CrfDev c, const
     const int idx = blockIdx.x * kBlock + threadIdx.x;
     if (idx >= c.n_points[f] * c.L) return;
     const int i = idx / c.L, m = idx - i * c.L;
-    const int t = label[(size_t)f * c.maxN + i];
+    const int t = label[(size_t)f * c.maxN + (c.perm ? c.perm[(size_t)f * c.perm_stride + i] : i)];
     float u;
     if (t < 0 || t >= c.L) u = tbl.v[0];      // -1 = unknown; out-of-range labels (UB in the reference) likewise
     else u = (m == t) ? tbl.v[1 + c.L + t] : tbl.v[1 + t];
@@ -645,15 +1137,31 @@ template <int D>
 void build_kernel_d(const KernelDev &kd, const CrfDev &c, hipStream_t s)
 {
     const int F = c.F, D1 = D + 1;
-    (void)hipMemsetAsync(kd.slot, 0xff, (size_t)F * kd.cap * sizeof(int), s);
+    (void)hipMemsetAsync(kd.slot, 0xff, (size_t)F * kd.cap * sizeof(unsigned long long), s);
     k_points<D><<<grid_for(kd.maxNpad, F), kBlock, 0, s>>>(kd, c.n_points);
-    k_insert<D><<<grid_for(kd.Epad, F), kBlock, 0, s>>>(kd, c.n_points);
+    {
+        int nb;
+        const dim3 g = grid_xcd(kd.Epad, LCCRF_BUILD_XCD ? F : 1, &nb);
+        k_insert<D><<<LCCRF_BUILD_XCD ? g : grid_for(kd.Epad, F), kBlock, 0, s>>>(kd, c.n_points, F, LCCRF_BUILD_XCD ? nb : 0);
+    }
     k_first_flag<<<grid_for(kd.Epad + 1, F), kBlock, 0, s>>>(kd, c.n_points);
     scan_frames(kd.flag, kd.prefix, kd.Epad + 1, kd.Epad + 1, kd.V, kd.rep, F, s);     // (rep is written later, by k_offsets: free scratch)
     k_offsets<<<grid_for(kd.Epad, F), kBlock, 0, s>>>(kd, c.n_points);
     (void)hipMemsetAsync(kd.nbr, 0xff, (size_t)F * D1 * kd.Epad * 2 * sizeof(int), s);          // every neighbour absent (-1)
-    k_neighbors<D><<<grid_for((long)kd.Epad * D1, F), kBlock, 0, s>>>(kd);
+    {
+        int nb;
+        const dim3 g = grid_xcd((long)kd.Epad * D1, LCCRF_BUILD_XCD ? F : 1, &nb);
+        k_neighbors<D><<<LCCRF_BUILD_XCD ? g : grid_for((long)kd.Epad * D1, F), kBlock, 0, s>>>(kd, F, LCCRF_BUILD_XCD ? nb : 0);
+    }
     if (kd.Epad < 65535) k_neighbors16<<<grid_for((long)kd.Epad * D1, F), kBlock, 0, s>>>(kd);
+    if (kd.nlist) {                                                     // two-label iteration of large frames: the compressed table
+        const int G = kd.Epad / 64 + 1;
+        int nb;
+        const dim3 g = grid_xcd((long)D1 * G * 64, F, &nb);
+        k_nbr_compress<<<g, kBlock, 0, s>>>(kd, 0, F, nb);
+        scan_frames(kd.ncount, kd.nbase, G, G, nullptr, kd.csr_pos, F * D1, s);     // (csr_pos is written later, by k_csr_order)
+        k_nbr_compress<<<g, kBlock, 0, s>>>(kd, 1, F, nb);
+    }
     // CSR
     (void)hipMemsetAsync(kd.flag, 0, (size_t)F * (kd.Epad + 1) * sizeof(int), s);
     k_csr_count<<<grid_for(kd.Epad, F), kBlock, 0, s>>>(kd, c.n_points);
@@ -730,9 +1238,8 @@ void launch_step_stream(const CrfDev &c, const KernelDev *kds, const int *maxV, 
             k_splat2<<<g, kBlock, 0, s>>>(kd, reinterpret_cast<const float2 *>(c.Q), c.maxN, c.F, nb);
             const float *src = kd.val0;
             float *dst = kd.val1;
-            g = grid_xcd((maxV[k] + 1) / 2, c.F, &nb);
             for (int j = 0; j < kd.D1; ++j) {
-                k_blur2<<<g, kBlock, 0, s>>>(kd, src, dst, j, c.F, nb);
+                launch_blur2(kd, src, dst, j, c.F, maxV[k], s);
                 const float *t = src;
                 src = dst;
                 dst = const_cast<float *>(t);
@@ -775,9 +1282,7 @@ hipError_t time_blur_pass(const KernelDev &kd, int F, int maxV, int L, int reps,
     auto pass = [&](int i) {
         const float *src = (i & 1) ? kd.val1 : kd.val0;
         float *dst = (i & 1) ? kd.val0 : kd.val1;
-        int nb;
-        const dim3 g = grid_xcd((maxV + 1) / 2, F, &nb);
-        if (L == 2) k_blur2<<<g, kBlock, 0, s>>>(kd, src, dst, i % kd.D1, F, nb);
+        if (L == 2) launch_blur2(kd, src, dst, i % kd.D1, F, maxV, s);
         else k_blur<<<grid_for((long)maxV * L, F), kBlock, 0, s>>>(kd, src, dst, i % kd.D1, L);
     };
     for (int i = 0; i < 3; ++i) pass(i);
@@ -817,6 +1322,39 @@ void launch_copy_frames(void *dst, size_t dst_stride, const void *src, size_t sr
     else
         k_copy_frames<unsigned short><<<g, kBlock, 0, s>>>(static_cast<unsigned short *>(dst), dst_stride / 2,
                                                            static_cast<const unsigned short *>(src), src_stride / 2, list, units, gather);
+}
+
+__global__ void __launch_bounds__(kBlock) k_permute_rows(CrfDev c, float *__restrict__ dst, const float *__restrict__ src, int width,
+                                                         int gather)
+{
+    const int f = blockIdx.y;
+    const int idx = blockIdx.x * kBlock + threadIdx.x;
+    if (idx >= c.n_points[f] * width) return;
+    const int i = idx / width, m = idx - i * width;
+    const int o = c.perm[(size_t)f * c.perm_stride + i];
+    const size_t a = ((size_t)f * c.maxN + i) * width + m, b = ((size_t)f * c.maxN + o) * width + m;
+    if (gather) dst[a] = src[b];
+    else dst[b] = src[a];
+}
+
+void launch_permute_rows(const CrfDev &c, float *dst, const float *src, int width, int gather, hipStream_t s)
+{
+    k_permute_rows<<<grid_for((long)c.maxN * width, c.F), kBlock, 0, s>>>(c, dst, src, width, gather);
+}
+
+void launch_sort_points(const KernelDev &kd, const CrfDev &c, const SortScratch &ss, hipStream_t s)
+{
+    switch (kd.d) {
+    case 1: sort_points_d<1>(kd, c, ss, s); break;
+    case 2: sort_points_d<2>(kd, c, ss, s); break;
+    case 3: sort_points_d<3>(kd, c, ss, s); break;
+    case 4: sort_points_d<4>(kd, c, ss, s); break;
+    case 5: sort_points_d<5>(kd, c, ss, s); break;
+    case 6: sort_points_d<6>(kd, c, ss, s); break;
+    case 7: sort_points_d<7>(kd, c, ss, s); break;
+    case 8: sort_points_d<8>(kd, c, ss, s); break;
+    default: break;
+    }
 }
 
 void launch_validate_npoints(const int *in, int *out, int F, int maxN, int *bad, hipStream_t s)

@@ -83,6 +83,53 @@ def gather_label_bits(local_bits, out=None, group=None):
     return out.view(world, S, W)
 
 
+class OverlappedLabelGather:
+    """The per-step label gather of `bench.py --gpus N`, overlapped with the next step's launch.
+
+    The inference kernel writes the bit-packed labels into a buffer the library owns (`bits_view`, int64 [S, words]); the
+    next launch overwrites it.  push() copies the bits (device to device, on the CURRENT stream, i.e. behind the launch
+    that produced them) into one of two staging buffers and starts an asynchronous all_gather_into_tensor of that
+    buffer on the collective's own stream; a staging buffer is reused only after the gather that read it has been
+    waited for (a stream-side wait, no host round trip).  wait_all() before the clock stops.  `serial=True` waits for
+    every gather right away (gather-then-launch).  The collective is issued whenever a process group exists -- also
+    with world size 1, which is how the RCCL path is exercised on a one-GPU box (tests/test_sharding.py)."""
+
+    def __init__(self, bits_view, world, group=None, serial=False):
+        self.bits, self.world, self.group, self.serial = bits_view, int(world), group, bool(serial)
+        self.collective = dist.is_available() and dist.is_initialized()
+        n = 1 if (serial or not self.collective) else 2
+        S, W = bits_view.shape
+        self.stage = [torch.empty((S, W), dtype=bits_view.dtype, device=bits_view.device) for _ in range(n)]
+        self.out = [torch.empty((self.world * S, W), dtype=bits_view.dtype, device=bits_view.device) for _ in range(n)]
+        self.pending = [None] * n
+        self.steps = 0
+
+    def push(self):
+        k = self.steps % len(self.stage)
+        if self.pending[k] is not None:
+            self.pending[k].wait()
+            self.pending[k] = None
+        if not self.collective:
+            self.out[k].copy_(self.bits, non_blocking=True)
+        elif self.serial:
+            dist.all_gather_into_tensor(self.out[k], self.bits, group=self.group)
+        else:
+            self.stage[k].copy_(self.bits, non_blocking=True)
+            self.pending[k] = dist.all_gather_into_tensor(self.out[k], self.stage[k], group=self.group, async_op=True)
+        self.steps += 1
+
+    def wait_all(self):
+        for k, w in enumerate(self.pending):
+            if w is not None:
+                w.wait()
+                self.pending[k] = None
+
+    def last(self):
+        """int64 [world, S, words]: what the most recent push() gathered (call wait_all() first)."""
+        S, W = self.bits.shape
+        return self.out[(self.steps - 1) % len(self.out)].view(self.world, S, W)
+
+
 def unpack_label_bits(bits, max_points):
     """int64 [..., words] -> int16 [..., max_points] labels (0 / 1)."""
     shifts = torch.arange(64, device=bits.device, dtype=torch.int64)

@@ -565,4 +565,61 @@ def test_large_ragged_batch_matches_oracle(po, wl, d_list, L):
         assert cc.same_bits(Q[f, :n], o.probability()), f
         assert np.array_equal(M[f, :n], o.map()), f
         o.close()
+    # frames of this size are built in LOCALITY MODE (an internal Z-order of the points, csrc/stream_engine.hip:
+    # launch_sort_points): what the caller sees stays in the caller's point order -- norm included
+    for k in range(len(d_list)):
+        nm = b.norm(k)
+        for f in (0, 3):
+            pbw = dict(pbs[f], kernels=[(pbs[f]["kernels"][j][0], np.float32(ws[j])) for j in range(len(d_list))])
+            o = cc.setup(po.OracleCRF, pbw)
+            assert cc.same_bits(nm[f, :sizes[f]], o.kernel(k)["norm"]), (k, f)
+            o.close()
+    # new inputs into the same handle (frames swapped, one frame shrunk), rebuilt twice: the order is decided afresh
+    order = [4, 3, 2, 1, 0]
+    sizes2 = [sizes[i] for i in order]
+    sizes2[0] = 5000
+    unary2 = unary[order].copy()
+    feats2 = [f[order].copy() for f in feats]
+    b.set_inputs_host(sizes2, feats2, unary=unary2)
+    b.build(); b.build()
+    b.inference(2, True)
+    Q, M = b.probability(), b.map()
+    for f in (0, 1, 4):
+        n = sizes2[f]
+        pb = dict(N=n, L=L, unary=unary2[f, :n], kernels=[(feats2[k][f, :n], np.float32(ws[k])) for k in range(len(d_list))])
+        o = cc.setup(po.OracleCRF, pb)
+        o.inference_native(2, True)
+        assert cc.same_bits(Q[f, :n], o.probability()) and np.array_equal(M[f, :n], o.map()), f
+        o.close()
+    b.close()
+
+
+@pytest.mark.gpu
+def test_locality_mode_with_labels_and_device_inputs(po, wl):
+    """Locality mode end to end the way bench.py drives C5: device-bound inputs, unaries from labels (derived in the
+    internal order), 8 frames (XCD-aware grids), two builds, against the oracle -- and one adversarial frame whose
+    points all share a cell (one bucket of the sort holds everything)."""
+    import torch
+    N, F = 12000, 8
+    dev = torch.device("cuda", 0)
+    pbs = [wl.bilateral_problem(N, seed=31 + i) for i in range(3)]
+    odd = dict(pbs[0], kernels=[(np.tile(pbs[0]["kernels"][0][0][:1], (N, 1)).copy(), pbs[0]["kernels"][0][1])])
+    frames = [pbs[i % 3] for i in range(F - 1)] + [odd]
+    f = torch.from_numpy(np.stack([pb["kernels"][0][0] for pb in frames])).to(dev)
+    lab = torch.from_numpy(np.stack([pb["label"] for pb in frames])).to(dev)
+    npt = torch.tensor([N, N - 1, N - 2, N - 3, N, 9001, 8192, N], dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    b = pkg.BatchCRF(F, N, 2, [6], [10.0])
+    b.bind_inputs_device(F, npt.data_ptr(), [f.data_ptr()], d_label=lab.data_ptr(), conf=0.7)
+    b.build(); b.build()
+    for rep in range(2):
+        b.inference(4, True)
+    Q, M, Vs = b.probability(), b.map(), b.lattice_sizes(0)
+    for i, pb in enumerate(frames):
+        n = int(npt[i])
+        o = cc.setup(po.OracleCRF, dict(pb, N=n, label=pb["label"][:n], kernels=[(pb["kernels"][0][0][:n], np.float32(10.0))]))
+        o.inference_native(4, True)
+        assert int(Vs[i]) == o.kernel(0)["V"], i
+        assert cc.same_bits(Q[i, :n], o.probability()) and np.array_equal(M[i, :n], o.map()), i
+        o.close()
     b.close()

@@ -12,7 +12,8 @@ import crf_cases as cc
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 rec = importlib.import_module("lc-crf-slam_amd.records")
-SAMPLE = os.path.join(ROOT, "tests", "golden", "sample_frames.lccrfrec")
+SAMPLE = os.path.join(ROOT, "tests", "golden", "sample_frames.lccrfrec")          # version 1, reference results from oracle/_ref
+SAMPLE_V2 = os.path.join(ROOT, "tests", "golden", "sample_sections_v2.lccrfrec")  # version 2 with all sections, SYNTHETIC outputs
 
 
 def test_c_header_matches_the_python_layout(tmp_path):
@@ -26,6 +27,16 @@ def test_c_header_matches_the_python_layout(tmp_path):
     out = subprocess.check_output([str(exe)]).split()
     assert [int(x) for x in out] == [rec._FILE_HDR.size, rec._FRAME_HDR.size, 16, 16 + 12 * 4, rec.VERSION]
     assert rec._FILE_HDR.size == 32 and rec._FRAME_HDR.size == 80
+    # version 2: section structs and tags
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "lccrf_record.h"\n'
+                   'int main(void){printf("%zu %zu %zu %zu %zu %zu %u %u %u\\n", sizeof(lccrf_rec_section_header), '
+                   'sizeof(lccrf_rec_unary_header), sizeof(lccrf_rec_bfmatch_header), sizeof(lccrf_rec_pose_header), '
+                   'offsetof(lccrf_rec_frame_header, n_sections), offsetof(lccrf_rec_file_header, origin), '
+                   'LCCRF_SEC_UNARY, LCCRF_SEC_BFMATCH, LCCRF_SEC_POSE);return 0;}\n')
+    subprocess.check_call(["gcc", "-std=c11", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    out = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    assert out == [rec._SEC_HDR.size, 16, 16, 32, 16 + 13 * 4, 20, rec.SEC_UNARY, rec.SEC_BFMATCH, rec.SEC_POSE]
+    assert [t.to_bytes(4, "little") for t in out[6:]] == [b"UNRY", b"BFMT", b"POSE"]
 
 
 def test_round_trip_is_bit_exact(tmp_path, wl):
@@ -48,6 +59,57 @@ def test_round_trip_is_bit_exact(tmp_path, wl):
                 assert b[k] is None
             else:
                 assert np.asarray(a[k]).tobytes() == b[k].tobytes(), k
+
+
+def test_version2_sections_round_trip_and_version1_files_still_read(tmp_path):
+    frames = list(rec.read_records(SAMPLE_V2))
+    assert len(frames) == 3 and rec.file_origin(SAMPLE_V2) == rec.ORIGIN_SYNTHETIC
+    assert all(set(fr["sections"]) == {"unary", "bfmatch", "pose"} for fr in frames)
+    frames[1]["unknown_sections"] = [(0x21212121, 7, b"from a newer writer")]      # carried along untouched
+    path = tmp_path / "v2.lccrfrec"
+    rec.write_records(path, frames, origin=rec.ORIGIN_SYNTHETIC)
+    back = list(rec.read_records(path))
+    assert back[1]["unknown_sections"] == [(0x21212121, 7, b"from a newer writer")]
+    for a, b in zip(frames, back):
+        for name, sec in a["sections"].items():
+            for k, v in sec.items():
+                w = b["sections"][name][k]
+                if v is None:
+                    assert w is None
+                elif isinstance(v, np.ndarray):
+                    assert v.dtype == w.dtype and v.tobytes() == w.tobytes(), (name, k)
+                else:
+                    assert v == w, (name, k)
+    # without the unknown section the file is reproduced byte for byte
+    frames[1]["unknown_sections"] = []
+    rec.write_records(path, frames, origin=rec.ORIGIN_SYNTHETIC)
+    assert path.read_bytes() == open(SAMPLE_V2, "rb").read()
+    # a version-1 file (no sections, origin 0) is still read; a section cut short is rejected
+    v1 = list(rec.read_records(SAMPLE))
+    assert len(v1) == 8 and all(not fr["sections"] for fr in v1) and rec.file_origin(SAMPLE) == rec.ORIGIN_REFERENCE
+    blob = open(SAMPLE_V2, "rb").read()
+    (tmp_path / "cut").write_bytes(blob[:-40])
+    with pytest.raises(rec.RecordError):
+        list(rec.read_records(tmp_path / "cut"))
+
+
+def test_sample_sections_agree_with_the_restatements(po):
+    """The committed version-2 sample is what tests/golden/make_sample_records_v2.py writes: its section outputs are
+    this repository's restatements (SYNTHETIC, pins nothing), its CRF results come from oracle/_ref."""
+    for fr in rec.read_records(SAMPLE_V2):
+        u, m, q = fr["sections"]["unary"], fr["sections"]["bfmatch"], fr["sections"]["pose"]
+        obs, err, dep, lab = po.oracle_unary_build(u["Xw"], u["obs_ptr"], u["obs_kf"], u["obs_kp"], u["kf_pose"], u["kf_intr"],
+                                                   u["kf_bounds"], match_prob=u["match_prob"])
+        assert cc.same_bits(obs, u["observs"]) and cc.same_bits(err, u["error"]) and cc.same_bits(dep, u["depth"])
+        assert np.array_equal(lab, u["rough_label"])
+        kept = u["observs"] != 0
+        assert cc.same_bits(u["error"][kept], fr["verrors"]) and np.array_equal(u["rough_label"][kept], fr["init_label"])
+        asso, _ = po.oracle_bf_match(m["desc_query"], m["desc_train"], m["ratio"])
+        assert np.array_equal(asso, m["asso"]) and (asso >= 0).sum() > 20
+        To, outl, ninl, _ = po.oracle_pose_optimization(q["Xw"], q["kp"], q["u_right"], q["inv_sigma2"], q["valid"], q["K4"], q["bf"], q["Tcw_in"])
+        assert cc.same_bits(To, q["Tcw_out"]) and np.array_equal(outl, q["outlier"]) and ninl == q["n_inliers"]
+        moved = q["crf_index"][(q["crf_index"] >= 0) & (q["valid"] == 0)]
+        assert np.all(fr["ref_label"][moved] == 0)          # exactly the keypoints the CRF labelled moving lost their map point
 
 
 def test_malformed_files_are_rejected(tmp_path, wl):
@@ -94,3 +156,27 @@ def test_replay_reproduces_the_reference_results(batch, engine):
     out = replay.replay(SAMPLE, batch=batch, engine=engine)
     assert out["frames"] == 8 and out["checked_frames"] == 8 and out["points"] == 10735
     assert out["label_mismatches"] == 0 and out["prob_mismatches"] == 0 and out["max_abs_dQ"] == 0.0
+
+
+@pytest.mark.gpu
+def test_replay_checks_every_section_of_a_version2_file(tmp_path):
+    """tools/replay.py on the version-2 sample: CRF results bit for bit, and every section through its entry point of
+    include/lccrf.h -- unary builder and BfMatch exact, pose within the stated tolerance.  Then a corrupted copy must fail."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import replay
+    out = replay.replay(SAMPLE_V2)
+    assert out["frames"] == 3 and out["checked_frames"] == 3 and out["origin"].startswith("synthetic")
+    assert out["label_mismatches"] == 0 and out["prob_mismatches"] == 0
+    s = out["sections"]
+    assert s["unary"]["frames"] == 3 and s["unary"]["candidates"] == 260 + 181 + 97
+    assert s["unary"]["observs_mismatches"] == 0 and s["unary"]["label_mismatches"] == 0 and s["unary"]["crf_input_mismatches"] == 0
+    assert s["unary"]["error_max_ulp"] == 0 and s["unary"]["depth_max_ulp"] == 0          # HIP == restatement bit for bit
+    assert s["bfmatch"]["asso_mismatches"] == 0 and s["pose"]["outlier_mismatches"] == 0 and s["pose"]["inlier_count_mismatches"] == 0
+    assert s["pose"]["max_abs_dT"] <= replay.POSE_ABS_TOL and out["sections_ok"]
+    frames = list(rec.read_records(SAMPLE_V2))
+    frames[0]["sections"]["bfmatch"]["asso"][:5] += 1
+    frames[2]["sections"]["pose"]["outlier"] ^= 1
+    bad = tmp_path / "bad.lccrfrec"
+    rec.write_records(bad, frames, origin=rec.ORIGIN_SYNTHETIC)
+    out = replay.replay(str(bad))
+    assert not out["sections_ok"] and out["sections"]["bfmatch"]["asso_mismatches"] >= 1 and out["sections"]["pose"]["outlier_mismatches"] > 0

@@ -79,3 +79,29 @@ def test_label_bit_packing_round_trip():
     t = torch.from_numpy(bits.view(np.int64))
     assert np.array_equal(sh.unpack_label_bits(t, 2000).numpy(), lab)
     assert torch.equal(sh.gather_label_bits(t[0]), t[0][None])          # world 1: a copy
+
+
+def test_overlapped_gather_without_a_process_group_is_a_copy():
+    import torch
+    bits = torch.arange(12, dtype=torch.int64).view(3, 4)
+    g = sh.OverlappedLabelGather(bits, 1)
+    assert not g.collective
+    for step in range(3):
+        bits += 1
+        g.push()
+    g.wait_all()
+    assert torch.equal(g.last()[0], bits) and g.steps == 3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["overlapped", "serial"])
+def test_rccl_label_gather_runs_with_world_size_one(mode):
+    """the RCCL code of `bench.py --gpus N` (process group on the device, async all_gather_into_tensor on a
+    view of library memory, double-buffered staging) executed once, with world size 1, in a child process."""
+    port = 29700 + (os.getpid() % 200) + (0 if mode == "overlapped" else 1)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+               HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "rccl_worker.py"), mode], capture_output=True, text=True,
+                       timeout=600, env=env)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    assert "rccl world-1 gather ok" in r.stdout
