@@ -317,13 +317,6 @@ struct Engine {
         if ((rc = mem.alloc(&k.csr_pos, Fz * E))) return rc;
         if ((rc = mem.alloc(&k.pk, Fz * E))) return rc;
         if ((rc = mem.alloc(&k.nbr16, Fz * k.D1 * E))) return rc;
-        if (L == 2 && maxN > 4096 && !getenv("LCCRF_NO_NBR_COMPRESS")) {   // frames beyond the one-workgroup engines iterate on the streaming engine
-            const size_t G = E / 64 + 1;
-            if ((rc = mem.alloc(&k.nflag, Fz * k.D1 * (E / 16 + 4)))) return rc;
-            if ((rc = mem.alloc(&k.nbase, Fz * k.D1 * G))) return rc;
-            if ((rc = mem.alloc(&k.ncount, Fz * k.D1 * G))) return rc;
-            if ((rc = mem.alloc(&k.nlist, Fz * k.D1 * E * 2))) return rc;
-        }
         if ((rc = mem.alloc(&k.norm, Fz * maxN))) return rc;
         if ((rc = mem.alloc(&k.val0, Fz * k.vstride))) return rc;
         if ((rc = mem.alloc(&k.val1, Fz * k.vstride))) return rc;

@@ -121,27 +121,6 @@ __device__ __forceinline__ unsigned hash_key(const int16_t (&key)[D])
     return h;
 }
 
-// Slot of a key in a table of mask + 1 slots (power of two) for the streaming build: keys of the same 8-unit box of the
-// lattice land in the same 32-slot region (one 128-byte line of 4-byte slots), boxes are spread by the mix above.  A
-// box holds at most (d+1) * (8 / (d+1))^d <= ~30 lattice points, so regions do not overload; vertices are processed
-// box by box in locality mode, so consecutive probes hit lines that are already in L2 instead of one HBM line each.
-template <int D>
-__device__ __forceinline__ unsigned hash_key_local(const int16_t (&key)[D], unsigned mask)
-{
-    unsigned hc = 0, hf = 0;
-#pragma unroll
-    for (int i = 0; i < D; ++i) {
-        hc += (unsigned)((int)key[i] >> 3);
-        hc *= 1664525u;
-        hf = hf * 8u + ((unsigned)(int)key[i] & 7u);
-    }
-    hc ^= hc >> 15;
-    hc *= 2246822519u;
-    hc ^= hc >> 13;
-    hf = (hf * 2654435761u) >> 27;
-    return ((hc << 5) | hf) & mask;
-}
-
 // ---------------------------------------------------------------------------------------
 // softmax with the reference's polynomial exp.  ref: densecrf3d.h:51-98
 // ---------------------------------------------------------------------------------------

@@ -38,7 +38,7 @@ struct KernelDev {
     uint8_t *rank;        // [F][maxNpad][d]   rank of each coordinate
     float *bary;          // [F][Epad]         barycentric weight of every entry
     int *offset;          // [F][Epad]         vertex id of every entry (reference offset_)
-    unsigned long long *slot;   // [F][cap]    hash slots: (32-bit fingerprint of the key) << 32 | lowest entry id with that key; ~0 = empty
+    int *slot;            // [F][cap]          hash slots: lowest entry id with that key, or -1
     int *slot_of;         // [F][Epad]         slot index each entry landed in
     int *flag;            // [F][Epad+1]       scratch: first-occurrence flags / row counts / unsorted rows
     int *prefix;          // [F][Epad+1]       exclusive scan of flag == dense vertex id of a first entry
@@ -53,13 +53,6 @@ struct KernelDev {
     // compact copies for the fused engine's prologue (frames with Epad < 65535 only; undefined otherwise)
     unsigned *pk;         // [F][Epad]         (offset + 1) | csr_pos << 16 of every real entry
     unsigned *nbr16;      // [F][D1][Epad]     (n1 + 1) | (n2 + 1) << 16 per (axis, vertex), 0 = absent
-    // compressed blur-neighbour table of the two-label streaming iteration (large frames; null otherwise).  Two thirds of
-    // the neighbour slots of a sparse lattice are absent: 2 presence bits per (axis, vertex) + the present ids in vertex
-    // order (n1 before n2) + a running count per 64 vertices replace the 8-byte pair (~3 B instead of 8 B per vertex and pass)
-    unsigned *nflag;      // [F][D1][Epad/16 + 4]   bit 2i = n1 of vertex 16w+i present, bit 2i+1 = its n2
-    int *nbase;           // [F][D1][Epad/64 + 1]   list entries before vertex 64g
-    int *ncount;          // [F][D1][Epad/64 + 1]   list entries of group g (build scratch: nbase = its exclusive scan)
-    int *nlist;           // [F][D1][2*Epad]        the present neighbour ids
     int *V_host, *rowmax_host;   // [F] pinned host mirrors of V / rowmax written by the fused build (or null)
     float *norm;          // [F][maxN]         1/(K*1 + 1e-20)  (PottsPotential3D::norm_)
     float *val0, *val1;   // [F][vstride]      lattice values (see vbase)

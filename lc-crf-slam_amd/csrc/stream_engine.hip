@@ -25,27 +25,6 @@ namespace lccrf {
 namespace {
 
 constexpr int kBlock = 256;
-constexpr unsigned long long kEmptySlot = ~0ull;
-
-// A/B switches of the streaming build (scripts/gpu_ab_build.sh); the defaults are what measured fastest
-#ifndef LCCRF_LOCAL_HASH
-#define LCCRF_LOCAL_HASH 1
-#endif
-#ifndef LCCRF_BUILD_XCD
-#define LCCRF_BUILD_XCD 1
-#endif
-#ifndef LCCRF_NBR_VERTEX_MAJOR
-#define LCCRF_NBR_VERTEX_MAJOR 1
-#endif
-template <int D>
-__device__ __forceinline__ unsigned table_slot(const int16_t (&key)[D], unsigned mask)
-{
-#if LCCRF_LOCAL_HASH
-    return hash_key_local<D>(key, mask);
-#else
-    return hash_key<D>(key) & mask;
-#endif
-}
 
 // XCD-aware grids for the mean-field iteration of many frames in flight.  The chip's eight XCDs have private 4 MB L2s and
 // workgroup L of a launch runs on XCD L % 8 (observed dispatch order; used for speed only, never for correctness).  With the
@@ -126,22 +105,17 @@ __global__ void __launch_bounds__(kBlock) k_insert(KernelDev kd, const int *__re
     int16_t key[D];
     load_entry_key<D>(kd, f, e, key);
     const unsigned mask = (unsigned)kd.cap - 1u;
-    unsigned h = table_slot<D>(key, mask);
-    // a slot carries a fingerprint of its key: a probe that runs into other keys rejects them from the slot word alone
-    // (the key itself -- two more loads from the owner's point record -- is read only when the fingerprints agree)
-    const unsigned long long me = ((unsigned long long)hash_key<D>(key) << 32) | (unsigned)e;
-    unsigned long long *slot = kd.slot + (size_t)f * kd.cap;
+    unsigned h = hash_key<D>(key) & mask;
+    int *slot = kd.slot + (size_t)f * kd.cap;
     for (;;) {
-        const unsigned long long prev = atomicCAS(&slot[h], kEmptySlot, me);
-        if (prev == kEmptySlot || prev == me) break;
-        if ((prev >> 32) == (me >> 32)) {
-            int16_t other[D];
-            load_entry_key<D>(kd, f, (int)(unsigned)prev, other);
-            bool same = true;
+        const int prev = atomicCAS(&slot[h], kEmpty, e);
+        if (prev == kEmpty || prev == e) break;
+        int16_t other[D];
+        load_entry_key<D>(kd, f, prev, other);
+        bool same = true;
 #pragma unroll
-            for (int i = 0; i < D; ++i) same &= (other[i] == key[i]);
-            if (same) { atomicMin(&slot[h], me); break; }          // same fingerprint: the lower entry id wins
-        }
+        for (int i = 0; i < D; ++i) same &= (other[i] == key[i]);
+        if (same) { atomicMin(&slot[h], e); break; }
         h = (h + 1u) & mask;
     }
     kd.slot_of[(size_t)f * kd.Epad + e] = (int)h;
@@ -157,7 +131,7 @@ __global__ void __launch_bounds__(kBlock) k_first_flag(KernelDev kd, const int *
     int v = 0;
     if (e < live) {
         const int s = kd.slot_of[(size_t)f * kd.Epad + e];
-        v = ((int)(unsigned)kd.slot[(size_t)f * kd.cap + s] == e);
+        v = (kd.slot[(size_t)f * kd.cap + s] == e);
     }
     kd.flag[(size_t)f * (kd.Epad + 1) + e] = v;
 }
@@ -458,7 +432,7 @@ __global__ void __launch_bounds__(kBlock) k_offsets(KernelDev kd, const int *__r
     if (e >= live) return;
     const size_t fe = (size_t)f * kd.Epad;
     const int *prefix = kd.prefix + (size_t)f * (kd.Epad + 1);
-    const int r = (int)(unsigned)kd.slot[(size_t)f * kd.cap + kd.slot_of[fe + e]];
+    const int r = kd.slot[(size_t)f * kd.cap + kd.slot_of[fe + e]];
     const int id = prefix[r];
     kd.offset[fe + e] = id;
     if (r == e) kd.rep[fe + id] = e;
@@ -468,20 +442,17 @@ template <int D>
 __device__ __forceinline__ int find_vertex(const KernelDev &kd, int f, const int16_t (&key)[D])
 {
     const unsigned mask = (unsigned)kd.cap - 1u;
-    unsigned h = table_slot<D>(key, mask);
-    const unsigned fp = hash_key<D>(key);
-    const unsigned long long *slot = kd.slot + (size_t)f * kd.cap;
+    unsigned h = hash_key<D>(key) & mask;
+    const int *slot = kd.slot + (size_t)f * kd.cap;
     for (;;) {
-        const unsigned long long r = slot[h];
-        if (r == kEmptySlot) return -1;
-        if ((unsigned)(r >> 32) == fp) {
-            int16_t other[D];
-            load_entry_key<D>(kd, f, (int)(unsigned)r, other);
-            bool same = true;
+        const int r = slot[h];
+        if (r == kEmpty) return -1;
+        int16_t other[D];
+        load_entry_key<D>(kd, f, r, other);
+        bool same = true;
 #pragma unroll
-            for (int i = 0; i < D; ++i) same &= (other[i] == key[i]);
-            if (same) return kd.prefix[(size_t)f * (kd.Epad + 1) + (unsigned)r];
-        }
+        for (int i = 0; i < D; ++i) same &= (other[i] == key[i]);
+        if (same) return kd.prefix[(size_t)f * (kd.Epad + 1) + r];
         h = (h + 1u) & mask;
     }
 }
@@ -499,11 +470,7 @@ __global__ void __launch_bounds__(kBlock) k_neighbors(KernelDev kd, int F, int n
     const int V = kd.V[f];
     const int idx = fb.bx * kBlock + threadIdx.x;
     if (idx >= V * D1) return;
-#if LCCRF_NBR_VERTEX_MAJOR
-    const int v = idx / D1, j = idx - v * D1;            // vertex-major: the D1 probes of a vertex go to neighbouring table lines
-#else
     const int j = idx / V, v = idx - j * V;
-#endif
     int16_t key[D], n2[D];
     load_entry_key<D>(kd, f, kd.rep[(size_t)f * kd.Epad + v], key);
 #pragma unroll
@@ -528,49 +495,6 @@ __global__ void __launch_bounds__(kBlock) k_neighbors16(KernelDev kd)
     const int j = idx / V, v = idx - j * V;
     const int2 r = reinterpret_cast<const int2 *>(kd.nbr)[((size_t)f * kd.D1 + j) * kd.Epad + v];
     kd.nbr16[((size_t)f * kd.D1 + j) * kd.Epad + v] = (unsigned)(r.x + 1) | ((unsigned)(r.y + 1) << 16);
-}
-
-// ---- compressed neighbour table (KernelDev::nflag / nbase / nlist) ---------------------------------
-__device__ __forceinline__ unsigned spread16(unsigned x)          // bit i of the low half -> bit 2i
-{
-    x &= 0xffffu;
-    x = (x | (x << 8)) & 0x00ff00ffu;
-    x = (x | (x << 4)) & 0x0f0f0f0fu;
-    x = (x | (x << 2)) & 0x33333333u;
-    x = (x | (x << 1)) & 0x55555555u;
-    return x;
-}
-
-// One lane per (axis, vertex), vertices of a wavefront = one group of 64.  pass 0: presence bits + group counts;
-// pass 1 (after the scan of the counts): the ids.
-__global__ void __launch_bounds__(kBlock) k_nbr_compress(KernelDev kd, int pass, int F, int nb)
-{
-    const FrameBlock fb = frame_block(nb);
-    const int f = fb.f;
-    if (f >= F) return;
-    const int V = kd.V[f];
-    const int G = kd.Epad / 64 + 1, W = kd.Epad / 16 + 4;
-    const int gidx = fb.bx * (kBlock / 64) + (threadIdx.x >> 6);       // (axis, group) of this wavefront
-    const int j = gidx / G, g = gidx - j * G;
-    if (j >= kd.D1 || g * 64 >= V) return;                             // (uniform per wavefront)
-    const int lane = threadIdx.x & 63, v = g * 64 + lane;
-    const size_t plane = (size_t)f * kd.D1 + j;
-    int2 nbv = make_int2(-1, -1);
-    if (v < V) nbv = reinterpret_cast<const int2 *>(kd.nbr)[plane * kd.Epad + v];
-    const unsigned long long b1 = __ballot(nbv.x >= 0), b2 = __ballot(nbv.y >= 0);
-    if (pass == 0) {
-        if ((lane & 15) == 0) {
-            const unsigned sh = lane;
-            kd.nflag[plane * W + (v >> 4)] = spread16((unsigned)(b1 >> sh)) | (spread16((unsigned)(b2 >> sh)) << 1);
-        }
-        if (lane == 0) kd.ncount[plane * G + g] = __popcll(b1) + __popcll(b2);
-    } else {
-        const unsigned long long below = (1ull << lane) - 1ull;
-        int p = kd.nbase[plane * G + g] + __popcll(b1 & below) + __popcll(b2 & below);
-        int *list = kd.nlist + plane * kd.Epad * 2;
-        if (nbv.x >= 0) list[p++] = nbv.x;
-        if (nbv.y >= 0) list[p] = nbv.y;
-    }
 }
 
 // ---- CSR of splat contributions: vertex -> (point, weight), points ascending ------------
@@ -778,9 +702,9 @@ __global__ void __launch_bounds__(kBlock) k_splat2(KernelDev kd, const float2 *_
     const int v = fb.bx * kBlock + threadIdx.x;
     if (v >= kd.V[f]) return;
     const size_t fe = (size_t)f * kd.Epad, f1 = (size_t)f * (kd.Epad + 1);
-    const int s = kd.rowptr[f1 + v], t = kd.rowptr[f1 + v + 1];
     const float2 *x = in + (size_t)f * in_stride;
     float a0 = 0.0f, a1 = 0.0f;
+    const int s = kd.rowptr[f1 + v], t = kd.rowptr[f1 + v + 1];
     for (int p = s; p < t; ++p) {
         const float w = kd.csr_w[fe + p];
         const float2 q = x[kd.csr_pt[fe + p]];
@@ -803,22 +727,12 @@ __device__ __forceinline__ int4 load_nbr_pair(const int *p)
 #endif
     return make_int4(x.x, x.y, x.z, x.w);
 }
-// kPairs vertex PAIRS per lane (pair p of a workgroup's tile: vertices 2p, 2p+1): the neighbour pairs (int4), the centres
-// (float4) and the results (float4) move as 16-byte accesses (the frame's value array is laid out so that vertex 2t is
-// 16-byte aligned, see Engine::add_kernel).  The pass is bound by memory LATENCY x what is in flight, not by instruction
-// count (one pair per lane: ~32 bytes per lane in flight in each of two dependent stages = half the HBM rate): every
-// lane issues the table and centre loads of all its pairs first, then all gathers, then the stores.
-#ifndef LCCRF_BLUR_PAIRS
-#define LCCRF_BLUR_PAIRS 1
-#endif
-constexpr int kPairs = LCCRF_BLUR_PAIRS;
-constexpr int kBlurTile = kBlock * kPairs;                // pairs per workgroup
-
-__device__ __forceinline__ float4 blur_pair(const float4 &c, const float2 &x0, const float2 &y0, const float2 &x1, const float2 &y1)
-{
-    return make_float4(c.x + 0.5f * (x0.x + y0.x), c.y + 0.5f * (x0.y + y0.y), c.z + 0.5f * (x1.x + y1.x), c.w + 0.5f * (x1.y + y1.y));
-}
-
+// Two vertices per thread: the neighbour pairs (int4), the centres (float4) and the results (float4) move as 16-byte
+// accesses (the frame's value array is laid out so that vertex 2t is 16-byte aligned, see Engine::add_kernel).
+// What bounds the pass is the CU's vector-memory path, not HBM bytes: an 8-byte gather costs ~16 + 2 cycles per distinct
+// 128-byte line it touches (scripts/ubench/tacost.hip), which is why locality mode -- fewer distinct lines per gather --
+// helps and why everything tried on top of it lost (notes/r3_experiments.md: 2-8 pairs per lane with all loads issued
+// first, a presence-bit + id-list neighbour table, a 4096/8192-vertex LDS tile serving the in-tile neighbours).
 __global__ void __launch_bounds__(kBlock) k_blur2(KernelDev kd, const float *__restrict__ src,
                                                   float *__restrict__ dst, int j, int F, int nb)
 {
@@ -826,207 +740,29 @@ __global__ void __launch_bounds__(kBlock) k_blur2(KernelDev kd, const float *__r
     const int f = fb.f;
     if (f >= F) return;
     const int V = kd.V[f];
-    const int p0 = fb.bx * kBlurTile + threadIdx.x;       // first pair of this lane; the others follow at a stride of kBlock
-    if (2 * (fb.bx * kBlurTile) >= V) return;
+    const int v = 2 * (fb.bx * kBlock + threadIdx.x);
+    if (v >= V) return;
     const float2 *o = reinterpret_cast<const float2 *>(src + (size_t)f * kd.vstride + kd.vbase);   // o[-1] = absent
     float2 *d = reinterpret_cast<float2 *>(dst + (size_t)f * kd.vstride + kd.vbase);
-    const int *nbp = kd.nbr + (((size_t)f * kd.D1 + j) * kd.Epad) * 2;
-    if (2 * (fb.bx * kBlurTile + kBlurTile) <= V) {       // a full tile (every workgroup but a frame's last)
-        int4 n[kPairs];
-        float4 c[kPairs];
-#pragma unroll
-        for (int u = 0; u < kPairs; ++u) {
-            const int v = 2 * (p0 + u * kBlock);
-            n[u] = load_nbr_pair(nbp + 2 * v);            // read once per pass: non-temporal, out of the value array's way in L2
-            c[u] = *reinterpret_cast<const float4 *>(o + v);
-        }
-        float2 g[kPairs][4];
-#pragma unroll
-        for (int u = 0; u < kPairs; ++u) {
-            g[u][0] = o[n[u].x];
-            g[u][1] = o[n[u].y];
-            g[u][2] = o[n[u].z];
-            g[u][3] = o[n[u].w];
-        }
-#pragma unroll
-        for (int u = 0; u < kPairs; ++u)
-            *reinterpret_cast<float4 *>(d + 2 * (p0 + u * kBlock)) = blur_pair(c[u], g[u][0], g[u][1], g[u][2], g[u][3]);
-        return;
+    const int *nbp = kd.nbr + (((size_t)f * kd.D1 + j) * kd.Epad + v) * 2;
+    if (v + 1 < V) {
+        const int4 nb4 = load_nbr_pair(nbp);              // read once per pass: non-temporal, out of the value array's way in L2
+        const float4 c = *reinterpret_cast<const float4 *>(o + v);
+        const float2 x0 = o[nb4.x], y0 = o[nb4.y], x1 = o[nb4.z], y1 = o[nb4.w];
+        *reinterpret_cast<float4 *>(d + v) = make_float4(c.x + 0.5f * (x0.x + y0.x), c.y + 0.5f * (x0.y + y0.y),
+                                                         c.z + 0.5f * (x1.x + y1.x), c.w + 0.5f * (x1.y + y1.y));
+    } else {
+        const int2 n2 = *reinterpret_cast<const int2 *>(nbp);
+        const float2 c = o[v], x = o[n2.x], y = o[n2.y];
+        d[v] = make_float2(c.x + 0.5f * (x.x + y.x), c.y + 0.5f * (x.y + y.y));
     }
-    for (int u = 0; u < kPairs; ++u) {
-        const int v = 2 * (p0 + u * kBlock);
-        if (v + 1 < V) {
-            const int4 n = load_nbr_pair(nbp + 2 * v);
-            const float4 c = *reinterpret_cast<const float4 *>(o + v);
-            *reinterpret_cast<float4 *>(d + v) = blur_pair(c, o[n.x], o[n.y], o[n.z], o[n.w]);
-        } else if (v < V) {
-            const int2 n = *reinterpret_cast<const int2 *>(nbp + 2 * v);
-            const float2 c = o[v], x = o[n.x], y = o[n.y];
-            d[v] = make_float2(c.x + 0.5f * (x.x + y.x), c.y + 0.5f * (x.y + y.y));
-        }
-    }
-}
-
-// The same pass on the compressed neighbour table.  A lane's pair u is pair (wavefront tile) + u * 64 + lane, so that the 64
-// pairs a wavefront handles together cover 128 consecutive vertices = two groups of the table: a lane's four presence
-// bits come from the flag word of its 16-vertex group, the position of its ids in the list from the running count of
-// the first of the two groups plus the set bits of the lanes below (four ballots).
-__global__ void __launch_bounds__(kBlock) k_blur2c(KernelDev kd, const float *__restrict__ src, float *__restrict__ dst, int j, int F,
-                                                   int nb)
-{
-    const FrameBlock fb = frame_block(nb);
-    const int f = fb.f;
-    if (f >= F) return;
-    const int V = kd.V[f];
-    if (2 * (fb.bx * kBlurTile) >= V) return;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int pw = fb.bx * kBlurTile + wave * (64 * kPairs);          // first pair of this wavefront's kPairs x 64 pairs
-    const int G = kd.Epad / 64 + 1, W = kd.Epad / 16 + 4;
-    const size_t plane = (size_t)f * kd.D1 + j;
-    const unsigned *flag = kd.nflag + plane * W;
-    const int *base = kd.nbase + plane * G;
-    const int *list = kd.nlist + plane * kd.Epad * 2;
-    const float2 *o = reinterpret_cast<const float2 *>(src + (size_t)f * kd.vstride + kd.vbase);   // o[-1] = absent
-    float2 *d = reinterpret_cast<float2 *>(dst + (size_t)f * kd.vstride + kd.vbase);
-    const unsigned long long below = (1ull << lane) - 1ull;
-    unsigned bits[kPairs];
-    int at[kPairs];
-    float4 c[kPairs];
-#pragma unroll
-    for (int u = 0; u < kPairs; ++u) {                                 // stage 1: flags, running counts, centres
-        const int v = 2 * (pw + u * 64 + lane);
-        bits[u] = 0u;
-        at[u] = 0;
-        c[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (v < V) {
-            bits[u] = (__builtin_nontemporal_load(flag + (v >> 4)) >> ((v & 15) * 2)) & (v + 1 < V ? 15u : 3u);
-            at[u] = base[(v >> 7) << 1];
-            if (v + 1 < V) c[u] = *reinterpret_cast<const float4 *>(o + v);
-            else { const float2 t = o[v]; c[u].x = t.x; c[u].y = t.y; }
-        }
-    }
-    int n[kPairs][4];
-#pragma unroll
-    for (int u = 0; u < kPairs; ++u) {                                 // stage 2: the present ids
-        const unsigned long long b0 = __ballot(bits[u] & 1u), b1 = __ballot(bits[u] & 2u), b2 = __ballot(bits[u] & 4u),
-                                 b3 = __ballot(bits[u] & 8u);
-        const int *lp = list + at[u] + (__popcll(b0 & below) + __popcll(b1 & below) + __popcll(b2 & below) + __popcll(b3 & below));
-        int p = 0;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            n[u][t] = -1;
-            if (bits[u] & (1u << t)) n[u][t] = __builtin_nontemporal_load(lp + p++);
-        }
-    }
-    float2 g[kPairs][4];
-#pragma unroll
-    for (int u = 0; u < kPairs; ++u)                                   // stage 3: the gathers
-#pragma unroll
-        for (int t = 0; t < 4; ++t) g[u][t] = o[n[u][t]];
-#pragma unroll
-    for (int u = 0; u < kPairs; ++u) {
-        const int v = 2 * (pw + u * 64 + lane);
-        const float4 r = blur_pair(c[u], g[u][0], g[u][1], g[u][2], g[u][3]);
-        if (v + 1 < V) *reinterpret_cast<float4 *>(d + v) = r;
-        else if (v < V) d[v] = make_float2(r.x, r.y);
-    }
-}
-
-// ---- the LDS-tiled blur pass (locality mode) -------------------------------------------------------------------------
-// What bounds k_blur2 is not bytes but the texture-address path: an 8-byte gather is one cache-line lookup per distinct
-// line and wavefront, ~64 cycles per gather instruction on scattered addresses, four gather instructions per vertex
-// pair (profiles/r3_stream_c5).  In locality mode consecutive vertex ids belong to neighbouring lattice cells, so most
-// present neighbours of a vertex sit within a few thousand ids of it: a workgroup stages a tile of kTileVerts consecutive
-// vertices in LDS with wide coalesced loads (BASELINE north_star: "LDS-staged lattice neighbourhoods") and serves every
-// neighbour that falls inside the tile with a ds_read_b64; only the rest (~1/3 of the present ones, ~0.2 per vertex) are
-// global gathers, and absent neighbours cost nothing.  Same operations per value as k_blur2: new = old + 0.5 * (n1 + n2).
-constexpr int kTileThreads = 1024;
-constexpr int kTilePairs = 4;                                          // vertex pairs per lane
-constexpr int kTileVerts = kTileThreads * kTilePairs * 2;              // 8192 vertices = 64 KB of float2
-
-__global__ void __launch_bounds__(kTileThreads) k_blur2t(KernelDev kd, const float *__restrict__ src, float *__restrict__ dst, int j,
-                                                         int F, int nb)
-{
-    extern __shared__ __attribute__((aligned(16))) float2 tile[];      // [kTileVerts]
-    int f, bx;
-    if (nb == 0) { f = blockIdx.y; bx = blockIdx.x; }
-    else { const int L = blockIdx.x, q = L >> 3, g = q / nb; f = g * 8 + (L & 7); bx = q - g * nb; }   // one XCD per frame (see frame_block)
-    if (f >= F) return;
-    const int V = kd.V[f];
-    const int v0 = bx * kTileVerts;
-    if (v0 >= V) return;
-    const float2 *o = reinterpret_cast<const float2 *>(src + (size_t)f * kd.vstride + kd.vbase);
-    float2 *d = reinterpret_cast<float2 *>(dst + (size_t)f * kd.vstride + kd.vbase);
-    const int *nbp = kd.nbr + (((size_t)f * kd.D1 + j) * kd.Epad) * 2;
-    int4 n[kTilePairs];
-    float4 c[kTilePairs];
-#pragma unroll
-    for (int u = 0; u < kTilePairs; ++u) {                             // stage 1: everything streamed, all in flight at once
-        const int lp = u * kTileThreads + threadIdx.x, v = v0 + 2 * lp;
-        n[u] = make_int4(-1, -1, -1, -1);
-        c[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (v + 1 < V) {
-            n[u] = load_nbr_pair(nbp + 2 * v);
-            c[u] = *reinterpret_cast<const float4 *>(o + v);
-        } else if (v < V) {
-            const int2 t = *reinterpret_cast<const int2 *>(nbp + 2 * v);
-            const float2 x = o[v];
-            n[u].x = t.x; n[u].y = t.y;
-            c[u].x = x.x; c[u].y = x.y;
-        }
-        *reinterpret_cast<float4 *>(tile + 2 * lp) = c[u];
-    }
-    __syncthreads();
-    float2 g[kTilePairs][4];
-#pragma unroll
-    for (int u = 0; u < kTilePairs; ++u) {                             // stage 2: the neighbours -- LDS inside the tile, HBM/L2 outside
-        const int nn[4] = {n[u].x, n[u].y, n[u].z, n[u].w};
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            g[u][t] = make_float2(0.f, 0.f);
-            const unsigned rel = (unsigned)(nn[t] - v0);
-            if (nn[t] >= 0) {
-                if (rel < (unsigned)kTileVerts) g[u][t] = tile[rel];
-                else g[u][t] = o[nn[t]];
-            }
-        }
-    }
-#pragma unroll
-    for (int u = 0; u < kTilePairs; ++u) {
-        const int v = v0 + 2 * (u * kTileThreads + threadIdx.x);
-        const float4 r = blur_pair(c[u], g[u][0], g[u][1], g[u][2], g[u][3]);
-        if (v + 1 < V) *reinterpret_cast<float4 *>(d + v) = r;
-        else if (v < V) d[v] = make_float2(r.x, r.y);
-    }
-}
-
-// grid of k_blur2t: tiles of kTileVerts vertices, frames XCD-aware like grid_xcd
-inline dim3 grid_tiles(int maxV, int F, int *nb)
-{
-    const int n = (maxV + kTileVerts - 1) / kTileVerts;
-    if (F < 8 || n < 1) { *nb = 0; return dim3((unsigned)(n > 0 ? n : 1), (unsigned)F); }
-    *nb = n;
-    return dim3((unsigned)(8L * ((F + 7) / 8) * n));
 }
 
 inline void launch_blur2(const KernelDev &kd, const float *src, float *dst, int j, int F, int maxV, hipStream_t s)
 {
-    static const bool no_tile = getenv("LCCRF_NO_BLUR_TILE") != nullptr;     // A/B switch: same results either way
     int nb;
-    if (kd.perm && !no_tile) {
-        static const bool once = [] {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_blur2t), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      kTileVerts * (int)sizeof(float2));
-            return true;
-        }();
-        (void)once;
-        const dim3 g = grid_tiles(maxV, F, &nb);
-        k_blur2t<<<g, kTileThreads, kTileVerts * sizeof(float2), s>>>(kd, src, dst, j, F, nb);
-        return;
-    }
-    const dim3 g = grid_xcd(((maxV + 1) / 2 + kPairs - 1) / kPairs, F, &nb);
-    if (kd.nlist) k_blur2c<<<g, kBlock, 0, s>>>(kd, src, dst, j, F, nb);
-    else k_blur2<<<g, kBlock, 0, s>>>(kd, src, dst, j, F, nb);
+    const dim3 g = grid_xcd((maxV + 1) / 2, F, &nb);
+    k_blur2<<<g, kBlock, 0, s>>>(kd, src, dst, j, F, nb);
 }
 
 // slice + apply for L = 2; the LAST kernel of the step also does the softmax (saves a pass over next).
@@ -1137,12 +873,12 @@ template <int D>
 void build_kernel_d(const KernelDev &kd, const CrfDev &c, hipStream_t s)
 {
     const int F = c.F, D1 = D + 1;
-    (void)hipMemsetAsync(kd.slot, 0xff, (size_t)F * kd.cap * sizeof(unsigned long long), s);
+    (void)hipMemsetAsync(kd.slot, 0xff, (size_t)F * kd.cap * sizeof(int), s);
     k_points<D><<<grid_for(kd.maxNpad, F), kBlock, 0, s>>>(kd, c.n_points);
     {
         int nb;
-        const dim3 g = grid_xcd(kd.Epad, LCCRF_BUILD_XCD ? F : 1, &nb);
-        k_insert<D><<<LCCRF_BUILD_XCD ? g : grid_for(kd.Epad, F), kBlock, 0, s>>>(kd, c.n_points, F, LCCRF_BUILD_XCD ? nb : 0);
+        const dim3 g = grid_xcd(kd.Epad, F, &nb);
+        k_insert<D><<<g, kBlock, 0, s>>>(kd, c.n_points, F, nb);
     }
     k_first_flag<<<grid_for(kd.Epad + 1, F), kBlock, 0, s>>>(kd, c.n_points);
     scan_frames(kd.flag, kd.prefix, kd.Epad + 1, kd.Epad + 1, kd.V, kd.rep, F, s);     // (rep is written later, by k_offsets: free scratch)
@@ -1150,18 +886,10 @@ void build_kernel_d(const KernelDev &kd, const CrfDev &c, hipStream_t s)
     (void)hipMemsetAsync(kd.nbr, 0xff, (size_t)F * D1 * kd.Epad * 2 * sizeof(int), s);          // every neighbour absent (-1)
     {
         int nb;
-        const dim3 g = grid_xcd((long)kd.Epad * D1, LCCRF_BUILD_XCD ? F : 1, &nb);
-        k_neighbors<D><<<LCCRF_BUILD_XCD ? g : grid_for((long)kd.Epad * D1, F), kBlock, 0, s>>>(kd, F, LCCRF_BUILD_XCD ? nb : 0);
+        const dim3 g = grid_xcd((long)kd.Epad * D1, F, &nb);
+        k_neighbors<D><<<g, kBlock, 0, s>>>(kd, F, nb);
     }
     if (kd.Epad < 65535) k_neighbors16<<<grid_for((long)kd.Epad * D1, F), kBlock, 0, s>>>(kd);
-    if (kd.nlist) {                                                     // two-label iteration of large frames: the compressed table
-        const int G = kd.Epad / 64 + 1;
-        int nb;
-        const dim3 g = grid_xcd((long)D1 * G * 64, F, &nb);
-        k_nbr_compress<<<g, kBlock, 0, s>>>(kd, 0, F, nb);
-        scan_frames(kd.ncount, kd.nbase, G, G, nullptr, kd.csr_pos, F * D1, s);     // (csr_pos is written later, by k_csr_order)
-        k_nbr_compress<<<g, kBlock, 0, s>>>(kd, 1, F, nb);
-    }
     // CSR
     (void)hipMemsetAsync(kd.flag, 0, (size_t)F * (kd.Epad + 1) * sizeof(int), s);
     k_csr_count<<<grid_for(kd.Epad, F), kBlock, 0, s>>>(kd, c.n_points);
