@@ -168,6 +168,8 @@ struct Engine {
     int *fb_list_host = nullptr;       // pinned [Fcap]
     Engine *fb = nullptr;
     int fallback_frames = 0;           // frames the last one-launch run had to re-run (report only)
+    bool frame_small_ok = true;        // small frames may run as 512-lane workgroups (two per CU); turned off for this engine when
+    bool frame_small_used = false;     //   more than 1/8 of a batch's frames did not fit that plan
     int late_iter = 0, late_map = 0;
     float late_relax = 1.0f;
     bool timed_build = false, timed_inf = false;
@@ -525,8 +527,8 @@ struct Engine {
     {
         *late_status = 0;
         const bool from_label = unary_deferred && L == 2;
-        launch_frame(crf, kdevs.data(), n_iter, with_map, relax, late_status, frame_status, from_label ? deferred_label : nullptr,
-                     deferred_tbl.v, stream);
+        frame_small_used = launch_frame(crf, kdevs.data(), n_iter, with_map, relax, late_status, frame_status,
+                                        from_label ? deferred_label : nullptr, deferred_tbl.v, stream, frame_small_ok);
         HIP_TRY(hipGetLastError());
         late_pending = true;
         late_iter = n_iter;
@@ -615,6 +617,7 @@ struct Engine {
         for (int f = 0; f < F; ++f)
             if (frame_status_host[f]) fb_list_host[n++] = f;
         fallback_frames = n;
+        if (frame_small_used && 8 * n > F) frame_small_ok = false;   // these lattices want the whole CU: 1024 lanes from now on
         int rc = LCCRF_OK;
         if (n >= F || n == 0) {                            // every frame (always so for the object API): two-kernel path in place
             built_upto = 0;

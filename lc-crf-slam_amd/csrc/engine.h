@@ -131,8 +131,10 @@ bool frame_supported(const CrfDev &c, const KernelDev *kds);
 // {u, n0, n1, p0, p1}; otherwise read from c.unary.  `status` (pinned host word, zeroed by the caller) reads 1
 // afterwards if some frame did not fit the kernel's LDS plan; `frame_status` (device [F], or null) then holds 1 for
 // exactly those frames and the caller runs them -- and only them -- on the two-kernel path.
-void launch_frame(const CrfDev &c, const KernelDev *kds, int n_iter, int with_map, float relax, int *status, int *frame_status,
-                  const int16_t *label, const float *tbl5, hipStream_t s);
+// allow_small: frames of up to 1024 points may run as 512-lane workgroups in half the CU's LDS (two frames per CU);
+// returns whether that shape was launched (a caller that sees many such frames flagged turns it off).
+bool launch_frame(const CrfDev &c, const KernelDev *kds, int n_iter, int with_map, float relax, int *status, int *frame_status,
+                  const int16_t *label, const float *tbl5, hipStream_t s, bool allow_small = true);
 // rows of `bytes` bytes each between a frame-strided array and a compact one: dst[i] = src[list[i]] (gather = 1) or
 // dst[list[i]] = src[i] (gather = 0); strides in bytes, everything 4-byte aligned
 void launch_copy_frames(void *dst, size_t dst_stride, const void *src, size_t src_stride, const int *list, int n_list,

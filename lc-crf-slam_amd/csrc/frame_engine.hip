@@ -94,6 +94,7 @@ __device__ __forceinline__ int wave_incl_scan(int x)
 
 // Exclusive scan of one int per lane over the workgroup; returns the prefix, `total` the grand total.
 // Two barriers; wave_sum may be reused right after the call returns only behind another barrier.
+template <int NT>
 __device__ __forceinline__ int block_excl_scan(int x, int tid, int *wave_sum, int &total)
 {
     const int lane = tid & 63, wave = tid >> 6;
@@ -101,9 +102,9 @@ __device__ __forceinline__ int block_excl_scan(int x, int tid, int *wave_sum, in
     __syncthreads();                                      // a previous scan's readers are done with wave_sum
     if (lane == 63) wave_sum[wave] = incl;
     __syncthreads();
-    const int ws = lane < kNT / 64 ? wave_sum[lane] : 0;  // the 16 wavefront totals, scanned again inside every wavefront
+    const int ws = lane < NT / 64 ? wave_sum[lane] : 0;  // the 16 wavefront totals, scanned again inside every wavefront
     const int wincl = wave_incl_scan(ws);
-    total = __builtin_amdgcn_readlane(wincl, kNT / 64 - 1);
+    total = __builtin_amdgcn_readlane(wincl, NT / 64 - 1);
     const int wbase = __builtin_amdgcn_readlane(wincl - ws, __builtin_amdgcn_readfirstlane(wave));
     return wbase + incl - x;
 }
@@ -116,8 +117,10 @@ __device__ __forceinline__ unsigned corner_key(const int16_t (&r0)[2], const uin
     return x | (y << 16);
 }
 
-template <int PPT, int K>
-__global__ void __launch_bounds__(kNT) k_frame(CrfDev c, FrameArgs a)
+// NT = 1024 lanes, or 512 for frames of up to 1024 points whose plan fits half the CU's LDS: two frames per CU
+// (fused_loop.h: kNTSmall).  Second launch bound: 128 registers per lane in both shapes.
+template <int NT, int PPT, int K>
+__global__ void __launch_bounds__(NT, 4) k_frame(CrfDev c, FrameArgs a)
 {
     constexpr int D1 = kD1;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -143,7 +146,7 @@ __global__ void __launch_bounds__(kNT) k_frame(CrfDev c, FrameArgs a)
     float2 ft[PPT][K];
 #pragma unroll
     for (int s = 0; s < PPT; ++s) {
-        const int ic = min(tid + s * kNT, N - 1);
+        const int ic = min(tid + s * NT, N - 1);
 #pragma unroll
         for (int k = 0; k < K; ++k) ft[s][k] = reinterpret_cast<const float2 *>(a.feat[k])[(size_t)f * a.maxN + ic];
         if (a.label) {                                    // densecrf3d.h:116-129 with L = 2
@@ -170,7 +173,7 @@ __global__ void __launch_bounds__(kNT) k_frame(CrfDev c, FrameArgs a)
         unsigned key[PPT][D1];
 #pragma unroll
         for (int s = 0; s < PPT; ++s) {
-            const int i = tid + s * kNT;
+            const int i = tid + s * NT;
             float feat[2] = {i < N ? ft[s][k].x : 0.0f, i < N ? ft[s][k].y : 0.0f};   // phantom lanes, :299
             int16_t r0[2];
             uint8_t rk[2];
@@ -182,7 +185,7 @@ __global__ void __launch_bounds__(kNT) k_frame(CrfDev c, FrameArgs a)
                 key[s][j] = corner_key(r0, rk, j);
             }
         }
-        for (int u = tid; u < hcap; u += kNT) hk[u] = kEmptyKey;
+        for (int u = tid; u < hcap; u += NT) hk[u] = kEmptyKey;
         __syncthreads();
         FL_PSTAMP();
 
@@ -198,7 +201,7 @@ __global__ void __launch_bounds__(kNT) k_frame(CrfDev c, FrameArgs a)
                 slot[s][j] = hash32(key[s][j]) & mask;
                 got[s][j] = key[s][j];
                 bad |= key[s][j] == kEmptyKey;
-                if (tid + s * kNT < Npad) got[s][j] = atomicCAS(&hk[slot[s][j]], kEmptyKey, key[s][j]);
+                if (tid + s * NT < Npad) got[s][j] = atomicCAS(&hk[slot[s][j]], kEmptyKey, key[s][j]);
             }
         int ncreated = 0;
 #pragma unroll
@@ -224,7 +227,7 @@ __global__ void __launch_bounds__(kNT) k_frame(CrfDev c, FrameArgs a)
         // ---- C: dense vertex ids, handed out to the entries that created their vertex (any numbering will do: a
         //      vertex's value is a sum over its own row, its neighbours are found by key); carve this kernel's tables
         int Vk;
-        int id = block_excl_scan(ncreated, tid, hdr->wave_sum, Vk);       // (its barriers also close phase B)
+        int id = block_excl_scan<NT>(ncreated, tid, hdr->wave_sum, Vk);       // (its barriers also close phase B)
         V[k] = Vk;
         FL_PSTAMP();
         const int W = (((Npad + 31) >> 5) + 3) & ~3;      // bitmap words per vertex, a multiple of 4
@@ -264,17 +267,17 @@ __global__ void __launch_bounds__(kNT) k_frame(CrfDev c, FrameArgs a)
                     vkey[id] = key[s][j];
                     ++id;
                 }
-        for (int v = tid; v <= Vk; v += kNT) cnt[v] = 0u;
+        for (int v = tid; v <= Vk; v += NT) cnt[v] = 0u;
         {
             unsigned *nbz = reinterpret_cast<unsigned *>(smem + lay.nbr[k]);   // absent neighbours stay 0
-            for (int u = tid; u < D1 * Vk; u += kNT) nbz[u] = 0u;
+            for (int u = tid; u < D1 * Vk; u += NT) nbz[u] = 0u;
         }
         if (bitmap) {
             uint4 *b4 = reinterpret_cast<uint4 *>(bm);
-            for (int u = tid; u < Vk * W / 4; u += kNT) b4[u] = make_uint4(0u, 0u, 0u, 0u);
+            for (int u = tid; u < Vk * W / 4; u += NT) b4[u] = make_uint4(0u, 0u, 0u, 0u);
         } else {
             uint4 *l4 = reinterpret_cast<uint4 *>(list);   // pads compare greater than every entry (entries are < 0x7fff)
-            for (int u = tid; u < list_cap / 8; u += kNT) l4[u] = make_uint4(0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu);
+            for (int u = tid; u < list_cap / 8; u += NT) l4[u] = make_uint4(0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu);
         }
         if (tid == 0) {
             reinterpret_cast<float2 *>(smem + lay.val[k][0])[0] = make_float2(0.f, 0.f);
@@ -289,11 +292,11 @@ __global__ void __launch_bounds__(kNT) k_frame(CrfDev c, FrameArgs a)
 #pragma unroll
         for (int s = 0; s < PPT; ++s)
 #pragma unroll
-            for (int j = 0; j < D1; ++j) vid[s][j] = (tid + s * kNT < Npad) ? (unsigned)ido[slot[s][j]] : 0u;
+            for (int j = 0; j < D1; ++j) vid[s][j] = (tid + s * NT < Npad) ? (unsigned)ido[slot[s][j]] : 0u;
         FL_PSTAMP();
 #pragma unroll
         for (int s = 0; s < PPT; ++s) {
-            const int i = tid + s * kNT;
+            const int i = tid + s * NT;
 #pragma unroll
             for (int j = 0; j < D1; ++j) {
                 arr[s][j] = 0u;
@@ -309,7 +312,7 @@ __global__ void __launch_bounds__(kNT) k_frame(CrfDev c, FrameArgs a)
             // The relation is mutual -- B = n2_j(A) iff A = n1_j(B) -- so one probe per (axis, vertex) finds n2 and
             // fills both halves; absent neighbours keep the 0 the table was cleared to.
             unsigned short *nb16 = reinterpret_cast<unsigned short *>(smem + lay.nbr[k]);   // [axis][vertex][n1+1, n2+1]
-            for (int t = tid; t < D1 * Vk; t += kNT) {
+            for (int t = tid; t < D1 * Vk; t += NT) {
                 const int j = t >= 2 * Vk ? 2 : (t >= Vk ? 1 : 0), v = t - j * Vk;
                 const unsigned kk = vkey[v];
                 const unsigned qx = ((kk & 0xffffu) + (j == 0 ? 0xfffeu : 1u)) & 0xffffu, qy = ((kk >> 16) + (j == 1 ? 0xfffeu : 1u)) & 0xffffu;
@@ -336,7 +339,7 @@ __global__ void __launch_bounds__(kNT) k_frame(CrfDev c, FrameArgs a)
             // prefix popcounts of every vertex's bitmap, one 16-lane group per vertex (W <= 128 words = 32 groups of 4
             // words: 2 groups per lane at most): pre[v][g] = entries of v in points before word group g
             const int lane16 = tid & 15, ng = W >> 2, gpl = (ng + 15) >> 4;
-            for (int v = tid >> 4; v < Vk; v += kNT / 16) {
+            for (int v = tid >> 4; v < Vk; v += NT / 16) {
                 int pc[2] = {0, 0}, sum = 0;
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
@@ -365,7 +368,7 @@ __global__ void __launch_bounds__(kNT) k_frame(CrfDev c, FrameArgs a)
         }
         {
             // packed scan: low half = products before the row, high half = padded list entries before it
-            const int vper = (Vk + 1 + kNT - 1) / kNT, v0 = tid * vper;
+            const int vper = (Vk + 1 + NT - 1) / NT, v0 = tid * vper;
             unsigned sum = 0u;
             int mx = 0;
             for (int u = 0; u < vper; ++u) {
@@ -377,7 +380,7 @@ __global__ void __launch_bounds__(kNT) k_frame(CrfDev c, FrameArgs a)
                 }
             }
             int tot;
-            unsigned run = (unsigned)block_excl_scan((int)sum, tid, hdr->wave_sum, tot);
+            unsigned run = (unsigned)block_excl_scan<NT>((int)sum, tid, hdr->wave_sum, tot);
             unsigned short *row = reinterpret_cast<unsigned short *>(smem + lay.row[k]);
             for (int u = 0; u < vper; ++u) {
                 const int v = v0 + u;
@@ -410,7 +413,7 @@ __global__ void __launch_bounds__(kNT) k_frame(CrfDev c, FrameArgs a)
         if (!bitmap) {
 #pragma unroll
             for (int s = 0; s < PPT; ++s) {
-                const int i = tid + s * kNT;
+                const int i = tid + s * NT;
                 if (i < N) {
 #pragma unroll
                     for (int j = 0; j < D1; ++j) list[(lc[s][j] & 0xffffu) + arr[s][j]] = (unsigned short)(i * D1 + j);
@@ -423,7 +426,7 @@ __global__ void __launch_bounds__(kNT) k_frame(CrfDev c, FrameArgs a)
         if (bitmap) {
 #pragma unroll
             for (int s = 0; s < PPT; ++s) {               // (one point at a time: three 16-byte reads in flight, 12 registers)
-                const int i = min(tid + s * kNT, N - 1);
+                const int i = min(tid + s * NT, N - 1);
                 uint4 bw[D1];
                 unsigned pv[D1];
 #pragma unroll
@@ -450,7 +453,7 @@ __global__ void __launch_bounds__(kNT) k_frame(CrfDev c, FrameArgs a)
             };
 #pragma unroll
             for (int s = 0; s < PPT; ++s) {
-                const int i = tid + s * kNT;
+                const int i = tid + s * NT;
                 uint4 first[D1];
 #pragma unroll
                 for (int j = 0; j < D1; ++j) first[j] = *reinterpret_cast<const uint4 *>(list + (lc[s][j] & 0xffffu));
@@ -469,7 +472,7 @@ __global__ void __launch_bounds__(kNT) k_frame(CrfDev c, FrameArgs a)
         for (int s = 0; s < PPT; ++s)
 #pragma unroll
             for (int j = 0; j < D1; ++j) {
-                const bool real = tid + s * kNT < N;
+                const bool real = tid + s * NT < N;
                 pk[s][k][j] = (vid[s][j] + 1u) | ((rw[s][j] + (real ? rank[s][j] : 0u)) << 16);
             }
         if (k == 0) row0max = hdr->rowmax;
@@ -480,7 +483,7 @@ __global__ void __launch_bounds__(kNT) k_frame(CrfDev c, FrameArgs a)
     FL_STAMP();
 
     // ---- loop-phase LDS plan: product buffers behind the persistent tables ---------------------------
-    lay.chain0 = chain_wanted(N, V[0], row0max) ? 1 : 0;
+    lay.chain0 = chain_wanted(N, V[0], row0max, NT) ? 1 : 0;
     {
         bool ok = false;
         for (int all = 1; all >= 0 && !ok; --all) {
@@ -507,7 +510,7 @@ __global__ void __launch_bounds__(kNT) k_frame(CrfDev c, FrameArgs a)
             return;
         }
     }
-    place_products<PPT, K, 2>(smem, lay, N, tid, pk, pr);
+    place_products<PPT, K, 2, NT>(smem, lay, N, tid, pk, pr);
     ChainLane cl{0u, 0u};
     if (lay.chain0) cl = chain_setup(smem, lay, V[0], tid);
 
@@ -515,13 +518,13 @@ __global__ void __launch_bounds__(kNT) k_frame(CrfDev c, FrameArgs a)
     //      splat / blur / slice with Q = 1 for every kernel at once
 #pragma unroll
     for (int s = 0; s < PPT; ++s) pr.q[s] = make_float2(1.0f, 1.0f);
-    splat_blur<PPT, K, 2>(smem, lay, V, N, tid, pr, cl, ins);
+    splat_blur<PPT, K, 2, true, NT>(smem, lay, V, N, tid, pr, cl, ins);
 #pragma unroll
     for (int s = 0; s < PPT; ++s) {
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             pr.wn[s][k] = 0.0f;
-            if (tid + s * kNT < N) {
+            if (tid + s * NT < N) {
                 const float t = slice_point(smem, lay, pr, s, k, a.alpha).x;
                 pr.wn[s][k] = a.w[k] * (1.0f / (t + 1e-20f));             // pairwise3d.h:26-27,77
             }
@@ -529,12 +532,12 @@ __global__ void __launch_bounds__(kNT) k_frame(CrfDev c, FrameArgs a)
     }
     FL_STAMP();                                           // (no barrier: the next writer of val[.][1] is two barriers away)
 
-    start_inference(pr, N, tid);
+    start_inference<PPT, K, NT>(pr, N, tid);
     float alpha[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) alpha[k] = a.alpha;
-    mean_field<PPT, K, 2>(smem, lay, V, N, tid, pr, cl, alpha, a.n_iter, a.relax, ins);
-    store_results(c, f, N, tid, pr, a.with_map);
+    mean_field<PPT, K, 2, NT>(smem, lay, V, N, tid, pr, cl, alpha, a.n_iter, a.relax, ins);
+    store_results<PPT, K, NT>(c, f, N, tid, pr, a.with_map);
     if (tid < K && a.V_out[tid]) a.V_out[tid][f] = tid == 0 ? V[0] : V[K - 1];
     if (tid == 0 && a.frame_status) a.frame_status[f] = 0;
     FL_STAMP();
@@ -549,12 +552,12 @@ int frame_hcap(int NA)
     return h;
 }
 
-template <int PPT, int K>
+template <int NT, int PPT, int K>
 void launch_frame_ppt(const CrfDev &c, const FrameArgs &a, hipStream_t s)
 {
-    auto fn = k_frame<PPT, K>;
+    auto fn = k_frame<NT, PPT, K>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit);
-    fn<<<dim3(c.F), dim3(kNT), a.lds_total, s>>>(c, a);
+    fn<<<dim3(c.F), dim3(NT), a.lds_total, s>>>(c, a);
 }
 
 }  // namespace
@@ -568,8 +571,8 @@ bool frame_supported(const CrfDev &c, const KernelDev *kds)
     return true;
 }
 
-void launch_frame(const CrfDev &c, const KernelDev *kds, int n_iter, int with_map, float relax, int *status, int *frame_status,
-                  const int16_t *label, const float *tbl5, hipStream_t s)
+bool launch_frame(const CrfDev &c, const KernelDev *kds, int n_iter, int with_map, float relax, int *status, int *frame_status,
+                  const int16_t *label, const float *tbl5, hipStream_t s, bool allow_small)
 {
     FrameArgs a{};
     for (int k = 0; k < c.K; ++k) {
@@ -600,18 +603,41 @@ void launch_frame(const CrfDev &c, const KernelDev *kds, int n_iter, int with_ma
     a.timing_block = want_timing ? std::max(atoi(getenv("LCCRF_FRAME_TIMING")) - 1, 0) : 0;
     if (a.timing_block >= c.F) a.timing_block = 0;
     a.timing_lane = (want_timing && getenv("LCCRF_FRAME_TIMING_LANE")) ? atoi(getenv("LCCRF_FRAME_TIMING_LANE")) & (kNT - 1) : 0;
-    const int ppt = (NA + kNT - 1) / kNT;
-#define FRAME_CASE(P)                                          \
+    // Small frames: 512 lanes and half the CU's LDS per frame, so that two frames share a CU.  A frame whose lattices
+    // do not fit that plan (or whose long rows need more chain lanes than four wavefront pairs have) flags itself
+    // and is re-run like any other frame that does not fit.
+    // The lattice sizes are not known before the kernel has built them: the small shape is chosen when a frame of NA
+    // points with lattices of the usual SLAM proportions (an appearance kernel at the chain limit, a smoothness kernel
+    // of NA + 400 vertices: 734 at 400 points, 927 at 650, 1071 at 1000 on 640x480 images) fits half the LDS -- NA up to
+    // ~650.  Sparser frames flag themselves.
+    static const bool no_small = getenv("LCCRF_NO_SMALL_WG") != nullptr;   // A/B switch: same results either way
+    bool small = allow_small && !no_small && NA <= 2 * kNTSmall && c.F >= kSmallMinFrames;
+    if (small) {
+        int vest[kMaxFusedK];
+        for (int k = 0; k < c.K; ++k) vest[k] = (c.K > 1 && k == 0) ? chain_max_v(kNTSmall) : std::min(3 * NA, NA + 400);
+        FusedLayout est;
+        small = layout_core(NA, c.K, vest, 1 << 20, &est, kNTSmall, kLdsHalf - (size_t)frame_hcap(NA) * 6 / 4);
+    }
+#define FRAME_CASE(NT, P)                                      \
     case P:                                                    \
-        if (c.K == 1) launch_frame_ppt<P, 1>(c, a, s);         \
-        else launch_frame_ppt<P, 2>(c, a, s);                  \
+        if (c.K == 1) launch_frame_ppt<NT, P, 1>(c, a, s);     \
+        else launch_frame_ppt<NT, P, 2>(c, a, s);              \
         break;
-    switch (ppt) {
-        FRAME_CASE(1)
-        FRAME_CASE(2)
-        FRAME_CASE(3)
-        FRAME_CASE(4)
-    default: break;
+    if (small) {
+        a.lds_total = (int)kLdsHalf;
+        switch ((NA + kNTSmall - 1) / kNTSmall) {
+            FRAME_CASE(kNTSmall, 1)
+            FRAME_CASE(kNTSmall, 2)
+        default: break;
+        }
+    } else {
+        switch ((NA + kNT - 1) / kNT) {
+            FRAME_CASE(kNT, 1)
+            FRAME_CASE(kNT, 2)
+            FRAME_CASE(kNT, 3)
+            FRAME_CASE(kNT, 4)
+        default: break;
+        }
     }
 #undef FRAME_CASE
     if (a.timing) {                       // instrumented builds: synchronous read-back of one workgroup's stamps
@@ -622,6 +648,7 @@ void launch_frame(const CrfDev &c, const KernelDev *kds, int n_iter, int with_ma
         for (int i = 1; i < h[63] && i < 63; ++i) fprintf(stderr, " %lld", h[i] - h[i - 1]);
         fprintf(stderr, "\n");
     }
+    return small;
 }
 
 }  // namespace lccrf

@@ -42,11 +42,14 @@ struct FusedArgs {
     int dbg;                              // instrumented builds: LCCRF_FUSED_DBG (see fused_loop.h)
 };
 
-// One workgroup per frame.  Lane t owns points t, t+1024, ... (PPT of them); the per-frame records a build
+// One workgroup per frame.  Lane t owns points t, t+NT, ... (PPT of them); the per-frame records a build
 // kernel left in HBM (~150 KB) are loaded once, then fused_loop.h runs the whole inference on chip.
+//   NT = 1024, or 512 for frames small enough that two workgroups share a CU (fused_loop.h: kNTSmall)
 //   CH = 0 / 1: kernel 0 short-row / chain, decided by the host
-template <int PPT, int K, int CH>
-__global__ void __launch_bounds__(kNT) k_fused(CrfDev c, FusedArgs a)
+// (second launch bound: four wavefronts per SIMD = 128 registers per lane in both shapes -- what lets two 512-lane
+// workgroups be co-resident)
+template <int NT, int PPT, int K, int CH>
+__global__ void __launch_bounds__(NT, 4) k_fused(CrfDev c, FusedArgs a)
 {
     constexpr int D1 = kD1;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -64,14 +67,14 @@ __global__ void __launch_bounds__(kNT) k_fused(CrfDev c, FusedArgs a)
     if (N <= 0) return;                   // nothing to infer (and nothing below may index an empty frame)
     const FusedLayout &lay = a.lay;
     if (FL_DBG(4)) {                      // debugging aid: NaN-poison the LDS so that reads of unwritten LDS show up
-        for (int i = tid; i < lay.total / 4; i += kNT) reinterpret_cast<unsigned *>(smem)[i] = 0x7fc00000u + (unsigned)i;
+        for (int i = tid; i < lay.total / 4; i += NT) reinterpret_cast<unsigned *>(smem)[i] = 0x7fc00000u + (unsigned)i;
         __syncthreads();
     }
 
     // All global loads of the prologue are issued before anything waits on them: the lattice
     // tables first (their LDS stores come last), then the per-point records.  Indices are clamped
     // instead of branched on, so that the loads stay back to back.
-    constexpr int kNbrRounds = 4, kRowRounds = 2;         // covers V <= 1365 in registers; larger lattices finish in copy loops
+    constexpr int kNbrRounds = 4096 / NT, kRowRounds = 2048 / NT;   // covers V <= 1365 in registers; larger lattices finish in copy loops
     unsigned g_nbr[K][kNbrRounds];
     int g_row[K][kRowRounds];
 #pragma unroll
@@ -81,17 +84,17 @@ __global__ void __launch_bounds__(kNT) k_fused(CrfDev c, FusedArgs a)
         const int *gr = kd.rowptr + (size_t)f * (kd.Epad + 1);
 #pragma unroll
         for (int r = 0; r < kNbrRounds; ++r) {            // element idx = j*V + v, j-major like the LDS copy
-            const int idx = min(tid + r * kNT, D1 * V[k] - 1);
+            const int idx = min(tid + r * NT, D1 * V[k] - 1);
             const int j = idx >= 2 * V[k] ? 2 : (idx >= V[k] ? 1 : 0);
             g_nbr[k][r] = gn[(size_t)j * kd.Epad + (idx - j * V[k])];
         }
 #pragma unroll
-        for (int r = 0; r < kRowRounds; ++r) g_row[k][r] = gr[min(tid + r * kNT, V[k])];
+        for (int r = 0; r < kRowRounds; ++r) g_row[k][r] = gr[min(tid + r * NT, V[k])];
     }
     unsigned pk[PPT][K][D1];              // (vertex id + 1) | place in the row << 16
 #pragma unroll
     for (int s = 0; s < PPT; ++s) {
-        const int ic = min(tid + s * kNT, N - 1);
+        const int ic = min(tid + s * NT, N - 1);
         pr.un[s] = reinterpret_cast<const float2 *>(c.unary)[(size_t)f * c.maxN + ic];
 #pragma unroll
         for (int k = 0; k < K; ++k) {
@@ -118,21 +121,21 @@ __global__ void __launch_bounds__(kNT) k_fused(CrfDev c, FusedArgs a)
         unsigned short *row = reinterpret_cast<unsigned short *>(smem + lay.row[k]);
 #pragma unroll
         for (int r = 0; r < kNbrRounds; ++r) {
-            const int idx = tid + r * kNT;
+            const int idx = tid + r * NT;
             if (idx < D1 * V[k]) nbr[idx] = g_nbr[k][r];
         }
 #pragma unroll
         for (int r = 0; r < kRowRounds; ++r)
-            if (tid + r * kNT <= V[k]) row[tid + r * kNT] = (unsigned short)g_row[k][r];
+            if (tid + r * NT <= V[k]) row[tid + r * NT] = (unsigned short)g_row[k][r];
         // lattices with more vertices than the register rounds cover (sparse frames): plain copy loops
         const KernelDev &kd = a.kd[k];
         const unsigned *gn = kd.nbr16 + (size_t)f * D1 * kd.Epad;
-        for (int idx = tid + kNbrRounds * kNT; idx < D1 * V[k]; idx += kNT) {
+        for (int idx = tid + kNbrRounds * NT; idx < D1 * V[k]; idx += NT) {
             const int j = idx >= 2 * V[k] ? 2 : (idx >= V[k] ? 1 : 0);
             nbr[idx] = gn[(size_t)j * kd.Epad + (idx - j * V[k])];
         }
         const int *gr = kd.rowptr + (size_t)f * (kd.Epad + 1);
-        for (int v = tid + kRowRounds * kNT; v <= V[k]; v += kNT) row[v] = (unsigned short)gr[v];
+        for (int v = tid + kRowRounds * NT; v <= V[k]; v += NT) row[v] = (unsigned short)gr[v];
     }
     if (tid < 16) reinterpret_cast<float *>(smem + lay.zero)[tid] = 0.0f;
     if (tid == 0) {
@@ -151,48 +154,64 @@ __global__ void __launch_bounds__(kNT) k_fused(CrfDev c, FusedArgs a)
     ChainLane cl{0u, 0u};
     if (CH != 0 && chain_k<CH>(lay, 0)) cl = chain_setup(smem, lay, V[0], tid);
     FL_PSTAMP();
-    start_inference(pr, N, tid);
-    place_products<PPT, K, CH>(smem, lay, N, tid, pk, pr);
+    start_inference<PPT, K, NT>(pr, N, tid);
+    place_products<PPT, K, CH, NT>(smem, lay, N, tid, pk, pr);
     FL_STAMP();
 
     float alpha[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) alpha[k] = a.kd[k].alpha;
-    mean_field<PPT, K, CH>(smem, lay, V, N, tid, pr, cl, alpha, a.n_iter, a.relax, ins);
+    mean_field<PPT, K, CH, NT>(smem, lay, V, N, tid, pr, cl, alpha, a.n_iter, a.relax, ins);
 
-    store_results(c, f, N, tid, pr, a.with_map);
+    store_results<PPT, K, NT>(c, f, N, tid, pr, a.with_map);
     FL_STAMP();
     if (kInstr && a.timing && (int)blockIdx.x == a.timing_block && tid == a.timing_lane) a.timing[63] = ins.n;
 }
 
-bool make_layout(const CrfDev &c, const KernelDev *kds, const int *maxV, const int *maxRow, FusedLayout *lay)
+bool make_layout(const CrfDev &c, const KernelDev *kds, const int *maxV, const int *maxRow, FusedLayout *lay, int nt = kNT,
+                 size_t lds_limit = kLdsLimit)
 {
     if (c.L != 2 || c.K < 1 || c.K > kMaxFusedK) return false;
     const int NA = c.activeN > 0 ? c.activeN : c.maxN;   // size LDS and the points-per-lane variant by the frames' real size
     for (int k = 0; k < c.K; ++k)
         if (kds[k].d != 2 || kds[k].Epad >= 65535) return false;       // u16 row pointers / neighbour ids / slots
-    return layout_core(NA, c.K, maxV, maxRow ? maxRow[0] : 0, lay);
+    return layout_core(NA, c.K, maxV, maxRow ? maxRow[0] : 0, lay, nt, lds_limit);
 }
 
-template <int PPT, int K, int CH>
+// Two frames per CU?  Up to 2 points per lane of a 512-lane workgroup, the whole plan in half the CU's LDS, and -- if
+// kernel 0 has long rows -- few enough vertices for the chain lanes of four wavefront pairs.
+bool small_layout(const CrfDev &c, const KernelDev *kds, const int *maxV, const int *maxRow, FusedLayout *lay)
+{
+    static const bool off = getenv("LCCRF_NO_SMALL_WG") != nullptr;      // A/B switch: same results either way
+    const int NA = c.activeN > 0 ? c.activeN : c.maxN;
+    if (off || c.F < kSmallMinFrames || NA > 2 * kNTSmall || maxV[0] > kNTSmall) return false;
+    const int row0 = maxRow ? maxRow[0] : 0;
+    if (row0 >= kChainMinRow && !chain_wanted(NA, maxV[0], row0, kNTSmall)) return false;   // long rows need the chain path: keep 1024 lanes
+    FusedLayout L;
+    if (!make_layout(c, kds, maxV, maxRow, &L, kNTSmall, kLdsHalf)) return false;
+    *lay = L;
+    return true;
+}
+
+template <int NT, int PPT, int K, int CH>
 void launch_fused(const CrfDev &c, const FusedArgs &a, hipStream_t s)
 {
-    auto fn = k_fused<PPT, K, CH>;
+    auto fn = k_fused<NT, PPT, K, CH>;
     // per (function, device); cheap enough to repeat and safe with several devices in one process
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)kLdsLimit);
-    fn<<<dim3(c.F), dim3(kNT), a.lay.total, s>>>(c, a);
+    fn<<<dim3(c.F), dim3(NT), a.lay.total, s>>>(c, a);
 }
 
-template <int PPT>
+template <int NT, int PPT>
 void launch_fused_ppt(const CrfDev &c, const FusedArgs &a, hipStream_t s)
 {
     if (c.K == 1) {
-        if (a.lay.chain0) launch_fused<PPT, 1, 1>(c, a, s);
-        else launch_fused<PPT, 1, 0>(c, a, s);
+        if (a.lay.chain0) launch_fused<NT, PPT, 1, 1>(c, a, s);
+        else launch_fused<NT, PPT, 1, 0>(c, a, s);
     } else {
-        if (a.lay.chain0) launch_fused<PPT, 2, 1>(c, a, s);
-        else launch_fused<PPT, 2, 0>(c, a, s);
+        if (a.lay.chain0) launch_fused<NT, PPT, 2, 1>(c, a, s);
+        else launch_fused<NT, PPT, 2, 0>(c, a, s);
     }
 }
 
@@ -210,7 +229,8 @@ void launch_inference_fused(const CrfDev &c, const KernelDev *kds, const int *ma
                             int with_map, float relax, hipStream_t s)
 {
     FusedArgs a{};
-    if (!make_layout(c, kds, maxV, maxRow, &a.lay)) return;
+    const bool small = small_layout(c, kds, maxV, maxRow, &a.lay);
+    if (!small && !make_layout(c, kds, maxV, maxRow, &a.lay)) return;
     static const bool no_chain = getenv("LCCRF_NO_CHAIN") != nullptr;     // debugging aid: compiler-scheduled S phase
     if (no_chain) a.lay.chain0 = 0;                                        // (the padded plane size is harmless)
     for (int k = 0; k < c.K; ++k) a.kd[k] = kds[k];
@@ -226,13 +246,18 @@ void launch_inference_fused(const CrfDev &c, const KernelDev *kds, const int *ma
     a.timing_lane = (want_timing && getenv("LCCRF_FUSED_TIMING_LANE")) ? atoi(getenv("LCCRF_FUSED_TIMING_LANE")) & (kNT - 1) : 0;
     static const int dbg = (kInstr && getenv("LCCRF_FUSED_DBG")) ? atoi(getenv("LCCRF_FUSED_DBG")) : 0;
     a.dbg = dbg;
-    const int ppt = ((c.activeN > 0 ? c.activeN : c.maxN) + kNT - 1) / kNT;
-    switch (ppt) {
-    case 1: launch_fused_ppt<1>(c, a, s); break;
-    case 2: launch_fused_ppt<2>(c, a, s); break;
-    case 3: launch_fused_ppt<3>(c, a, s); break;
-    case 4: launch_fused_ppt<4>(c, a, s); break;
-    default: break;
+    const int NAp = c.activeN > 0 ? c.activeN : c.maxN;
+    if (small) {
+        if (NAp <= kNTSmall) launch_fused_ppt<kNTSmall, 1>(c, a, s);
+        else launch_fused_ppt<kNTSmall, 2>(c, a, s);
+    } else {
+        switch ((NAp + kNT - 1) / kNT) {
+        case 1: launch_fused_ppt<kNT, 1>(c, a, s); break;
+        case 2: launch_fused_ppt<kNT, 2>(c, a, s); break;
+        case 3: launch_fused_ppt<kNT, 3>(c, a, s); break;
+        case 4: launch_fused_ppt<kNT, 4>(c, a, s); break;
+        default: break;
+        }
     }
     if (a.timing) {                       // debug only: synchronous read-back of workgroup 0's phase stamps
         long long h[64];

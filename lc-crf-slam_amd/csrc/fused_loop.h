@@ -29,7 +29,16 @@ constexpr int kChainGap = 14;             // product slots reserved per chain ro
 constexpr int kChainTop = 16;             // rows of the first chain wavefront pair (see chain_setup)
 constexpr size_t kLdsLimit = 160 * 1024;  // MI355X: 160 KiB LDS per CU, one workgroup may own it all
 constexpr int kChainMinRow = 64;          // kernel 0 runs chain_rows when its longest splat row has at least this many products ...
-constexpr int kChainMaxV = kChainTop + 7 * 64;           // ... and it has at most this many vertices (one lane per (vertex,label) row)
+// ... and it has at most this many vertices (one lane per (vertex,label) row: wavefront pair 0 takes the kChainTop longest
+// rows, every further pair of the workgroup's nt / 128 pairs 64 rows)
+__host__ __device__ constexpr int chain_max_v(int nt) { return kChainTop + (nt / 128 - 1) * 64; }
+constexpr int kChainMaxV = chain_max_v(kNT);
+// Small frames: a 512-lane workgroup needs half the registers of the CU and, up to ~1000 points, less than half its LDS,
+// so TWO frames share a CU and one frame's ordered row sums (one wavefront, latency-bound) run under the other's
+// point phases (VALU / LDS-bound) -- across workgroups, where the hardware arbitrates, not inside one.
+constexpr int kNTSmall = 512;
+constexpr int kSmallMinFrames = 256;       // fewer frames than CUs: nothing to share a CU with, 1024 lanes finish a frame sooner
+constexpr size_t kLdsHalf = kLdsLimit / 2;
 
 #ifndef LCCRF_FUSE_XP
 #define LCCRF_FUSE_XP 1
@@ -79,21 +88,22 @@ __host__ __device__ inline int pst(int r0, int v) { return (r0 + kChainGap * v +
 // Size of the product plane of kernel k (floats per label) for frames of NA points.
 __host__ __device__ inline int plane_floats(int NA, int V, bool chain) { return ((chain ? NA * kD1 + kChainGap * V + 16 : NA * kD1) + 63) & ~63; }
 
-__host__ __device__ inline bool chain_wanted(int NA, int V0, int row0)
+__host__ __device__ inline bool chain_wanted(int NA, int V0, int row0, int nt = kNT)
 {
-    return row0 >= kChainMinRow && V0 <= kChainMaxV && NA * kD1 + kChainGap * V0 + 64 < 65535;
+    return row0 >= kChainMinRow && V0 <= chain_max_v(nt) && NA * kD1 + kChainGap * V0 + 64 < 65535;
 }
 
 // LDS plan of one workgroup for frames of at most NA points whose K lattices (all 2-D) have at most
 // V[k] vertices and kernel 0's longest row has `row0` products.  Shared by the host (batch API: sizes
 // maximised over the frames) and k_fused itself (late-bound launches: each frame sizes its own).
-__host__ __device__ inline bool layout_core(int NA, int K, const int *V, int row0, FusedLayout *lay)
+__host__ __device__ inline bool layout_core(int NA, int K, const int *V, int row0, FusedLayout *lay, int nt = kNT,
+                                            size_t lds_limit = kLdsLimit)
 {
     constexpr int D1 = kD1;
     if (NA < 1 || NA > 4 * kNT || K < 1 || K > kMaxFusedK) return false;
     for (int k = 0; k < K; ++k)
         if (V[k] >= 65535) return false;
-    const int chain0 = chain_wanted(NA, V[0], row0);
+    const int chain0 = chain_wanted(NA, V[0], row0, nt);
     for (int all = 1; all >= 0; --all) {                  // own product buffers, else one shared buffer
         FusedLayout L{};
         size_t o = 0;
@@ -118,7 +128,7 @@ __host__ __device__ inline bool layout_core(int NA, int K, const int *V, int row
             for (int k = 0; k < K; ++k) L.prod[k] = p;
         }
         L.total = (int)o;
-        if (o <= kLdsLimit) {
+        if (o <= lds_limit) {
             *lay = L;
             return true;
         }
@@ -220,7 +230,7 @@ __device__ __forceinline__ bool chain_k(const FusedLayout &lay, int k)
 // vertex's row in ascending point order, the reference's splat order, counted from the start of the CSR
 // (row[v] + rank).  A plain kernel stores its products at exactly that position; the chain kernel re-places
 // row v at pst(row[v], v).  Fills ix.  The row tables must be in LDS and visible (barrier before).
-template <int PPT, int K, int CH>
+template <int PPT, int K, int CH, int NT = kNT>
 __device__ __forceinline__ void place_products(unsigned char *smem, const FusedLayout &lay, int N, int tid,
                                                const unsigned (&pk)[PPT][K][kD1], PointRegs<PPT, K> &pr)
 {
@@ -232,7 +242,7 @@ __device__ __forceinline__ void place_products(unsigned char *smem, const FusedL
             pr.ix[s][k][0] = (pk[s][k][0] & 0xffffu) | (pk[s][k][1] << 16);
             pr.ix[s][k][1] = pk[s][k][2] & 0xffffu;
             pr.ix[s][k][2] = 0;
-            if (tid + s * kNT < N) {
+            if (tid + s * NT < N) {
                 unsigned sl[kD1];
 #pragma unroll
                 for (int j = 0; j < kD1; ++j) {
@@ -346,7 +356,7 @@ __device__ __forceinline__ void chain_pads(unsigned char *smem, const ChainLane 
 
 // WITH_P = false (own product buffers only): the products are already in place -- mean_field writes the next
 // iteration's products point by point right behind each point's softmax.
-template <int PPT, int K, int CH, bool WITH_P = true>
+template <int PPT, int K, int CH, bool WITH_P = true, int NT = kNT>
 __device__ __forceinline__ void splat_blur(unsigned char *smem, const FusedLayout &lay, const int (&V)[K], int N, int tid,
                                            const PointRegs<PPT, K> &pr, const ChainLane &cl, Instr &ins)
 {
@@ -354,10 +364,10 @@ __device__ __forceinline__ void splat_blur(unsigned char *smem, const FusedLayou
     auto phase_P = [&](int k) {
 #pragma unroll
         for (int s = 0; s < PPT; ++s)
-            if (tid + s * kNT < N) point_products<PPT, K, CH>(smem, lay, pr, s, k);
+            if (tid + s * NT < N) point_products<PPT, K, CH>(smem, lay, pr, s, k);
         if (chain_k<CH>(lay, k)) chain_pads(smem, cl);    // (the buffer may have held another kernel's products)
     };
-    // lanes [s_lo, kNT) share the short-row kernels; the wavefronts that own the chain kernel's
+    // lanes [s_lo, NT) share the short-row kernels; the wavefronts that own the chain kernel's
     // longest rows keep out of them
     auto phase_S = [&](int k, int s_lo) {
         float *val = reinterpret_cast<float *>(smem + lay.val[k][0]);
@@ -382,7 +392,7 @@ __device__ __forceinline__ void splat_blur(unsigned char *smem, const FusedLayou
         const float2 *zero = reinterpret_cast<const float2 *>(smem + lay.zero);
         const unsigned short *row = reinterpret_cast<const unsigned short *>(smem + lay.row[k]);
         if (tid < s_lo || FL_DBG(1)) return;
-        for (int v = tid - s_lo; v < V[k]; v += kNT - s_lo) {
+        for (int v = tid - s_lo; v < V[k]; v += NT - s_lo) {
             const int t = row[v + 1];
             float a0 = 0.0f, a1 = 0.0f;
             for (int p = row[v]; p < t; p += 8) {
@@ -425,7 +435,7 @@ __device__ __forceinline__ void splat_blur(unsigned char *smem, const FusedLayou
             const float2 *src = reinterpret_cast<const float2 *>(smem + lay.val[k][j & 1]);
             float2 *dst = reinterpret_cast<float2 *>(smem + lay.val[k][(j & 1) ^ 1]);
             const unsigned *nbr = reinterpret_cast<const unsigned *>(smem + lay.nbr[k]) + j * V[k];
-            for (int v = tid; v < V[k]; v += kNT) {
+            for (int v = tid; v < V[k]; v += NT) {
                 const unsigned n = nbr[v];
                 const float2 o = src[v + 1], x = src[n & 0xffffu], y = src[n >> 16];
                 float2 r;
@@ -472,13 +482,13 @@ __device__ __forceinline__ void opaque(PointRegs<PPT, K> &pr)
 }
 
 // startInference: Q = softmax(-unary), densecrf_base.h:78-80
-template <int PPT, int K>
+template <int PPT, int K, int NT = kNT>
 __device__ __forceinline__ void start_inference(PointRegs<PPT, K> &pr, int N, int tid)
 {
 #pragma unroll
     for (int s = 0; s < PPT; ++s) {
         pr.q[s] = make_float2(0.f, 0.f);
-        if (tid + s * kNT < N) {
+        if (tid + s * NT < N) {
             pr.q[s] = softmax2(-pr.un[s].x, -pr.un[s].y, make_float2(0.f, 0.f), 1.0f);   // scale = -1 is an exact negation
         }
     }
@@ -487,7 +497,7 @@ __device__ __forceinline__ void start_inference(PointRegs<PPT, K> &pr, int N, in
 // n_iter x stepInference (densecrf_base.h:82-91): splat, blur, then slice + apply + softmax per point.
 // No barrier is needed behind X: the next P only writes the product buffers, whose readers finished
 // two barriers ago.
-template <int PPT, int K, int CH>
+template <int PPT, int K, int CH, int NT = kNT>
 __device__ __forceinline__ void mean_field(unsigned char *smem, const FusedLayout &lay, const int (&V)[K], int N, int tid,
                                            PointRegs<PPT, K> &pr, const ChainLane &cl, const float (&alpha)[K], int n_iter,
                                            float relax, Instr &ins)
@@ -513,17 +523,17 @@ __device__ __forceinline__ void mean_field(unsigned char *smem, const FusedLayou
             for (int k = 0; k < K; ++k) {
 #pragma unroll
                 for (int s = 0; s < PPT; ++s)
-                    if (tid + s * kNT < N) point_products<PPT, K, CH>(smem, lay, pr, s, k);
+                    if (tid + s * NT < N) point_products<PPT, K, CH>(smem, lay, pr, s, k);
                 if (chain_k<CH>(lay, k)) chain_pads(smem, cl);
             }
         }
         for (int it = 0; it < n_iter; ++it) {
             opaque(pr);
-            splat_blur<PPT, K, CH, false>(smem, lay, V, N, tid, pr, cl, ins);
+            splat_blur<PPT, K, CH, false, NT>(smem, lay, V, N, tid, pr, cl, ins);
             const bool more = it + 1 < n_iter;
 #pragma unroll
             for (int s = 0; s < PPT; ++s) {
-                if (tid + s * kNT < N) {
+                if (tid + s * NT < N) {
                     point_update(s);
                     if (more) {
 #pragma unroll
@@ -537,21 +547,21 @@ __device__ __forceinline__ void mean_field(unsigned char *smem, const FusedLayou
     }
     for (int it = 0; it < n_iter; ++it) {
         opaque(pr);
-        splat_blur<PPT, K, CH>(smem, lay, V, N, tid, pr, cl, ins);
+        splat_blur<PPT, K, CH, true, NT>(smem, lay, V, N, tid, pr, cl, ins);
 #pragma unroll
         for (int s = 0; s < PPT; ++s)
-            if (tid + s * kNT < N) point_update(s);
+            if (tid + s * NT < N) point_update(s);
         FL_STAMP();
     }
 }
 
 // Q and the MAP labels (densecrf3d.h:136-151: first maximum wins, ties -> label 0) of this lane's points.
-template <int PPT, int K>
+template <int PPT, int K, int NT = kNT>
 __device__ __forceinline__ void store_results(const CrfDev &c, int f, int N, int tid, const PointRegs<PPT, K> &pr, int with_map)
 {
 #pragma unroll
     for (int s = 0; s < PPT; ++s) {
-        const int i = tid + s * kNT;
+        const int i = tid + s * NT;
         if (i < N) {
             reinterpret_cast<float2 *>(c.Q)[(size_t)f * c.maxN + i] = pr.q[s];
             if (with_map) c.map[(size_t)f * c.maxN + i] = (pr.q[s].x < pr.q[s].y) ? 1 : 0;   // densecrf3d.h:145
