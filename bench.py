@@ -247,7 +247,40 @@ def single_frame_latency(pkg, pbs, n_iter, reps=240):
     b.close()
     out["hip_breakdown_us"]["kernel_k_frame_hip_events"] = float(np.median(ks[5:]))
     out["cpu_reference_kind"] = "reference" if po.have_ref() else "port"
+    out["hip_cpp_caller"] = cpp_caller_latency(pbs, reps)
     return out
+
+
+def cpp_caller_latency(pbs, reps):
+    """The same call site from C++ (tools/latency_cpp.cpp through include/lccrf_densecrf.hpp): what the tracker -- a C++
+    program -- sees, without the ctypes / numpy time of the Python figures above.  Compiled here with g++ against the
+    in-tree library; product code only.  None (with the reason) if no compiler is around."""
+    import shutil
+    import tempfile
+    import numpy as np
+    if shutil.which("g++") is None:
+        return {"error": "g++ not found"}
+    tmp = tempfile.mkdtemp(prefix="lccrf_lat_")
+    try:
+        exe, inp = os.path.join(tmp, "latency_cpp"), os.path.join(tmp, "frames.bin")
+        libdir = os.path.join(ROOT, "lc-crf-slam_amd")
+        subprocess.run(["g++", "-std=c++14", "-O2", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tools", "latency_cpp.cpp"),
+                        "-o", exe, os.path.join(libdir, "liblccrf_hip.so"), "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"],
+                       check=True, capture_output=True, timeout=300)
+        N = pbs[0]["N"]
+        with open(inp, "wb") as f:
+            f.write(np.int32(len(pbs)).tobytes() + np.int32(N).tobytes())
+            for pb in pbs:
+                fr = pb["frame"]
+                for a, dt in ((fr["obs"], np.float32), (fr["err"], np.float32), (fr["uv"], np.float32), (fr["init_label"], np.int16)):
+                    f.write(np.ascontiguousarray(a, dt).tobytes())
+        r = subprocess.run([exe, inp, str(reps)], capture_output=True, text=True, timeout=300)
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        return json.loads(line[-1]) if line else {"error": (r.stderr or r.stdout)[-300:]}
+    except Exception as e:                          # the Python figures stand on their own
+        return {"error": repr(e)[:300]}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def slam_subrecord(pkg, wl, torch, dev, name, steps=10, warmup=3, distinct=32):
@@ -488,6 +521,9 @@ def main():
                     help="N > 1: wait for each step's label gather before the next launch instead of overlapping them")
     ap.add_argument("--distinct", type=int, default=64, help="distinct synthetic frames tiled into the batch")
     ap.add_argument("--rehearse-cpu", action="store_true", help="launcher test: gloo, no GPU, no compute, no metric")
+    ap.add_argument("--lite", action="store_true",
+                    help="counter-collection runs (rocprofv3 --pmc serialises every dispatch): one event-timed launch instead of "
+                         "five, two one-launch batches instead of many -- the timed region itself is unchanged")
     args = ap.parse_args()
 
     if args.gpus < 1:
@@ -593,7 +629,7 @@ def main():
 
     # HIP-event duration of the inference launch(es), on the stream they are launched on
     kernel_ms = []
-    for _ in range(5):
+    for _ in range(1 if args.lite else 5):
         b.inference(n_iter, True, stream=stream)
         kernel_ms.append(b.last_timing()["inference_ms"])
     inf_ms = float(np.median(kernel_ms))
@@ -601,15 +637,16 @@ def main():
     # end to end per frame = PottsPotential ctors + inference, as the reference pays per frame: ONE launch per frame
     run_ms = None
     if name != "c5":
-        for _ in range(2):
+        n_run = 1 if args.lite else max(args.steps // 2, 3)
+        for _ in range(1 if args.lite else 2):
             b.run(n_iter, True, stream=stream)
         torch.cuda.synchronize()
         t0r = time.perf_counter()
-        for _ in range(max(args.steps // 2, 3)):
+        for _ in range(n_run):
             b.run(n_iter, True, stream=stream)
         b.synchronize()
-        run_ms = (time.perf_counter() - t0r) / max(args.steps // 2, 3) * 1e3
-        run_engine = b.engine()
+        run_ms = (time.perf_counter() - t0r) / n_run * 1e3
+        run_engine, run_fallback = b.engine(), b.fallback_frames()
 
     # parity gate on the timed configuration: labels vs the CPU reference path
     label_match = None
@@ -693,6 +730,7 @@ def main():
             "build_ms_per_batch": build_ms,
             "frames_per_s_end_to_end": (F * world / (run_ms * 1e-3)) if (run_ms and run_engine == 3) else F * world / ((build_ms + inf_ms) * 1e-3),
             "end_to_end": {"one_launch_ms_per_batch": run_ms, "one_launch_engine": (run_engine if run_ms else None),
+                           "fallback_frames": (run_fallback if run_ms else None),
                            "two_kernel_ms_per_batch": build_ms + inf_ms,
                            "one_launch_hbm_bytes_per_frame": (pmc_traffic(latest_profile("fused_c2"), "k_frame") / F) if ((name, F) == ("c2", DEFAULT_FRAMES) and pmc_traffic(latest_profile("fused_c2"), "k_frame")) else None,
                            "note": "per frame: both PottsPotential3D ctors (lattice + norm) + inference(n, true); one_launch = "

@@ -812,14 +812,11 @@ int lccrf_create(lccrf_handle *out, int device_id, int n_points, int n_labels)
     static const bool no_late = getenv("LCCRF_NO_LATE") != nullptr;   // debugging aid: always size the fused kernel on the host
     h->eng.late_ok = !no_late;
     h->label_stage_busy = false;    // a parked engine's stream is idle (recycle() synchronised it)
-    h->eng.sync_views();
+    // the kernels read the point count where the host wrote it (pinned, device-visible): no upload command on a path
+    // whose every DMA packet costs microseconds of stream time (a parked engine's stream is idle, nothing reads the old value)
     *h->stage_n = n_points;
-    hipError_t e = hipMemcpyAsync(h->eng.npoints_own, h->stage_n, sizeof(int), hipMemcpyHostToDevice, h->eng.stream);
-    if (e != hipSuccess) {
-        h->eng.destroy();
-        delete h;
-        return fail(LCCRF_E_HIP, "hipMemcpyAsync n_points: %s", hipGetErrorString(e));
-    }
+    h->eng.crf.n_points = h->stage_n;
+    h->eng.sync_views();
     *out = h;
     return LCCRF_OK;
 }

@@ -142,13 +142,17 @@ __global__ void __launch_bounds__(NT, 4) k_frame(CrfDev c, FrameArgs a)
     unsigned short *ido = reinterpret_cast<unsigned short *>(smem + ido_off);    // slot -> vertex id
 
     // ---- inputs: every global load of the launch is issued here --------------------------------
+    // (3-4 points per lane: a kernel's features are fetched when its build starts instead -- holding both kernels'
+    //  features across the first build is what pushed those shapes into scratch)
+    constexpr bool kFeatUpFront = PPT <= 2;
     PointRegs<PPT, K> pr;
     float2 ft[PPT][K];
 #pragma unroll
     for (int s = 0; s < PPT; ++s) {
         const int ic = min(tid + s * NT, N - 1);
 #pragma unroll
-        for (int k = 0; k < K; ++k) ft[s][k] = reinterpret_cast<const float2 *>(a.feat[k])[(size_t)f * a.maxN + ic];
+        for (int k = 0; k < K; ++k)
+            if (kFeatUpFront || k == 0) ft[s][k] = reinterpret_cast<const float2 *>(a.feat[k])[(size_t)f * a.maxN + ic];
         if (a.label) {                                    // densecrf3d.h:116-129 with L = 2
             const int t = a.label[(size_t)f * a.maxN + ic];
             const bool known = t >= 0 && t < 2;
@@ -171,6 +175,11 @@ __global__ void __launch_bounds__(NT, 4) k_frame(CrfDev c, FrameArgs a)
     for (int k = 0; k < K; ++k) {
         // ---- A: point records (elevate, round, rank, barycentric) and the keys of their three corners ----
         unsigned key[PPT][D1];
+        if (!kFeatUpFront && k > 0) {
+#pragma unroll
+            for (int s = 0; s < PPT; ++s)
+                ft[s][k] = reinterpret_cast<const float2 *>(a.feat[k])[(size_t)f * a.maxN + min(tid + s * NT, N - 1)];
+        }
 #pragma unroll
         for (int s = 0; s < PPT; ++s) {
             const int i = tid + s * NT;
@@ -401,51 +410,22 @@ __global__ void __launch_bounds__(NT, 4) k_frame(CrfDev c, FrameArgs a)
         FL_PSTAMP();
 
         // ---- F/G: the place of every entry in its row = number of smaller entries of the same vertex ----
-        const unsigned short *row = reinterpret_cast<const unsigned short *>(smem + lay.row[k]);
-        unsigned lc[PPT][D1], rw[PPT][D1];
+        if constexpr (PPT >= 3) {
+            // 3-4 points per lane: one point slot at a time, nothing kept across slots but vid / arr (the all-slots-at-once
+            // form below keeps 27 more registers live and spilled them: 56-208 bytes of scratch per lane)
+            const unsigned short *row = reinterpret_cast<const unsigned short *>(smem + lay.row[k]);
+            if (!bitmap) {
 #pragma unroll
-        for (int s = 0; s < PPT; ++s)
+                for (int s = 0; s < PPT; ++s) {
+                    const int i = tid + s * NT;
+                    if (i < N) {
 #pragma unroll
-            for (int j = 0; j < D1; ++j) {
-                lc[s][j] = cnt[vid[s][j]];
-                rw[s][j] = row[vid[s][j]];
-            }
-        if (!bitmap) {
-#pragma unroll
-            for (int s = 0; s < PPT; ++s) {
-                const int i = tid + s * NT;
-                if (i < N) {
-#pragma unroll
-                    for (int j = 0; j < D1; ++j) list[(lc[s][j] & 0xffffu) + arr[s][j]] = (unsigned short)(i * D1 + j);
+                        for (int j = 0; j < D1; ++j) list[(cnt[vid[s][j]] & 0xffffu) + arr[s][j]] = (unsigned short)(i * D1 + j);
+                    }
                 }
+                __syncthreads();
             }
-            __syncthreads();
-        }
-        FL_PSTAMP();
-        unsigned rank[PPT][D1];
-        if (bitmap) {
-#pragma unroll
-            for (int s = 0; s < PPT; ++s) {               // (one point at a time: three 16-byte reads in flight, 12 registers)
-                const int i = min(tid + s * NT, N - 1);
-                uint4 bw[D1];
-                unsigned pv[D1];
-#pragma unroll
-                for (int j = 0; j < D1; ++j) {
-                    bw[j] = *reinterpret_cast<const uint4 *>(bm + vid[s][j] * W + ((i >> 5) & ~3));   // the 4-word group of my word
-                    pv[j] = pre[vid[s][j] * (W >> 2) + (i >> 7)];
-                }
-                const int wq = (i >> 5) & 3;
-                const unsigned low = (1u << (i & 31)) - 1u;
-#pragma unroll
-                for (int j = 0; j < D1; ++j) {
-                    const uint4 b = bw[j];
-                    rank[s][j] = pv[j] + (wq > 0 ? __popc(b.x) : 0) + (wq > 1 ? __popc(b.y) : 0) + (wq > 2 ? __popc(b.z) : 0) +
-                                 __popc((wq == 0 ? b.x : wq == 1 ? b.y : wq == 2 ? b.z : b.w) & low);
-                }
-            }
-        } else {
-            // eight 16-bit entries against e at once: entries and e are < 0x8000, so (x | 0x8000) - e keeps bit 15 of a
-            // half exactly when that half is >= e, and no half ever borrows from its neighbour
+            FL_PSTAMP();
             auto below = [](const uint4 &x, unsigned e) {
                 const unsigned e2 = e | (e << 16), hi = 0x80008000u;
                 return 8u - (unsigned)(__popc(((x.x | hi) - e2) & hi) + __popc(((x.y | hi) - e2) & hi) + __popc(((x.z | hi) - e2) & hi) +
@@ -453,28 +433,104 @@ __global__ void __launch_bounds__(NT, 4) k_frame(CrfDev c, FrameArgs a)
             };
 #pragma unroll
             for (int s = 0; s < PPT; ++s) {
-                const int i = tid + s * NT;
-                uint4 first[D1];
-#pragma unroll
-                for (int j = 0; j < D1; ++j) first[j] = *reinterpret_cast<const uint4 *>(list + (lc[s][j] & 0xffffu));
+                const int i = tid + s * NT, ic = min(i, N - 1);
+                const bool real = i < N;
 #pragma unroll
                 for (int j = 0; j < D1; ++j) {
-                    const unsigned e = (unsigned)(i * D1 + j);
-                    unsigned r = below(first[j], e);
-                    const uint4 *lp = reinterpret_cast<const uint4 *>(list + (lc[s][j] & 0xffffu));
-                    const int n8 = (int)(((lc[s][j] >> 16) + 7u) >> 3);
-                    for (int u = 1; u < n8; ++u) r += below(lp[u], e);    // rows of more than 8 entries
-                    rank[s][j] = r;
+                    const unsigned v = vid[s][j];
+                    unsigned r;
+                    if (bitmap) {
+                        const uint4 bq = *reinterpret_cast<const uint4 *>(bm + v * W + ((ic >> 5) & ~3));
+                        const int wq = (ic >> 5) & 3;
+                        const unsigned low = (1u << (ic & 31)) - 1u;
+                        r = pre[v * (W >> 2) + (ic >> 7)] + (wq > 0 ? __popc(bq.x) : 0) + (wq > 1 ? __popc(bq.y) : 0) + (wq > 2 ? __popc(bq.z) : 0) +
+                            __popc((wq == 0 ? bq.x : wq == 1 ? bq.y : wq == 2 ? bq.z : bq.w) & low);
+                    } else {
+                        const unsigned lcv = cnt[v], e = (unsigned)(i * D1 + j);
+                        const uint4 *lp = reinterpret_cast<const uint4 *>(list + (lcv & 0xffffu));
+                        r = below(lp[0], e);
+                        const int n8 = (int)(((lcv >> 16) + 7u) >> 3);
+                        for (int u = 1; u < n8; ++u) r += below(lp[u], e);
+                    }
+                    pk[s][k][j] = (v + 1u) | (((unsigned)row[v] + (real ? r : 0u)) << 16);
                 }
             }
-        }
-#pragma unroll
-        for (int s = 0; s < PPT; ++s)
-#pragma unroll
-            for (int j = 0; j < D1; ++j) {
-                const bool real = tid + s * NT < N;
-                pk[s][k][j] = (vid[s][j] + 1u) | ((rw[s][j] + (real ? rank[s][j] : 0u)) << 16);
+        } else {
+            const unsigned short *row = reinterpret_cast<const unsigned short *>(smem + lay.row[k]);
+            unsigned lc[PPT][D1], rw[PPT][D1];
+    #pragma unroll
+            for (int s = 0; s < PPT; ++s)
+    #pragma unroll
+                for (int j = 0; j < D1; ++j) {
+                    lc[s][j] = cnt[vid[s][j]];
+                    rw[s][j] = row[vid[s][j]];
+                }
+            if (!bitmap) {
+    #pragma unroll
+                for (int s = 0; s < PPT; ++s) {
+                    const int i = tid + s * NT;
+                    if (i < N) {
+    #pragma unroll
+                        for (int j = 0; j < D1; ++j) list[(lc[s][j] & 0xffffu) + arr[s][j]] = (unsigned short)(i * D1 + j);
+                    }
+                }
+                __syncthreads();
             }
+            FL_PSTAMP();
+            unsigned rank[PPT][D1];
+            if (bitmap) {
+    #pragma unroll
+                for (int s = 0; s < PPT; ++s) {               // (one point at a time: three 16-byte reads in flight, 12 registers)
+                    const int i = min(tid + s * NT, N - 1);
+                    uint4 bw[D1];
+                    unsigned pv[D1];
+    #pragma unroll
+                    for (int j = 0; j < D1; ++j) {
+                        bw[j] = *reinterpret_cast<const uint4 *>(bm + vid[s][j] * W + ((i >> 5) & ~3));   // the 4-word group of my word
+                        pv[j] = pre[vid[s][j] * (W >> 2) + (i >> 7)];
+                    }
+                    const int wq = (i >> 5) & 3;
+                    const unsigned low = (1u << (i & 31)) - 1u;
+    #pragma unroll
+                    for (int j = 0; j < D1; ++j) {
+                        const uint4 b = bw[j];
+                        rank[s][j] = pv[j] + (wq > 0 ? __popc(b.x) : 0) + (wq > 1 ? __popc(b.y) : 0) + (wq > 2 ? __popc(b.z) : 0) +
+                                     __popc((wq == 0 ? b.x : wq == 1 ? b.y : wq == 2 ? b.z : b.w) & low);
+                    }
+                }
+            } else {
+                // eight 16-bit entries against e at once: entries and e are < 0x8000, so (x | 0x8000) - e keeps bit 15 of a
+                // half exactly when that half is >= e, and no half ever borrows from its neighbour
+                auto below = [](const uint4 &x, unsigned e) {
+                    const unsigned e2 = e | (e << 16), hi = 0x80008000u;
+                    return 8u - (unsigned)(__popc(((x.x | hi) - e2) & hi) + __popc(((x.y | hi) - e2) & hi) + __popc(((x.z | hi) - e2) & hi) +
+                                           __popc(((x.w | hi) - e2) & hi));
+                };
+    #pragma unroll
+                for (int s = 0; s < PPT; ++s) {
+                    const int i = tid + s * NT;
+                    uint4 first[D1];
+    #pragma unroll
+                    for (int j = 0; j < D1; ++j) first[j] = *reinterpret_cast<const uint4 *>(list + (lc[s][j] & 0xffffu));
+    #pragma unroll
+                    for (int j = 0; j < D1; ++j) {
+                        const unsigned e = (unsigned)(i * D1 + j);
+                        unsigned r = below(first[j], e);
+                        const uint4 *lp = reinterpret_cast<const uint4 *>(list + (lc[s][j] & 0xffffu));
+                        const int n8 = (int)(((lc[s][j] >> 16) + 7u) >> 3);
+                        for (int u = 1; u < n8; ++u) r += below(lp[u], e);    // rows of more than 8 entries
+                        rank[s][j] = r;
+                    }
+                }
+            }
+    #pragma unroll
+            for (int s = 0; s < PPT; ++s)
+    #pragma unroll
+                for (int j = 0; j < D1; ++j) {
+                    const bool real = tid + s * NT < N;
+                    pk[s][k][j] = (vid[s][j] + 1u) | ((rw[s][j] + (real ? rank[s][j] : 0u)) << 16);
+                }
+        }
         if (k == 0) row0max = hdr->rowmax;
         FL_PSTAMP();
         __syncthreads();                                  // the next kernel's build (or the loop's product buffers) reuses the scratch

@@ -12,7 +12,7 @@ mkdir -p $OUT/stats $OUT/fetch $OUT/write
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o run -- \
     python3 bench.py "$@" --no-cpu-baseline --no-extras > $OUT/bench.json 2> $OUT/stats/err.log
 timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -o run -- \
-    python3 bench.py "$@" --steps 5 --warmup 1 --no-cpu-baseline --no-check --no-extras > /dev/null 2> $OUT/fetch/err.log
+    python3 bench.py "$@" --steps 2 --warmup 1 --lite --no-cpu-baseline --no-check --no-extras > /dev/null 2> $OUT/fetch/err.log
 timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -o run -- \
-    python3 bench.py "$@" --steps 5 --warmup 1 --no-cpu-baseline --no-check --no-extras > /dev/null 2> $OUT/write/err.log
+    python3 bench.py "$@" --steps 2 --warmup 1 --lite --no-cpu-baseline --no-check --no-extras > /dev/null 2> $OUT/write/err.log
 find $OUT -type f | head -40

@@ -50,18 +50,18 @@ def test_fused_slam_variants_do_not_spill():
 
 @pytest.mark.skipif(shutil.which(HIPCC) is None, reason="hipcc not installed")
 def test_frame_kernel_slam_variants_do_not_spill():
-    """The one-launch-per-frame kernel: no scratch for 1-2 points per lane (C1, C2, C3); the 3-points-per-lane variant
-    (C4) may spill a few registers in its build phases but stays small."""
+    """The one-launch-per-frame kernel: no scratch up to 3 points per lane (C1-C4; VERDICT r2 item 7: the 3-points-per-lane
+    shape used to spill 56 bytes per lane in its build phases), nor for 4 points per lane with one kernel."""
     use = resource_usage("frame_engine.hip")
     frame = {k: v for k, v in use.items() if "k_frame" in k}
     assert len(frame) == 12                                   # 1024 lanes: PPT 1..4 x K 1..2; 512 lanes: PPT 1..2 x K 1..2
     for name, r in frame.items():
         nt, ppt, K = (int(x) for x in re.search(r"k_frameILi(\d+)ELi(\d)ELi(\d)E", name).groups())
         assert r["VGPRs"] + r.get("AGPRs", 0) <= 128, name
-        if ppt <= 2:
+        if ppt <= 3 or K == 1:
             assert r["ScratchSize [bytes/lane]"] == 0 and r["VGPRs Spill"] == 0, (name, r)
-        if ppt == 3:
-            assert r["ScratchSize [bytes/lane]"] <= 64, (name, r)
+        else:
+            assert r["ScratchSize [bytes/lane]"] <= 128, (name, r)      # 4 points per lane, two kernels (3073-4096 points): 108 B
 
 
 @pytest.mark.skipif(shutil.which(HIPCC) is None, reason="hipcc not installed")
