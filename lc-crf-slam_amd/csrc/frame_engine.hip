@@ -147,20 +147,24 @@ __global__ void __launch_bounds__(NT, 4) k_frame(CrfDev c, FrameArgs a)
     constexpr bool kFeatUpFront = PPT <= 2;
     PointRegs<PPT, K> pr;
     float2 ft[PPT][K];
+    // Kernel 0's features first: its build starts when THEY have arrived (loads return in order; for a single frame
+    // through the object API they come from pinned host memory, ~7 us for all of a 2000-point frame's 36 KB), with the
+    // other kernels' features and the labels / unaries still on their way.
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        if (kFeatUpFront || k == 0) {
+#pragma unroll
+            for (int s = 0; s < PPT; ++s)
+                ft[s][k] = reinterpret_cast<const float2 *>(a.feat[k])[(size_t)f * a.maxN + min(tid + s * NT, N - 1)];
+        }
+    }
+    int lab_raw[PPT];
 #pragma unroll
     for (int s = 0; s < PPT; ++s) {
         const int ic = min(tid + s * NT, N - 1);
-#pragma unroll
-        for (int k = 0; k < K; ++k)
-            if (kFeatUpFront || k == 0) ft[s][k] = reinterpret_cast<const float2 *>(a.feat[k])[(size_t)f * a.maxN + ic];
-        if (a.label) {                                    // densecrf3d.h:116-129 with L = 2
-            const int t = a.label[(size_t)f * a.maxN + ic];
-            const bool known = t >= 0 && t < 2;
-            pr.un[s].x = !known ? a.tbl[0] : (t == 0 ? a.tbl[3] : a.tbl[1 + t]);
-            pr.un[s].y = !known ? a.tbl[0] : (t == 1 ? a.tbl[4] : a.tbl[1 + t]);
-        } else {
-            pr.un[s] = reinterpret_cast<const float2 *>(c.unary)[(size_t)f * c.maxN + ic];
-        }
+        lab_raw[s] = 0;
+        if (a.label) lab_raw[s] = a.label[(size_t)f * a.maxN + ic];
+        else pr.un[s] = reinterpret_cast<const float2 *>(c.unary)[(size_t)f * c.maxN + ic];
     }
     if (tid < 16) reinterpret_cast<float *>(smem + 128)[tid] = 0.0f;
     if (tid == 0) { hdr->fail = 0; hdr->rowmax = 0; }
@@ -588,6 +592,15 @@ __global__ void __launch_bounds__(NT, 4) k_frame(CrfDev c, FrameArgs a)
     }
     FL_STAMP();                                           // (no barrier: the next writer of val[.][1] is two barriers away)
 
+    if (a.label) {                                        // densecrf3d.h:116-129 with L = 2 (the labels arrived long ago)
+#pragma unroll
+        for (int s = 0; s < PPT; ++s) {
+            const int t = lab_raw[s];
+            const bool known = t >= 0 && t < 2;
+            pr.un[s].x = !known ? a.tbl[0] : (t == 0 ? a.tbl[3] : a.tbl[1 + t]);
+            pr.un[s].y = !known ? a.tbl[0] : (t == 1 ? a.tbl[4] : a.tbl[1 + t]);
+        }
+    }
     start_inference<PPT, K, NT>(pr, N, tid);
     float alpha[K];
 #pragma unroll

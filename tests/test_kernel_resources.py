@@ -61,7 +61,7 @@ def test_frame_kernel_slam_variants_do_not_spill():
         if ppt <= 3 or K == 1:
             assert r["ScratchSize [bytes/lane]"] == 0 and r["VGPRs Spill"] == 0, (name, r)
         else:
-            assert r["ScratchSize [bytes/lane]"] <= 128, (name, r)      # 4 points per lane, two kernels (3073-4096 points): 108 B
+            assert r["ScratchSize [bytes/lane]"] <= 160, (name, r)      # 4 points per lane, two kernels (3073-4096 points): 132 B
 
 
 @pytest.mark.skipif(shutil.which(HIPCC) is None, reason="hipcc not installed")
