@@ -615,6 +615,8 @@ def test_locality_mode_with_labels_and_device_inputs(po, wl):
     for rep in range(2):
         b.inference(4, True)
     Q, M, Vs = b.probability(), b.map(), b.lattice_sizes(0)
+    b.run(4, True)                                         # lccrf_batch_run on frames beyond the one-launch kernel: rebuild + infer
+    assert b.engine() == 1 and cc.same_bits(b.probability(), Q) and np.array_equal(b.map(), M)
     for i, pb in enumerate(frames):
         n = int(npt[i])
         o = cc.setup(po.OracleCRF, dict(pb, N=n, label=pb["label"][:n], kernels=[(pb["kernels"][0][0][:n], np.float32(10.0))]))
