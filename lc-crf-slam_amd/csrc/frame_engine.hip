@@ -256,9 +256,13 @@ __global__ void __launch_bounds__(NT, 4) k_frame(CrfDev c, FrameArgs a)
         // long rows (few vertices, many entries each): rank by bitmap, if the bitmap fits
         const bool bitmap = (long)E >= 16L * Vk && vs + 5 * Vk * W + 64 <= ido_off;
         const int bm_off = vs, pre_off = bm_off + Vk * W * 4;             // pre: entries before every 4-word group (u16)
-        const int list_off = vs;                          // short mode: u16 entry lists, rows padded to 8
+        // short mode: u16 entry lists, rows padded to 8.  They are written after phase D, when the hash table (keys + slot ids,
+        // at the end of LDS) is dead: if they fit there they take its place instead of more scratch -- what lets a
+        // 1000-point frame build inside half the CU's LDS
         const int list_cap = (E + 7 * Vk + 8) & ~7;
-        const int vs_end = bitmap ? pre_off + Vk * W / 2 : list_off + list_cap * 2;
+        const bool list_in_hash = !bitmap && list_cap * 2 <= a.lds_total - ido_off;
+        const int list_off = list_in_hash ? ido_off : vs;
+        const int vs_end = bitmap ? pre_off + Vk * W / 2 : (list_in_hash ? vs : list_off + list_cap * 2);
         if (vs_end > ido_off || Vk >= 32767 || E + 7 * Vk >= 65535 || hdr->fail) {   // does not fit: leave the frame to the fallback path
             if (tid == 0) {
                 if (a.status) *a.status = 1;
@@ -288,7 +292,7 @@ __global__ void __launch_bounds__(NT, 4) k_frame(CrfDev c, FrameArgs a)
         if (bitmap) {
             uint4 *b4 = reinterpret_cast<uint4 *>(bm);
             for (int u = tid; u < Vk * W / 4; u += NT) b4[u] = make_uint4(0u, 0u, 0u, 0u);
-        } else {
+        } else if (!list_in_hash) {
             uint4 *l4 = reinterpret_cast<uint4 *>(list);   // pads compare greater than every entry (entries are < 0x7fff)
             for (int u = tid; u < list_cap / 8; u += NT) l4[u] = make_uint4(0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu);
         }
@@ -346,6 +350,10 @@ __global__ void __launch_bounds__(NT, 4) k_frame(CrfDev c, FrameArgs a)
         FL_PSTAMP();
         __syncthreads();
         FL_PSTAMP();
+        if (list_in_hash) {                               // the hash table is dead now (the scans of phase E separate this from F's writes)
+            uint4 *l4 = reinterpret_cast<uint4 *>(list);
+            for (int u = tid; u < list_cap / 8; u += NT) l4[u] = make_uint4(0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu, 0x7fff7fffu);
+        }
 
         // ---- E: row lengths -> row starts (and, short mode, the start of every padded entry list) -------
         if (bitmap) {
@@ -675,17 +683,22 @@ bool launch_frame(const CrfDev &c, const KernelDev *kds, int n_iter, int with_ma
     // Small frames: 512 lanes and half the CU's LDS per frame, so that two frames share a CU.  A frame whose lattices
     // do not fit that plan (or whose long rows need more chain lanes than four wavefront pairs have) flags itself
     // and is re-run like any other frame that does not fit.
-    // The lattice sizes are not known before the kernel has built them: the small shape is chosen when a frame of NA
-    // points with lattices of the usual SLAM proportions (an appearance kernel at the chain limit, a smoothness kernel
-    // of NA + 400 vertices: 734 at 400 points, 927 at 650, 1071 at 1000 on 640x480 images) fits half the LDS -- NA up to
-    // ~650.  Sparser frames flag themselves.
+    // The lattice sizes are not known before the kernel has built them: the small shape is chosen when a frame of NA points
+    // with lattices of the usual SLAM proportions fits half the LDS in both phases -- an appearance kernel of ~112
+    // vertices, a smoothness kernel of min(NA + 350, 1150) (734 vertices at 400 points, 985 at 700, 1071 at 1000 on
+    // 640x480 images with an 18-pixel kernel) -- i.e. up to 1024 points.  Frames with larger lattices flag themselves and
+    // are re-run; an engine that sees more than 1/8 of a batch flagged stops asking for this shape (allow_small).
     static const bool no_small = getenv("LCCRF_NO_SMALL_WG") != nullptr;   // A/B switch: same results either way
     bool small = allow_small && !no_small && NA <= 2 * kNTSmall && c.F >= kSmallMinFrames;
     if (small) {
-        int vest[kMaxFusedK];
-        for (int k = 0; k < c.K; ++k) vest[k] = (c.K > 1 && k == 0) ? chain_max_v(kNTSmall) : std::min(3 * NA, NA + 400);
+        int vest[kMaxFusedK], tables = 0;
+        for (int k = 0; k < c.K; ++k) {
+            vest[k] = (c.K > 1 && k == 0) ? 112 : std::min(std::min(3 * NA, NA + 350), 1150);
+            tables += 2 * (vest[k] + 1) * 8 + kD1 * vest[k] * 4 + (vest[k] + 2) * 2 + 64;
+        }
         FusedLayout est;
-        small = layout_core(NA, c.K, vest, 1 << 20, &est, kNTSmall, kLdsHalf - (size_t)frame_hcap(NA) * 6 / 4);
+        const int build_bytes = kHdr + tables + 8 * vest[c.K - 1] + 6 * frame_hcap(NA) + 64;   // tables + vertex keys + counters + hash table
+        small = layout_core(NA, c.K, vest, 1 << 20, &est, kNTSmall, kLdsHalf) && build_bytes <= (int)kLdsHalf;
     }
 #define FRAME_CASE(NT, P)                                      \
     case P:                                                    \

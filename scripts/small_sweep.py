@@ -2,7 +2,7 @@ import importlib,sys
 sys.path.insert(0,".")
 import numpy as np
 pkg=importlib.import_module("lc-crf-slam_amd"); wl=importlib.import_module("lc-crf-slam_amd.workloads")
-for N in (100,300,500,600,640,660,680,700,720,1000):
+for N in (100,500,640,700,800,900,1000,1024,1100):
     F=256
     pbs=[wl.slam_problem(N, seed=10+i) for i in range(16)]
     feats=[np.stack([pbs[f%16]["kernels"][k][0] for f in range(F)]) for k in range(2)]

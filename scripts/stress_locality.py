@@ -98,7 +98,7 @@ def large_case(rng):
 
 def small_case(rng):
     F = int(rng.integers(256, 400))
-    maxN = int(rng.integers(40, 650))
+    maxN = int(rng.integers(40, 1025))
     base = [wl.slam_problem(int(rng.integers(0, maxN + 1)), seed=int(rng.integers(1, 1 << 30))) for _ in range(6)]
     base[0] = wl.slam_problem(maxN, seed=int(rng.integers(1, 1 << 30)))
     sys.path.insert(0, os.path.join(ROOT, "tests"))

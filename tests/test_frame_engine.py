@@ -191,16 +191,16 @@ def test_one_outlier_frame_costs_one_frame(po, wl):
 
 
 def test_small_frames_share_a_cu_and_give_the_same_bits(po, wl):
-    """Frames of up to ~650 points run as 512-lane workgroups in half the CU's LDS when a batch has at least 256 frames (two
+    """Frames of up to 1024 points run as 512-lane workgroups in half the CU's LDS when a batch has at least 256 frames (two
     frames per CU: fused_loop.h kNTSmall) -- in the one-launch kernel and in the inference kernel on built lattices.  Ragged
     sizes around the 512-lane boundary, an empty frame, one sparse frame that does not fit the half-LDS plan (flagged and
     re-run alone); every frame against the oracle, and against the same frames in a batch too small for that shape."""
-    sizes = [640, 0, 1, 5, 511, 512, 513, 333, 64, 600, 640, 129]
+    sizes = [1024, 0, 1, 5, 511, 512, 513, 333, 64, 1000, 1023, 129]
     base = [wl.slam_problem(n, seed=2300 + i) for i, n in enumerate(sizes)]
-    odd = _shaped_problem(wl, 600, "sparse", seed=5)
+    odd = _shaped_problem(wl, 900, "sparse", seed=5)
     F = 300
     pbs = [odd if f == 77 else base[f % len(base)] for f in range(F)]
-    b = _batch_of(pbs, maxN=640)
+    b = _batch_of(pbs, maxN=1024)
     b.run(5, True)
     q1, m1 = b.probability(), b.map()
     assert b.engine() == 3 and b.fallback_frames() == 1
@@ -223,7 +223,7 @@ def test_small_frames_share_a_cu_and_give_the_same_bits(po, wl):
         assert cc.same_bits(q2[f, :n], q) and np.array_equal(m2[f, :n], m), f
         assert [int(v1[k][f]) for k in range(2)] == V, f
     # without the outlier the built lattices fit the half-LDS plan: the inference kernel takes the 512-lane shape too
-    b = _batch_of([base[f % len(base)] for f in range(F)], maxN=640)
+    b = _batch_of([base[f % len(base)] for f in range(F)], maxN=1024)
     b.build(); b.inference(5, True)
     assert b.engine() == 2
     q3 = b.probability()
@@ -231,7 +231,7 @@ def test_small_frames_share_a_cu_and_give_the_same_bits(po, wl):
         n = base[f % len(base)]["N"]
         assert cc.same_bits(q3[f, :n], refs[f % len(base)][0]), f
     b.close()
-    small = _batch_of(base, maxN=640)                      # 12 frames: the 1024-lane shape
+    small = _batch_of(base, maxN=1024)                      # 12 frames: the 1024-lane shape
     small.run(5, True)
     for f in range(len(base)):
         assert cc.same_bits(small.probability()[f, :sizes[f]], refs[f][0])
