@@ -54,4 +54,4 @@ def po():
 @pytest.fixture(scope="session")
 def golden():
     return {n: np.load(os.path.join(GOLDEN, n + ".npz"))
-            for n in ("slam", "generic", "bilateral", "example_im1")}
+            for n in ("slam", "generic", "bilateral", "example_im1", "large")}

@@ -595,6 +595,34 @@ def test_large_ragged_batch_matches_oracle(po, wl, d_list, L):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name", ["c5", "gen"])
+def test_locality_mode_on_reference_vectors(golden, name):
+    """Locality mode against vectors generated by the reference build itself (tests/golden/large.npz): a frame alone,
+    and eight copies (XCD-aware grids), must reproduce the reference's V, norm, Q and labels bit for bit although the
+    points are processed in an internal order."""
+    from test_oracle_golden import _large_case
+    z = golden["large"]
+    pb, n_iter, relax = _large_case(z, name)
+    N, L = pb["N"], pb["L"]
+    f, w = pb["kernels"][0]
+    for F in (1, 8):
+        b = pkg.BatchCRF(F, N, L, [f.shape[1]], [float(w)])
+        feats = [np.repeat(f[None], F, 0)]
+        if "unary" in pb:
+            b.set_inputs_host([N] * F, feats, unary=np.repeat(pb["unary"][None], F, 0))
+        else:
+            b.set_inputs_host([N] * F, feats, label=np.repeat(pb["label"][None], F, 0), conf=pb["conf"])
+        b.build()
+        b.inference(n_iter, True, relax=relax)
+        Q, M, V, nm = b.probability(), b.map(), b.lattice_sizes(0), b.norm(0)
+        assert b.engine() == 1
+        for g in range(F):
+            assert int(V[g]) == int(z[name + "_V"]) and cc.same_bits(nm[g], z[name + "_norm"]), (F, g)
+            assert cc.same_bits(Q[g], z[name + "_Q"]) and np.array_equal(M[g], z[name + "_map"]), (F, g)
+        b.close()
+
+
+@pytest.mark.gpu
 def test_locality_mode_with_labels_and_device_inputs(po, wl):
     """Locality mode end to end the way bench.py drives C5: device-bound inputs, unaries from labels (derived in the
     internal order), 8 frames (XCD-aware grids), two builds, against the oracle -- and one adversarial frame whose
