@@ -170,6 +170,8 @@ struct Engine {
     int fallback_frames = 0;           // frames the last one-launch run had to re-run (report only)
     bool frame_small_ok = true;        // small frames may run as 512-lane workgroups (two per CU); turned off for this engine when
     bool frame_small_used = false;     //   more than 1/8 of a batch's frames did not fit that plan
+    unsigned *dual_area = nullptr;     // object API (one frame at a time): hand-off area of the two-workgroup form of the frame kernel
+    unsigned dual_epoch = 0;
     int late_iter = 0, late_map = 0;
     float late_relax = 1.0f;
     bool timed_build = false, timed_inf = false;
@@ -527,8 +529,17 @@ struct Engine {
     {
         *late_status = 0;
         const bool from_label = unary_deferred && L == 2;
+        unsigned *dual = nullptr;
+        if (late_ok && F == 1 && crf.K == 2) {             // the tracker's case: one frame, 255 idle CUs -- one workgroup per lattice build
+            if (!dual_area) {
+                int rc = mem.alloc(reinterpret_cast<char **>(&dual_area), frame_dual_bytes(1));
+                if (rc) return rc;
+            }
+            dual = dual_area;
+            if (++dual_epoch == 0) dual_epoch = 1;
+        }
         frame_small_used = launch_frame(crf, kdevs.data(), n_iter, with_map, relax, late_status, frame_status,
-                                        from_label ? deferred_label : nullptr, deferred_tbl.v, stream, frame_small_ok);
+                                        from_label ? deferred_label : nullptr, deferred_tbl.v, stream, frame_small_ok, dual, dual_epoch);
         HIP_TRY(hipGetLastError());
         late_pending = true;
         late_iter = n_iter;

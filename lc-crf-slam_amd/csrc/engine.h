@@ -133,8 +133,12 @@ bool frame_supported(const CrfDev &c, const KernelDev *kds);
 // exactly those frames and the caller runs them -- and only them -- on the two-kernel path.
 // allow_small: frames of up to 1024 points may run as 512-lane workgroups in half the CU's LDS (two frames per CU);
 // returns whether that shape was launched (a caller that sees many such frames flagged turns it off).
+// dual (device memory of frame_dual_bytes(F), zeroed once) + a launch-unique dual_epoch != 0: two-kernel frames are given
+// two workgroups each -- one per lattice build (single frames: the other 255 CUs are idle anyway).
 bool launch_frame(const CrfDev &c, const KernelDev *kds, int n_iter, int with_map, float relax, int *status, int *frame_status,
-                  const int16_t *label, const float *tbl5, hipStream_t s, bool allow_small = true);
+                  const int16_t *label, const float *tbl5, hipStream_t s, bool allow_small = true, unsigned *dual = nullptr,
+                  unsigned dual_epoch = 0);
+size_t frame_dual_bytes(int frames);
 // rows of `bytes` bytes each between a frame-strided array and a compact one: dst[i] = src[list[i]] (gather = 1) or
 // dst[list[i]] = src[i] (gather = 0); strides in bytes, everything 4-byte aligned
 void launch_copy_frames(void *dst, size_t dst_stride, const void *src, size_t src_stride, const int *list, int n_list,

@@ -60,6 +60,8 @@ struct FrameArgs {
     int *V_out[kMaxFusedK];               // [F] vertices per kernel (reference M_), or null
     int *status;                          // pinned host word: set to 1 when a frame does not fit this kernel's LDS plan
     int *frame_status;                    // device [F] or null: 1 for exactly the frames that did not fit (they alone are re-run), else 0
+    unsigned *dual;                       // DUAL launches: [F][kDualWords] hand-off area between a frame's two workgroups, else null
+    unsigned dual_epoch;                  //   value the helper publishes in word 0 when its tables are complete (changes every launch)
     long long *timing;                    // instrumented builds only
     int timing_block, timing_lane;
 };
@@ -68,7 +70,21 @@ struct Hdr {                              // lives at smem + 192
     int wave_sum[16];
     int fail;
     int rowmax;
+    int dual_ok, dual_V;
 };
+
+// DUAL: a single frame (the live tracker's case: one CU busy, 255 idle) is given TWO workgroups -- workgroup 0 builds
+// kernel 0's lattice and runs everything else, workgroup 1 (on another CU) builds kernel 1's lattice meanwhile and hands
+// its tables (neighbour table, row starts) and per-point records (vertex | row place words, barycentric weights) over
+// through this area: 29k of the frame's 157k cycles leave the critical path for ~10k of hand-off.
+constexpr int kDualVcap = 8192;                           // vertices of kernel 1 the area can carry (more: the frame falls back)
+constexpr int kDualHdr = 16, kDualNbr = kDualHdr, kDualRow = kDualNbr + kD1 * kDualVcap, kDualPk = kDualRow + kDualVcap / 2 + 8,
+              kDualBary = kDualPk + 4 * kD1 * kNT, kDualWords = kDualBary + 4 * kD1 * kNT;
+
+__device__ __forceinline__ unsigned dual_load(const unsigned *p)       // device-coherent load (the producer ran on another CU / XCD)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 __device__ __forceinline__ unsigned hash32(unsigned key)
 {
@@ -119,20 +135,34 @@ __device__ __forceinline__ unsigned corner_key(const int16_t (&r0)[2], const uin
 
 // NT = 1024 lanes, or 512 for frames of up to 1024 points whose plan fits half the CU's LDS: two frames per CU
 // (fused_loop.h: kNTSmall).  Second launch bound: 128 registers per lane in both shapes.
-template <int NT, int PPT, int K>
+template <int NT, int PPT, int K, bool DUAL = false>
 __global__ void __launch_bounds__(NT, 4) k_frame(CrfDev c, FrameArgs a)
 {
     constexpr int D1 = kD1;
+    static_assert(!DUAL || (K == 2 && NT == kNT), "the two-workgroup form splits a two-kernel frame");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int f = blockIdx.x, tid = threadIdx.x;
+    const int f = DUAL ? (int)(blockIdx.x >> 1) : (int)blockIdx.x, tid = threadIdx.x;
+    const int role = DUAL ? (int)(blockIdx.x & 1) : 0;    // DUAL: 0 = the frame's main workgroup, 1 = the helper that builds kernel 1
     const int N = c.n_points[f];
     Instr ins{a.timing, a.timing_block, 8, 0, a.timing_lane};
     FL_STAMP();
     if (N <= 0) {                                         // an empty frame has no lattice (V = 0) and nothing to infer
-        if (tid < K && a.V_out[tid]) a.V_out[tid][f] = 0;
-        if (tid == 0 && a.frame_status) a.frame_status[f] = 0;
+        if (role == 0) {
+            if (tid < K && a.V_out[tid]) a.V_out[tid][f] = 0;
+            if (tid == 0 && a.frame_status) a.frame_status[f] = 0;
+        }
         return;
     }
+    unsigned *xs = DUAL ? a.dual + (size_t)f * kDualWords : nullptr;
+    // the helper's way out when its lattice cannot be handed over: tell the main workgroup (which then flags the frame)
+    auto helper_fail = [&]() {
+        if (tid == 0) {
+            xs[2] = 1u;
+            __threadfence();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(&xs[0], a.dual_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
     const int Npad = (N + 3) & ~3;                       // blocks of four, permutohedral_cpu.h:294 (quirk Q1)
     Hdr *hdr = reinterpret_cast<Hdr *>(smem + 192);
     const int hcap = a.hcap;
@@ -152,7 +182,7 @@ __global__ void __launch_bounds__(NT, 4) k_frame(CrfDev c, FrameArgs a)
     // other kernels' features and the labels / unaries still on their way.
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-        if (kFeatUpFront || k == 0) {
+        if ((kFeatUpFront || k == 0) && (!DUAL || k == role)) {
 #pragma unroll
             for (int s = 0; s < PPT; ++s)
                 ft[s][k] = reinterpret_cast<const float2 *>(a.feat[k])[(size_t)f * a.maxN + min(tid + s * NT, N - 1)];
@@ -177,6 +207,7 @@ __global__ void __launch_bounds__(NT, 4) k_frame(CrfDev c, FrameArgs a)
 
 #pragma unroll
     for (int k = 0; k < K; ++k) {
+        if (DUAL && k != role) continue;                  // (uniform per workgroup)
         // ---- A: point records (elevate, round, rank, barycentric) and the keys of their three corners ----
         unsigned key[PPT][D1];
         if (!kFeatUpFront && k > 0) {
@@ -263,7 +294,11 @@ __global__ void __launch_bounds__(NT, 4) k_frame(CrfDev c, FrameArgs a)
         const bool list_in_hash = !bitmap && list_cap * 2 <= a.lds_total - ido_off;
         const int list_off = list_in_hash ? ido_off : vs;
         const int vs_end = bitmap ? pre_off + Vk * W / 2 : (list_in_hash ? vs : list_off + list_cap * 2);
-        if (vs_end > ido_off || Vk >= 32767 || E + 7 * Vk >= 65535 || hdr->fail) {   // does not fit: leave the frame to the fallback path
+        if (vs_end > ido_off || Vk >= 32767 || E + 7 * Vk >= 65535 || hdr->fail || (DUAL && role == 1 && Vk > kDualVcap)) {   // does not fit: leave the frame to the fallback path
+            if (DUAL && role == 1) {
+                helper_fail();
+                return;
+            }
             if (tid == 0) {
                 if (a.status) *a.status = 1;
                 if (a.frame_status) a.frame_status[f] = 1;
@@ -550,6 +585,78 @@ __global__ void __launch_bounds__(NT, 4) k_frame(CrfDev c, FrameArgs a)
     }
     FL_STAMP();
 
+    if (DUAL && role == 1) {
+        // ---- helper: kernel 1's tables and per-point records into the hand-off area, then the flag -----------------
+        const int Vk = V[1];
+        const unsigned *nb = reinterpret_cast<const unsigned *>(smem + lay.nbr[1]);
+        for (int u = tid; u < D1 * Vk; u += NT) xs[kDualNbr + u] = nb[u];
+        const unsigned *rw = reinterpret_cast<const unsigned *>(smem + lay.row[1]);      // (Vk + 2) u16, the area is 4-byte aligned
+        for (int u = tid; u < (Vk + 3) / 2; u += NT) xs[kDualRow + u] = rw[u];
+#pragma unroll
+        for (int s = 0; s < PPT; ++s)
+#pragma unroll
+            for (int j = 0; j < D1; ++j) {
+                xs[kDualPk + (s * D1 + j) * NT + tid] = pk[s][1][j];
+                xs[kDualBary + (s * D1 + j) * NT + tid] = __float_as_uint(pr.bary[s][1][j]);
+            }
+        __syncthreads();
+        if (tid == 0) {                                   // plain stores -> barrier -> one agent-scope release -> drained -> relaxed flag store
+            xs[1] = (unsigned)Vk;
+            xs[2] = 0u;
+            __threadfence();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(&xs[0], a.dual_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        return;
+    }
+    if (DUAL) {
+        // ---- main: wait for the helper (bounded: a helper that never comes makes this frame fall back, it cannot hang the
+        //      launch), then take kernel 1's tables into LDS behind kernel 0's and its records into registers ---------------
+        if (tid == 0) {
+            int ok = 0;
+            for (int spin = 0; spin < (1 << 22); ++spin) {
+                if (dual_load(&xs[0]) == a.dual_epoch) { ok = 1; break; }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            hdr->dual_ok = (ok && dual_load(&xs[2]) == 0u) ? 1 : 0;
+            hdr->dual_V = (int)dual_load(&xs[1]);
+        }
+        __syncthreads();
+        const int Vk = __builtin_amdgcn_readfirstlane(hdr->dual_V);        // (scalar: every LDS offset below derives from it)
+        const int dual_ok = __builtin_amdgcn_readfirstlane(hdr->dual_ok);
+        auto take = [&](int &o, int bytes) { const int r = o; o += (bytes + 15) & ~15; return r; };
+        lay.val[1][0] = take(cursor, (Vk + 1) * 8);
+        lay.val[1][1] = take(cursor, (Vk + 1) * 8);
+        lay.nbr[1] = take(cursor, D1 * Vk * 4);
+        lay.row[1] = take(cursor, (Vk + 2) * 2);
+        if (!dual_ok || Vk < 0 || Vk > kDualVcap || cursor > a.lds_total) {
+            if (tid == 0) {
+                if (a.status) *a.status = 1;
+                if (a.frame_status) a.frame_status[f] = 1;
+            }
+            return;
+        }
+        V[1] = Vk;
+        unsigned *nb = reinterpret_cast<unsigned *>(smem + lay.nbr[1]);
+        for (int u = tid; u < D1 * Vk; u += NT) nb[u] = dual_load(&xs[kDualNbr + u]);
+        unsigned *rw = reinterpret_cast<unsigned *>(smem + lay.row[1]);
+        for (int u = tid; u < (Vk + 3) / 2; u += NT) rw[u] = dual_load(&xs[kDualRow + u]);
+#pragma unroll
+        for (int s = 0; s < PPT; ++s)
+#pragma unroll
+            for (int j = 0; j < D1; ++j) {
+                pk[s][1][j] = dual_load(&xs[kDualPk + (s * D1 + j) * NT + tid]);
+                pr.bary[s][1][j] = __uint_as_float(dual_load(&xs[kDualBary + (s * D1 + j) * NT + tid]));
+            }
+        if (tid == 0) {
+            reinterpret_cast<float2 *>(smem + lay.val[1][0])[0] = make_float2(0.f, 0.f);
+            reinterpret_cast<float2 *>(smem + lay.val[1][1])[0] = make_float2(0.f, 0.f);
+        }
+        __syncthreads();
+        FL_STAMP();
+    }
+
     // ---- loop-phase LDS plan: product buffers behind the persistent tables ---------------------------
     lay.chain0 = chain_wanted(N, V[0], row0max, NT) ? 1 : 0;
     {
@@ -637,6 +744,14 @@ void launch_frame_ppt(const CrfDev &c, const FrameArgs &a, hipStream_t s)
     fn<<<dim3(c.F), dim3(NT), a.lds_total, s>>>(c, a);
 }
 
+template <int PPT>
+void launch_frame_dual(const CrfDev &c, const FrameArgs &a, hipStream_t s)
+{
+    auto fn = k_frame<kNT, PPT, 2, true>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit);
+    fn<<<dim3(2 * c.F), dim3(kNT), a.lds_total, s>>>(c, a);
+}
+
 }  // namespace
 
 bool frame_supported(const CrfDev &c, const KernelDev *kds)
@@ -648,8 +763,10 @@ bool frame_supported(const CrfDev &c, const KernelDev *kds)
     return true;
 }
 
+size_t frame_dual_bytes(int frames) { return (size_t)frames * kDualWords * sizeof(unsigned); }
+
 bool launch_frame(const CrfDev &c, const KernelDev *kds, int n_iter, int with_map, float relax, int *status, int *frame_status,
-                  const int16_t *label, const float *tbl5, hipStream_t s, bool allow_small)
+                  const int16_t *label, const float *tbl5, hipStream_t s, bool allow_small, unsigned *dual, unsigned dual_epoch)
 {
     FrameArgs a{};
     for (int k = 0; k < c.K; ++k) {
@@ -673,6 +790,8 @@ bool launch_frame(const CrfDev &c, const KernelDev *kds, int n_iter, int with_ma
     a.lds_total = (int)kLdsLimit;
     a.status = status;
     a.frame_status = frame_status;
+    a.dual = dual;
+    a.dual_epoch = dual_epoch;
     static long long *timing_buf = nullptr;
     static const bool want_timing = kInstr && getenv("LCCRF_FRAME_TIMING") != nullptr;
     if (want_timing && !timing_buf) (void)hipMalloc(&timing_buf, 64 * sizeof(long long));
@@ -705,7 +824,16 @@ bool launch_frame(const CrfDev &c, const KernelDev *kds, int n_iter, int with_ma
         if (c.K == 1) launch_frame_ppt<NT, P, 1>(c, a, s);     \
         else launch_frame_ppt<NT, P, 2>(c, a, s);              \
         break;
-    if (small) {
+    static const bool no_dual = getenv("LCCRF_NO_DUAL") != nullptr;         // A/B switch: same results either way
+    if (dual && !no_dual && c.K == 2 && !small) {                           // a frame alone: two workgroups, one per lattice build
+        switch ((NA + kNT - 1) / kNT) {
+        case 1: launch_frame_dual<1>(c, a, s); break;
+        case 2: launch_frame_dual<2>(c, a, s); break;
+        case 3: launch_frame_dual<3>(c, a, s); break;
+        case 4: launch_frame_dual<4>(c, a, s); break;
+        default: break;
+        }
+    } else if (small) {
         a.lds_total = (int)kLdsHalf;
         switch ((NA + kNTSmall - 1) / kNTSmall) {
             FRAME_CASE(kNTSmall, 1)

@@ -339,6 +339,40 @@ np.save(sys.argv[1], np.concatenate([o.ravel() for o in out]))
     assert cc.same_bits(res[0], res[1])
 
 
+def test_two_workgroup_form_gives_the_same_bits(wl):
+    """Single frames through the object API run the frame kernel as TWO workgroups (one per lattice build, hand-off through
+    device memory: frame_engine.hip DUAL).  LCCRF_NO_DUAL=1 in a child process is the one-workgroup form: same bits for every
+    points-per-lane shape, a one-kernel CRF (not split), a sparse frame (the helper's lattice does not fit beside the main
+    workgroup's: fallback) and alternating sizes (the hand-off area is reused by every frame)."""
+    code = r"""
+import importlib, sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+pkg = importlib.import_module("lc-crf-slam_amd"); wl = importlib.import_module("lc-crf-slam_amd.workloads")
+from test_hip_parity import _shaped_problem
+out = []
+for rep in range(3):
+    for N in (5, 700, 2000, 1024, 3000, 4096, 2047, 1):
+        pb = wl.slam_problem(N, seed=321 + rep)
+        h = pkg.DenseCRFHIP(pb["N"], pb["L"]); h.set_unary_from_label(pb["label"], pb["conf"])
+        for f, w in pb["kernels"]: h.add_pairwise(f, w)
+        h.inference(5, True); out.append(h.probability()); out.append(h.map().astype(np.float32)); h.close()
+for pb in (_shaped_problem(wl, 1200, "sparse", seed=5), _shaped_problem(wl, 2000, "one_cell", seed=5)):
+    h = pkg.DenseCRFHIP(pb["N"], pb["L"]); h.set_unary_from_label(pb["label"], pb["conf"])
+    for f, w in pb["kernels"]: h.add_pairwise(f, w)
+    h.inference(4, True); out.append(h.probability()); h.close()
+    h = pkg.DenseCRFHIP(pb["N"], pb["L"]); h.set_unary_from_label(pb["label"], pb["conf"])
+    h.add_pairwise(*pb["kernels"][1]); h.inference(3, True); out.append(h.probability()); h.close()
+np.save(sys.argv[1], np.concatenate([o.ravel() for o in out]))
+""" % (ROOT, os.path.join(ROOT, "tests"))
+    res = []
+    for env in ({}, {"LCCRF_NO_DUAL": "1"}):
+        path = os.path.join(ROOT, "gpurun_out", "dual_%d.npy" % len(res))
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        subprocess.run([sys.executable, "-c", code, path], check=True, env=dict(os.environ, **env), timeout=600)
+        res.append(np.load(path))
+    assert cc.same_bits(res[0], res[1])
+
+
 def test_frame_kernel_many_copies_are_identical(wl):
     """Race hunt: 1536 frames in flight (6 per CU), three distinct frames tiled, three runs -- every copy must equal its
     original bit for bit, every time (workgroups of different frames share nothing but the kernel's code)."""
