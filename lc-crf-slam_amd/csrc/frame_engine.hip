@@ -78,12 +78,16 @@ struct Hdr {                              // lives at smem + 192
 // its tables (neighbour table, row starts) and per-point records (vertex | row place words, barycentric weights) over
 // through this area: 29k of the frame's 157k cycles leave the critical path for ~10k of hand-off.
 constexpr int kDualVcap = 8192;                           // vertices of kernel 1 the area can carry (more: the frame falls back)
-constexpr int kDualHdr = 16, kDualNbr = kDualHdr, kDualRow = kDualNbr + kD1 * kDualVcap, kDualPk = kDualRow + kDualVcap / 2 + 8,
-              kDualBary = kDualPk + 4 * kD1 * kNT, kDualWords = kDualBary + 4 * kD1 * kNT;
+constexpr int kDualHdr = 16, kDualNbr = kDualHdr, kDualRow = kDualNbr + kD1 * kDualVcap, kDualRec = kDualRow + kDualVcap / 2 + 8,
+              kDualWords = kDualRec + 2 * 4 * kD1 * kNT;   // records: (vertex | row place word, barycentric weight) pairs, 8 bytes each
 
 __device__ __forceinline__ unsigned dual_load(const unsigned *p)       // device-coherent load (the producer ran on another CU / XCD)
 {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long dual_load2(const unsigned *p)   // the same, 8 bytes (p 8-byte aligned)
+{
+    return __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 __device__ __forceinline__ unsigned hash32(unsigned key)
@@ -595,10 +599,8 @@ __global__ void __launch_bounds__(NT, 4) k_frame(CrfDev c, FrameArgs a)
 #pragma unroll
         for (int s = 0; s < PPT; ++s)
 #pragma unroll
-            for (int j = 0; j < D1; ++j) {
-                xs[kDualPk + (s * D1 + j) * NT + tid] = pk[s][1][j];
-                xs[kDualBary + (s * D1 + j) * NT + tid] = __float_as_uint(pr.bary[s][1][j]);
-            }
+            for (int j = 0; j < D1; ++j)
+                reinterpret_cast<uint2 *>(xs + kDualRec)[(s * D1 + j) * NT + tid] = make_uint2(pk[s][1][j], __float_as_uint(pr.bary[s][1][j]));
         __syncthreads();
         if (tid == 0) {                                   // plain stores -> barrier -> one agent-scope release -> drained -> relaxed flag store
             xs[1] = (unsigned)Vk;
@@ -638,17 +640,18 @@ __global__ void __launch_bounds__(NT, 4) k_frame(CrfDev c, FrameArgs a)
             return;
         }
         V[1] = Vk;
-        unsigned *nb = reinterpret_cast<unsigned *>(smem + lay.nbr[1]);
-        for (int u = tid; u < D1 * Vk; u += NT) nb[u] = dual_load(&xs[kDualNbr + u]);
-        unsigned *rw = reinterpret_cast<unsigned *>(smem + lay.row[1]);
-        for (int u = tid; u < (Vk + 3) / 2; u += NT) rw[u] = dual_load(&xs[kDualRow + u]);
 #pragma unroll
-        for (int s = 0; s < PPT; ++s)
+        for (int s = 0; s < PPT; ++s)                     // (8-byte loads: half the instructions of the hand-off's import)
 #pragma unroll
             for (int j = 0; j < D1; ++j) {
-                pk[s][1][j] = dual_load(&xs[kDualPk + (s * D1 + j) * NT + tid]);
-                pr.bary[s][1][j] = __uint_as_float(dual_load(&xs[kDualBary + (s * D1 + j) * NT + tid]));
+                const unsigned long long r = dual_load2(xs + kDualRec + 2 * ((s * D1 + j) * NT + tid));
+                pk[s][1][j] = (unsigned)r;
+                pr.bary[s][1][j] = __uint_as_float((unsigned)(r >> 32));
             }
+        unsigned long long *nb = reinterpret_cast<unsigned long long *>(smem + lay.nbr[1]);      // (16-byte aligned, sizes rounded up to 16)
+        for (int u = tid; u < (D1 * Vk + 1) / 2; u += NT) nb[u] = dual_load2(xs + kDualNbr + 2 * u);
+        unsigned *rw = reinterpret_cast<unsigned *>(smem + lay.row[1]);
+        for (int u = tid; u < (Vk + 3) / 2; u += NT) rw[u] = dual_load(&xs[kDualRow + u]);
         if (tid == 0) {
             reinterpret_cast<float2 *>(smem + lay.val[1][0])[0] = make_float2(0.f, 0.f);
             reinterpret_cast<float2 *>(smem + lay.val[1][1])[0] = make_float2(0.f, 0.f);
