@@ -15,6 +15,8 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <atomic>
+#include <chrono>
 #include <vector>
 
 using namespace lccrf;
@@ -172,6 +174,12 @@ struct Engine {
     bool frame_small_used = false;     //   more than 1/8 of a batch's frames did not fit that plan
     unsigned *dual_area = nullptr;     // object API (one frame at a time): hand-off area of the two-workgroup form of the frame kernel
     unsigned dual_epoch = 0;
+    // object API: the frame kernel's last act is a store of `done_epoch` into this pinned word, behind its results; the host
+    // polls it instead of waiting for the runtime's completion signal (which arrives a few microseconds later)
+    unsigned *done_word = nullptr;
+    unsigned done_epoch = 0;
+    bool done_armed = false;
+    bool idle_by_done = false;         // the last call on the handle was a getMap() that saw the done word: nothing is in flight
     int late_iter = 0, late_map = 0;
     float late_relax = 1.0f;
     bool timed_build = false, timed_inf = false;
@@ -233,6 +241,8 @@ struct Engine {
         if ((rc = mem.alloc_pinned(&row_host, (size_t)LCCRF_MAX_KERNELS * Fcap))) return rc;
         if ((rc = mem.alloc_pinned(&late_status, 1))) return rc;
         *late_status = 0;
+        if ((rc = mem.alloc_pinned(&done_word, 1))) return rc;
+        *done_word = 0;
         if ((rc = mem.alloc(&frame_status, Fcap))) return rc;
         if ((rc = mem.alloc(&fb_list, Fcap))) return rc;
         if ((rc = mem.alloc_pinned(&frame_status_host, Fcap))) return rc;
@@ -339,7 +349,10 @@ struct Engine {
     // Park everything for the next user of this engine (object API handle cache).
     void recycle()
     {
-        if (stream) (void)hipStreamSynchronize(stream);
+        // (a synchronisation that starts after the kernel has ended costs ~10 us: the runtime queues a barrier packet and
+        // waits for its round trip; the done word has already told us that nothing is in flight)
+        if (stream && !idle_by_done) (void)hipStreamSynchronize(stream);
+        idle_by_done = false;
         for (auto &ks : kernels) spare.push_back(ks);
         kernels.clear();
         F = Fcap;
@@ -538,8 +551,12 @@ struct Engine {
             dual = dual_area;
             if (++dual_epoch == 0) dual_epoch = 1;
         }
+        static const bool no_done_word = getenv("LCCRF_NO_DONE_WORD") != nullptr;   // A/B switch: wait on the stream instead
+        done_armed = late_ok && F == 1 && !no_done_word;
+        if (done_armed && ++done_epoch == 0) done_epoch = 1;
         frame_small_used = launch_frame(crf, kdevs.data(), n_iter, with_map, relax, late_status, frame_status,
-                                        from_label ? deferred_label : nullptr, deferred_tbl.v, stream, frame_small_ok, dual, dual_epoch);
+                                        from_label ? deferred_label : nullptr, deferred_tbl.v, stream, frame_small_ok, dual, dual_epoch,
+                                        done_armed ? done_word : nullptr, done_epoch);
         HIP_TRY(hipGetLastError());
         late_pending = true;
         late_iter = n_iter;
@@ -612,17 +629,35 @@ struct Engine {
     }
 
     // Before anything looks at (or continues from) the results of a late-bound inference.
-    int resolve_late()
+    // *seen_done (optional): the frame's results were observed through the done word -- the caller may read the pinned
+    // outputs without a stream synchronisation of its own.
+    int resolve_late(bool *seen_done = nullptr)
     {
+        if (seen_done) *seen_done = false;
         if (!late_pending) return LCCRF_OK;
         late_pending = false;
-        HIP_TRY(hipStreamSynchronize(stream));
+        bool seen = false;
+        if (done_armed) {                                  // bounded poll; a word that never comes is waited for the ordinary way
+            done_armed = false;
+            const volatile unsigned *w = done_word;
+            const auto t0 = std::chrono::steady_clock::now();
+            for (unsigned spins = 1; !(seen = (*w == done_epoch)); ++spins) {
+                if ((spins & 0x3ff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+                __builtin_ia32_pause();
+            }
+            std::atomic_thread_fence(std::memory_order_acquire);
+        }
+        if (!seen) HIP_TRY(hipStreamSynchronize(stream));
         if (*npoints_bad) {                                // (the one-launch path never passes through learn_sizes())
             *npoints_bad = 0;
             return fail(LCCRF_E_CAPACITY, "a bound n_points[f] lies outside [0, max_points=%d] (the kernels clamped it)", maxN);
         }
-        if (*late_status == 0) return LCCRF_OK;
+        if (*late_status == 0) {
+            if (seen_done) *seen_done = seen;
+            return LCCRF_OK;
+        }
         *late_status = 0;                                  // some frame did not fit the one-launch kernel
+        if (seen) HIP_TRY(hipStreamSynchronize(stream));   // (the kernel has nothing left to do; the stream formally still holds it)
         HIP_TRY(hipMemcpy(frame_status_host, frame_status, sizeof(int) * F, hipMemcpyDeviceToHost));
         int n = 0;
         for (int f = 0; f < F; ++f)
@@ -877,6 +912,7 @@ int lccrf_trim_cache(void)
     do {                                                              \
         if (!(h)) return fail(LCCRF_E_INVALID, "handle is NULL");     \
         HIP_TRY(hipSetDevice((h)->eng.device));                       \
+        (h)->eng.idle_by_done = false;                                \
     } while (0)
 
 #define CHECK_K(h, k)                                                                      \
@@ -1108,9 +1144,11 @@ int lccrf_get_map(lccrf_handle h, int16_t *map_out)
     CHECK_H(h);
     if (!map_out && h->N) return fail(LCCRF_E_INVALID, "map_out is NULL");
     Engine &e = h->eng;
-    { int rl = e.resolve_late(); if (rl) return rl; }
-    HIP_TRY(hipStreamSynchronize(e.stream));
+    bool seen_done = false;
+    { int rl = e.resolve_late(&seen_done); if (rl) return rl; }
+    if (!seen_done) HIP_TRY(hipStreamSynchronize(e.stream));
     if (h->N) memcpy(map_out, h->map_pin, (size_t)h->N * sizeof(int16_t));   // written there by the kernels
+    e.idle_by_done = seen_done;
     return LCCRF_OK;
 }
 

@@ -137,7 +137,7 @@ bool frame_supported(const CrfDev &c, const KernelDev *kds);
 // two workgroups each -- one per lattice build (single frames: the other 255 CUs are idle anyway).
 bool launch_frame(const CrfDev &c, const KernelDev *kds, int n_iter, int with_map, float relax, int *status, int *frame_status,
                   const int16_t *label, const float *tbl5, hipStream_t s, bool allow_small = true, unsigned *dual = nullptr,
-                  unsigned dual_epoch = 0);
+                  unsigned dual_epoch = 0, unsigned *done = nullptr, unsigned done_epoch = 0);
 size_t frame_dual_bytes(int frames);
 // rows of `bytes` bytes each between a frame-strided array and a compact one: dst[i] = src[list[i]] (gather = 1) or
 // dst[list[i]] = src[i] (gather = 0); strides in bytes, everything 4-byte aligned

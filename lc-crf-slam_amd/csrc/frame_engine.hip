@@ -62,6 +62,8 @@ struct FrameArgs {
     int *frame_status;                    // device [F] or null: 1 for exactly the frames that did not fit (they alone are re-run), else 0
     unsigned *dual;                       // DUAL launches: [F][kDualWords] hand-off area between a frame's two workgroups, else null
     unsigned dual_epoch;                  //   value the helper publishes in word 0 when its tables are complete (changes every launch)
+    unsigned *done;                       // single-frame launches: pinned host word that receives done_epoch when the frame's results (labels in
+    unsigned done_epoch;                  //   pinned memory, status words) are visible to the host -- earlier than the runtime's completion signal
     long long *timing;                    // instrumented builds only
     int timing_block, timing_lane;
 };
@@ -150,10 +152,19 @@ __global__ void __launch_bounds__(NT, 4) k_frame(CrfDev c, FrameArgs a)
     const int N = c.n_points[f];
     Instr ins{a.timing, a.timing_block, 8, 0, a.timing_lane};
     FL_STAMP();
+    // The last thing the frame's main workgroup does (uniform; every lane): results first, then the word the host polls.
+    auto publish_done = [&]() {
+        if (a.done) {
+            __threadfence_system();                       // this lane's stores have reached host memory ...
+            __syncthreads();                              // ... every lane's have
+            if (tid == 0) __hip_atomic_store(a.done, a.done_epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    };
     if (N <= 0) {                                         // an empty frame has no lattice (V = 0) and nothing to infer
         if (role == 0) {
             if (tid < K && a.V_out[tid]) a.V_out[tid][f] = 0;
             if (tid == 0 && a.frame_status) a.frame_status[f] = 0;
+            publish_done();
         }
         return;
     }
@@ -307,6 +318,7 @@ __global__ void __launch_bounds__(NT, 4) k_frame(CrfDev c, FrameArgs a)
                 if (a.status) *a.status = 1;
                 if (a.frame_status) a.frame_status[f] = 1;
             }
+            publish_done();
             return;                                       // uniform: every lane read the same V and the same flag
         }
         unsigned *vkey = reinterpret_cast<unsigned *>(smem + vkey_off);
@@ -637,6 +649,7 @@ __global__ void __launch_bounds__(NT, 4) k_frame(CrfDev c, FrameArgs a)
                 if (a.status) *a.status = 1;
                 if (a.frame_status) a.frame_status[f] = 1;
             }
+            publish_done();
             return;
         }
         V[1] = Vk;
@@ -685,6 +698,7 @@ __global__ void __launch_bounds__(NT, 4) k_frame(CrfDev c, FrameArgs a)
                 if (a.status) *a.status = 1;
                 if (a.frame_status) a.frame_status[f] = 1;
             }
+            publish_done();
             return;
         }
     }
@@ -727,6 +741,7 @@ __global__ void __launch_bounds__(NT, 4) k_frame(CrfDev c, FrameArgs a)
     store_results<PPT, K, NT>(c, f, N, tid, pr, a.with_map);
     if (tid < K && a.V_out[tid]) a.V_out[tid][f] = tid == 0 ? V[0] : V[K - 1];
     if (tid == 0 && a.frame_status) a.frame_status[f] = 0;
+    publish_done();
     FL_STAMP();
     if (kInstr && a.timing && (int)blockIdx.x == a.timing_block && tid == a.timing_lane) a.timing[63] = ins.n;
 }
@@ -769,7 +784,8 @@ bool frame_supported(const CrfDev &c, const KernelDev *kds)
 size_t frame_dual_bytes(int frames) { return (size_t)frames * kDualWords * sizeof(unsigned); }
 
 bool launch_frame(const CrfDev &c, const KernelDev *kds, int n_iter, int with_map, float relax, int *status, int *frame_status,
-                  const int16_t *label, const float *tbl5, hipStream_t s, bool allow_small, unsigned *dual, unsigned dual_epoch)
+                  const int16_t *label, const float *tbl5, hipStream_t s, bool allow_small, unsigned *dual, unsigned dual_epoch,
+                  unsigned *done, unsigned done_epoch)
 {
     FrameArgs a{};
     for (int k = 0; k < c.K; ++k) {
@@ -795,6 +811,8 @@ bool launch_frame(const CrfDev &c, const KernelDev *kds, int n_iter, int with_ma
     a.frame_status = frame_status;
     a.dual = dual;
     a.dual_epoch = dual_epoch;
+    a.done = c.F == 1 ? done : nullptr;
+    a.done_epoch = done_epoch;
     static long long *timing_buf = nullptr;
     static const bool want_timing = kInstr && getenv("LCCRF_FRAME_TIMING") != nullptr;
     if (want_timing && !timing_buf) (void)hipMalloc(&timing_buf, 64 * sizeof(long long));
