@@ -179,6 +179,10 @@ struct Engine {
     unsigned *done_word = nullptr;
     unsigned done_epoch = 0;
     bool done_armed = false;
+    // ... and with_map launches of the object API do not even wait for that word: the host pre-fills the pinned label array
+    // with -1 and takes each label as it arrives (the kernel's last stores; no fence, no acknowledgement round trip)
+    int16_t *map_host = nullptr;       // the handle's pinned label array (= crf.map), or null
+    bool labels_armed = false;
     bool idle_by_done = false;         // the last call on the handle was a getMap() that saw the done word: nothing is in flight
     int late_iter = 0, late_map = 0;
     float late_relax = 1.0f;
@@ -353,6 +357,7 @@ struct Engine {
         // waits for its round trip; the done word has already told us that nothing is in flight)
         if (stream && !idle_by_done) (void)hipStreamSynchronize(stream);
         idle_by_done = false;
+        labels_armed = done_armed = false;
         for (auto &ks : kernels) spare.push_back(ks);
         kernels.clear();
         F = Fcap;
@@ -554,6 +559,8 @@ struct Engine {
         static const bool no_done_word = getenv("LCCRF_NO_DONE_WORD") != nullptr;   // A/B switch: wait on the stream instead
         done_armed = late_ok && F == 1 && !no_done_word;
         if (done_armed && ++done_epoch == 0) done_epoch = 1;
+        labels_armed = done_armed && with_map && L == 2 && map_host && map_host == crf.map && activeN > 0;
+        if (labels_armed) memset(map_host, 0xff, (size_t)activeN * sizeof(int16_t));
         frame_small_used = launch_frame(crf, kdevs.data(), n_iter, with_map, relax, late_status, frame_status,
                                         from_label ? deferred_label : nullptr, deferred_tbl.v, stream, frame_small_ok, dual, dual_epoch,
                                         done_armed ? done_word : nullptr, done_epoch);
@@ -636,6 +643,7 @@ struct Engine {
         if (seen_done) *seen_done = false;
         if (!late_pending) return LCCRF_OK;
         late_pending = false;
+        labels_armed = false;
         bool seen = false;
         if (done_armed) {                                  // bounded poll; a word that never comes is waited for the ordinary way
             done_armed = false;
@@ -854,6 +862,7 @@ int lccrf_create(lccrf_handle *out, int device_id, int n_points, int n_labels)
     h->N = n_points;
     h->eng.activeN = n_points;
     h->eng.crf.map = h->map_pin;
+    h->eng.map_host = h->map_pin;
     h->eng.crf.map_bits = nullptr;                       // the packed copy is the batch API's gather payload only
     static const bool no_late = getenv("LCCRF_NO_LATE") != nullptr;   // debugging aid: always size the fused kernel on the host
     h->eng.late_ok = !no_late;
@@ -1144,6 +1153,29 @@ int lccrf_get_map(lccrf_handle h, int16_t *map_out)
     CHECK_H(h);
     if (!map_out && h->N) return fail(LCCRF_E_INVALID, "map_out is NULL");
     Engine &e = h->eng;
+    if (e.late_pending && e.labels_armed) {             // one frame in flight, its labels go straight into map_pin: take them as they land
+        e.labels_armed = false;
+        const volatile int16_t *m = h->map_pin;
+        const auto t0 = std::chrono::steady_clock::now();
+        bool ok = true;
+        unsigned spins = 0;
+        for (int i = 0; i < h->N && ok; ++i) {
+            int16_t v;
+            while ((v = m[i]) == (int16_t)-1) {           // (bounded: whatever goes wrong is left to the ordinary path below)
+                if ((++spins & 0x3ff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) { ok = false; break; }
+                __builtin_ia32_pause();
+            }
+            if (v < 0) ok = false;                        // -2: the frame did not fit the one-launch kernel
+        }
+        if (ok) {
+            std::atomic_thread_fence(std::memory_order_acquire);
+            memcpy(map_out, h->map_pin, (size_t)h->N * sizeof(int16_t));
+            e.late_pending = false;                       // every label is there: the frame fitted and the kernel is past its last read
+            e.done_armed = false;
+            e.idle_by_done = true;
+            return LCCRF_OK;
+        }
+    }
     bool seen_done = false;
     { int rl = e.resolve_late(&seen_done); if (rl) return rl; }
     if (!seen_done) HIP_TRY(hipStreamSynchronize(e.stream));

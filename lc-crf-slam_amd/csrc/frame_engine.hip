@@ -32,6 +32,7 @@
 #include "engine.h"
 #include "device_math.h"
 #include "fused_loop.h"
+#include <type_traits>
 
 #include <algorithm>
 #include <cstdio>
@@ -81,7 +82,8 @@ struct Hdr {                              // lives at smem + 192
 // through this area: 29k of the frame's 157k cycles leave the critical path for ~10k of hand-off.
 constexpr int kDualVcap = 8192;                           // vertices of kernel 1 the area can carry (more: the frame falls back)
 constexpr int kDualHdr = 16, kDualNbr = kDualHdr, kDualRow = kDualNbr + kD1 * kDualVcap, kDualRec = kDualRow + kDualVcap / 2 + 8,
-              kDualWords = kDualRec + 2 * 4 * kD1 * kNT;   // records: (vertex | row place word, barycentric weight) pairs, 8 bytes each
+              kDualWn = kDualRec + 2 * 4 * kD1 * kNT,      // records: (vertex | row place word, barycentric weight) pairs, 8 bytes each
+              kDualWords = kDualWn + 4 * kNT;              // w * norm of kernel 1, per point
 
 __device__ __forceinline__ unsigned dual_load(const unsigned *p)       // device-coherent load (the producer ran on another CU / XCD)
 {
@@ -158,6 +160,15 @@ __global__ void __launch_bounds__(NT, 4) k_frame(CrfDev c, FrameArgs a)
             __threadfence_system();                       // this lane's stores have reached host memory ...
             __syncthreads();                              // ... every lane's have
             if (tid == 0) __hip_atomic_store(a.done, a.done_epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    };
+    // A frame that does not fit this kernel's LDS plan is left to the fallback path.  (A host that reads the labels of a
+    // single frame as they arrive -- lccrf_get_map -- finds -2 in place of the first one.)
+    auto flag_unfit = [&]() {
+        if (tid == 0) {
+            if (a.status) *a.status = 1;
+            if (a.frame_status) a.frame_status[f] = 1;
+            if (a.done && c.map) c.map[(size_t)f * c.maxN] = (int16_t)-2;
         }
     };
     if (N <= 0) {                                         // an empty frame has no lattice (V = 0) and nothing to infer
@@ -314,10 +325,7 @@ __global__ void __launch_bounds__(NT, 4) k_frame(CrfDev c, FrameArgs a)
                 helper_fail();
                 return;
             }
-            if (tid == 0) {
-                if (a.status) *a.status = 1;
-                if (a.frame_status) a.frame_status[f] = 1;
-            }
+            flag_unfit();
             publish_done();
             return;                                       // uniform: every lane read the same V and the same flag
         }
@@ -601,18 +609,54 @@ __global__ void __launch_bounds__(NT, 4) k_frame(CrfDev c, FrameArgs a)
     }
     FL_STAMP();
 
+    // norm = 1 / (compute(ones) + 1e-20), pairwise3d.h:22-27, of the kernels in KM: one pass of the loop's own splat / blur /
+    // slice with Q = 1.  Fills pr.wn (= w * norm, pairwise3d.h:77).
+    ChainLane cl{0u, 0u};
+    auto normalise = [&](auto km) {
+        constexpr int KM = decltype(km)::value;
+#pragma unroll
+        for (int s = 0; s < PPT; ++s) pr.q[s] = make_float2(1.0f, 1.0f);
+        splat_blur<PPT, K, 2, true, NT, KM>(smem, lay, V, N, tid, pr, cl, ins);
+#pragma unroll
+        for (int s = 0; s < PPT; ++s) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                if (!((KM >> k) & 1)) continue;
+                pr.wn[s][k] = 0.0f;
+                if (tid + s * NT < N) {
+                    const float t = slice_point(smem, lay, pr, s, k, a.alpha).x;
+                    pr.wn[s][k] = a.w[k] * (1.0f / (t + 1e-20f));             // pairwise3d.h:26-27,77
+                }
+            }
+        }
+    };
+
     if (DUAL && role == 1) {
-        // ---- helper: kernel 1's tables and per-point records into the hand-off area, then the flag -----------------
+        // ---- helper: normalise kernel 1 on its own lattice, then its tables (neighbour table, row starts) and per-point
+        //      records (vertex | row place words, barycentric weights, w * norm) into the hand-off area, then the flag ------
         const int Vk = V[1];
+        V[0] = 0;
+        lay.chain0 = 0;
+        lay.prod_all = 1;
+        lay.Ecap[1] = plane_floats(N, Vk, false);
+        lay.prod[1] = cursor;
+        if (cursor + lay.Ecap[1] * 8 > a.lds_total) {     // (uniform)
+            helper_fail();
+            return;
+        }
+        place_products<PPT, K, 2, NT, 2>(smem, lay, N, tid, pk, pr);
+        normalise(std::integral_constant<int, 2>{});
         const unsigned *nb = reinterpret_cast<const unsigned *>(smem + lay.nbr[1]);
         for (int u = tid; u < D1 * Vk; u += NT) xs[kDualNbr + u] = nb[u];
         const unsigned *rw = reinterpret_cast<const unsigned *>(smem + lay.row[1]);      // (Vk + 2) u16, the area is 4-byte aligned
         for (int u = tid; u < (Vk + 3) / 2; u += NT) xs[kDualRow + u] = rw[u];
 #pragma unroll
-        for (int s = 0; s < PPT; ++s)
+        for (int s = 0; s < PPT; ++s) {
 #pragma unroll
             for (int j = 0; j < D1; ++j)
                 reinterpret_cast<uint2 *>(xs + kDualRec)[(s * D1 + j) * NT + tid] = make_uint2(pk[s][1][j], __float_as_uint(pr.bary[s][1][j]));
+            xs[kDualWn + s * NT + tid] = __float_as_uint(pr.wn[s][1]);
+        }
         __syncthreads();
         if (tid == 0) {                                   // plain stores -> barrier -> one agent-scope release -> drained -> relaxed flag store
             xs[1] = (unsigned)Vk;
@@ -624,8 +668,26 @@ __global__ void __launch_bounds__(NT, 4) k_frame(CrfDev c, FrameArgs a)
         return;
     }
     if (DUAL) {
-        // ---- main: wait for the helper (bounded: a helper that never comes makes this frame fall back, it cannot hang the
-        //      launch), then take kernel 1's tables into LDS behind kernel 0's and its records into registers ---------------
+        // ---- main: kernel 0's product buffer right behind its tables (sized for either kernel: it is the shared buffer when the
+        //      two do not fit side by side), rank its chain rows and normalise it -- all of that while the helper is still
+        //      building; then wait for the helper (bounded: a helper that never comes makes this frame fall back, it cannot
+        //      hang the launch) and take kernel 1's tables into LDS behind the buffer, its records and norms into registers ---
+        lay.chain0 = chain_wanted(N, V[0], row0max, NT) ? 1 : 0;
+        lay.Ecap[0] = plane_floats(N, V[0], lay.chain0 != 0);
+        lay.Ecap[1] = plane_floats(N, 0, false);          // (a short-row kernel's plane does not depend on its V)
+        lay.prod[0] = cursor;
+        cursor += (max(lay.Ecap[0], lay.Ecap[1]) * 8 + 15) & ~15;
+        lay.prod_all = 1;
+        if (cursor > a.lds_total) {
+            flag_unfit();
+            publish_done();
+            return;
+        }
+        V[1] = 0;
+        place_products<PPT, K, 2, NT, 1>(smem, lay, N, tid, pk, pr);
+        if (lay.chain0) cl = chain_setup(smem, lay, V[0], tid);
+        normalise(std::integral_constant<int, 1>{});
+        FL_STAMP();
         if (tid == 0) {
             int ok = 0;
             for (int spin = 0; spin < (1 << 22); ++spin) {
@@ -645,22 +707,21 @@ __global__ void __launch_bounds__(NT, 4) k_frame(CrfDev c, FrameArgs a)
         lay.nbr[1] = take(cursor, D1 * Vk * 4);
         lay.row[1] = take(cursor, (Vk + 2) * 2);
         if (!dual_ok || Vk < 0 || Vk > kDualVcap || cursor > a.lds_total) {
-            if (tid == 0) {
-                if (a.status) *a.status = 1;
-                if (a.frame_status) a.frame_status[f] = 1;
-            }
+            flag_unfit();
             publish_done();
             return;
         }
         V[1] = Vk;
 #pragma unroll
-        for (int s = 0; s < PPT; ++s)                     // (8-byte loads: half the instructions of the hand-off's import)
+        for (int s = 0; s < PPT; ++s) {                   // (8-byte loads: half the instructions of the hand-off's import)
 #pragma unroll
             for (int j = 0; j < D1; ++j) {
                 const unsigned long long r = dual_load2(xs + kDualRec + 2 * ((s * D1 + j) * NT + tid));
                 pk[s][1][j] = (unsigned)r;
                 pr.bary[s][1][j] = __uint_as_float((unsigned)(r >> 32));
             }
+            pr.wn[s][1] = __uint_as_float(dual_load(xs + kDualWn + s * NT + tid));
+        }
         unsigned long long *nb = reinterpret_cast<unsigned long long *>(smem + lay.nbr[1]);      // (16-byte aligned, sizes rounded up to 16)
         for (int u = tid; u < (D1 * Vk + 1) / 2; u += NT) nb[u] = dual_load2(xs + kDualNbr + 2 * u);
         unsigned *rw = reinterpret_cast<unsigned *>(smem + lay.row[1]);
@@ -669,58 +730,48 @@ __global__ void __launch_bounds__(NT, 4) k_frame(CrfDev c, FrameArgs a)
             reinterpret_cast<float2 *>(smem + lay.val[1][0])[0] = make_float2(0.f, 0.f);
             reinterpret_cast<float2 *>(smem + lay.val[1][1])[0] = make_float2(0.f, 0.f);
         }
+        if (cursor + lay.Ecap[1] * 8 <= a.lds_total) {    // own product buffer, else kernel 0's serves both (P / S one kernel at a time)
+            lay.prod[1] = cursor;
+            lay.total = cursor + lay.Ecap[1] * 8;
+        } else {
+            lay.prod[1] = lay.prod[0];
+            lay.prod_all = 0;
+            lay.total = cursor;
+        }
         __syncthreads();
+        place_products<PPT, K, 2, NT, 2>(smem, lay, N, tid, pk, pr);
         FL_STAMP();
-    }
-
-    // ---- loop-phase LDS plan: product buffers behind the persistent tables ---------------------------
-    lay.chain0 = chain_wanted(N, V[0], row0max, NT) ? 1 : 0;
-    {
-        bool ok = false;
-        for (int all = 1; all >= 0 && !ok; --all) {
-            int o = cursor, shared = 0;
-            for (int k = 0; k < K; ++k) {
-                lay.Ecap[k] = plane_floats(N, V[k], k == 0 && lay.chain0);
-                const int pb = lay.Ecap[k] * 8;
-                if (all) { lay.prod[k] = o; o += (pb + 15) & ~15; }
-                else shared = max(shared, pb);
+    } else {
+        // ---- loop-phase LDS plan: product buffers behind the persistent tables ---------------------------
+        lay.chain0 = chain_wanted(N, V[0], row0max, NT) ? 1 : 0;
+        {
+            bool ok = false;
+            for (int all = 1; all >= 0 && !ok; --all) {
+                int o = cursor, shared = 0;
+                for (int k = 0; k < K; ++k) {
+                    lay.Ecap[k] = plane_floats(N, V[k], k == 0 && lay.chain0);
+                    const int pb = lay.Ecap[k] * 8;
+                    if (all) { lay.prod[k] = o; o += (pb + 15) & ~15; }
+                    else shared = max(shared, pb);
+                }
+                if (!all) {
+                    for (int k = 0; k < K; ++k) lay.prod[k] = o;
+                    o += (shared + 15) & ~15;
+                }
+                lay.prod_all = all;
+                lay.total = o;
+                ok = o <= a.lds_total;
             }
-            if (!all) {
-                for (int k = 0; k < K; ++k) lay.prod[k] = o;
-                o += (shared + 15) & ~15;
-            }
-            lay.prod_all = all;
-            lay.total = o;
-            ok = o <= a.lds_total;
-        }
-        if (!ok) {
-            if (tid == 0) {
-                if (a.status) *a.status = 1;
-                if (a.frame_status) a.frame_status[f] = 1;
-            }
-            publish_done();
-            return;
-        }
-    }
-    place_products<PPT, K, 2, NT>(smem, lay, N, tid, pk, pr);
-    ChainLane cl{0u, 0u};
-    if (lay.chain0) cl = chain_setup(smem, lay, V[0], tid);
-
-    // ---- normalisation: norm = 1 / (compute(ones) + 1e-20), pairwise3d.h:22-27 -- one pass of the loop's own
-    //      splat / blur / slice with Q = 1 for every kernel at once
-#pragma unroll
-    for (int s = 0; s < PPT; ++s) pr.q[s] = make_float2(1.0f, 1.0f);
-    splat_blur<PPT, K, 2, true, NT>(smem, lay, V, N, tid, pr, cl, ins);
-#pragma unroll
-    for (int s = 0; s < PPT; ++s) {
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-            pr.wn[s][k] = 0.0f;
-            if (tid + s * NT < N) {
-                const float t = slice_point(smem, lay, pr, s, k, a.alpha).x;
-                pr.wn[s][k] = a.w[k] * (1.0f / (t + 1e-20f));             // pairwise3d.h:26-27,77
+            if (!ok) {
+                flag_unfit();
+                publish_done();
+                return;
             }
         }
+        place_products<PPT, K, 2, NT>(smem, lay, N, tid, pk, pr);
+        if (lay.chain0) cl = chain_setup(smem, lay, V[0], tid);
+        // every kernel at once
+        normalise(std::integral_constant<int, (1 << K) - 1>{});
     }
     FL_STAMP();                                           // (no barrier: the next writer of val[.][1] is two barriers away)
 

@@ -230,12 +230,14 @@ __device__ __forceinline__ bool chain_k(const FusedLayout &lay, int k)
 // vertex's row in ascending point order, the reference's splat order, counted from the start of the CSR
 // (row[v] + rank).  A plain kernel stores its products at exactly that position; the chain kernel re-places
 // row v at pst(row[v], v).  Fills ix.  The row tables must be in LDS and visible (barrier before).
-template <int PPT, int K, int CH, int NT = kNT>
+// KMASK: the kernels to place (bit k); the frame kernel's two-workgroup form places them one at a time.
+template <int PPT, int K, int CH, int NT = kNT, int KMASK = (1 << K) - 1>
 __device__ __forceinline__ void place_products(unsigned char *smem, const FusedLayout &lay, int N, int tid,
                                                const unsigned (&pk)[PPT][K][kD1], PointRegs<PPT, K> &pr)
 {
 #pragma unroll
     for (int k = 0; k < K; ++k) {
+        if (!((KMASK >> k) & 1)) continue;
         const unsigned short *row = reinterpret_cast<const unsigned short *>(smem + lay.row[k]);
 #pragma unroll
         for (int s = 0; s < PPT; ++s) {
@@ -356,7 +358,9 @@ __device__ __forceinline__ void chain_pads(unsigned char *smem, const ChainLane 
 
 // WITH_P = false (own product buffers only): the products are already in place -- mean_field writes the next
 // iteration's products point by point right behind each point's softmax.
-template <int PPT, int K, int CH, bool WITH_P = true, int NT = kNT>
+// KMASK: the kernels that take part (bit k) -- all of them in the loop; the frame kernel's two-workgroup form normalises
+// its kernels one at a time (frame_engine.hip).
+template <int PPT, int K, int CH, bool WITH_P = true, int NT = kNT, int KMASK = (1 << K) - 1>
 __device__ __forceinline__ void splat_blur(unsigned char *smem, const FusedLayout &lay, const int (&V)[K], int N, int tid,
                                            const PointRegs<PPT, K> &pr, const ChainLane &cl, Instr &ins)
 {
@@ -407,21 +411,25 @@ __device__ __forceinline__ void splat_blur(unsigned char *smem, const FusedLayou
             reinterpret_cast<float2 *>(val)[v + 1] = make_float2(a0, a1);
         }
     };
+    constexpr auto on = [](int k) { return ((KMASK >> k) & 1) != 0; };
     if (lay.prod_all) {
         if (WITH_P) {
 #pragma unroll
-            for (int k = 0; k < K; ++k) phase_P(k);
+            for (int k = 0; k < K; ++k)
+                if (on(k)) phase_P(k);
         }
         __syncthreads();
         FL_STAMP();
-        const int s_lo = (K > 1 && chain_k<CH>(lay, 0)) ? 128 : 0;
+        const int s_lo = (K > 1 && on(0) && on(1) && chain_k<CH>(lay, 0)) ? 128 : 0;
 #pragma unroll
-        for (int k = 0; k < K; ++k) phase_S(k, s_lo);                 // the chain kernel is kernel 0: it starts first
+        for (int k = 0; k < K; ++k)
+            if (on(k)) phase_S(k, s_lo);                               // the chain kernel is kernel 0: it starts first
         __syncthreads();
         FL_STAMP();
     } else {
 #pragma unroll
         for (int k = 0; k < K; ++k) {
+            if (!on(k)) continue;
             phase_P(k);
             __syncthreads();
             phase_S(k, 0);
@@ -434,6 +442,7 @@ __device__ __forceinline__ void splat_blur(unsigned char *smem, const FusedLayou
     for (int j = 0; j < D1; ++j) {
 #pragma unroll
         for (int k = 0; k < K; ++k) {
+            if (!on(k)) continue;
             const float2 *src = reinterpret_cast<const float2 *>(smem + lay.val[k][j & 1]);
             float2 *dst = reinterpret_cast<float2 *>(smem + lay.val[k][(j & 1) ^ 1]);
             const unsigned *nbr = reinterpret_cast<const unsigned *>(smem + lay.nbr[k]) + j * V[k];
