@@ -631,6 +631,21 @@ __global__ void __launch_bounds__(NT, 4) k_frame(CrfDev c, FrameArgs a)
         }
     };
 
+    // unary energies (densecrf3d.h:116-129 with L = 2; the labels arrived long ago) and Q0 = softmax(-unary)
+    int first_p = -1;
+    auto begin_inference = [&]() {
+        if (a.label) {
+#pragma unroll
+            for (int s = 0; s < PPT; ++s) {
+                const int t = lab_raw[s];
+                const bool known = t >= 0 && t < 2;
+                pr.un[s].x = !known ? a.tbl[0] : (t == 0 ? a.tbl[3] : a.tbl[1 + t]);
+                pr.un[s].y = !known ? a.tbl[0] : (t == 1 ? a.tbl[4] : a.tbl[1 + t]);
+            }
+        }
+        start_inference<PPT, K, NT>(pr, N, tid);
+    };
+
     if (DUAL && role == 1) {
         // ---- helper: normalise kernel 1 on its own lattice, then its tables (neighbour table, row starts) and per-point
         //      records (vertex | row place words, barycentric weights, w * norm) into the hand-off area, then the flag ------
@@ -646,6 +661,7 @@ __global__ void __launch_bounds__(NT, 4) k_frame(CrfDev c, FrameArgs a)
         }
         place_products<PPT, K, 2, NT, 2>(smem, lay, N, tid, pk, pr);
         normalise(std::integral_constant<int, 2>{});
+        FL_STAMP();
         const unsigned *nb = reinterpret_cast<const unsigned *>(smem + lay.nbr[1]);
         for (int u = tid; u < D1 * Vk; u += NT) xs[kDualNbr + u] = nb[u];
         const unsigned *rw = reinterpret_cast<const unsigned *>(smem + lay.row[1]);      // (Vk + 2) u16, the area is 4-byte aligned
@@ -665,6 +681,8 @@ __global__ void __launch_bounds__(NT, 4) k_frame(CrfDev c, FrameArgs a)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __hip_atomic_store(&xs[0], a.dual_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        FL_STAMP();
+        if (kInstr && a.timing && (int)blockIdx.x == a.timing_block && tid == a.timing_lane) a.timing[63] = ins.n;
         return;
     }
     if (DUAL) {
@@ -687,6 +705,14 @@ __global__ void __launch_bounds__(NT, 4) k_frame(CrfDev c, FrameArgs a)
         place_products<PPT, K, 2, NT, 1>(smem, lay, N, tid, pk, pr);
         if (lay.chain0) cl = chain_setup(smem, lay, V[0], tid);
         normalise(std::integral_constant<int, 1>{});
+        // still nothing from the helper is needed: Q0 = softmax(-unary) and kernel 0's first products
+        begin_inference();
+        if (kFuseXP && PPT <= 2 && a.n_iter > 0) {
+#pragma unroll
+            for (int s = 0; s < PPT; ++s)                 // (the normalisation's row sums finished with the buffer four barriers ago)
+                if (tid + s * NT < N) point_products<PPT, K, 2>(smem, lay, pr, s, 0);
+            first_p = 2;
+        }
         FL_STAMP();
         if (tid == 0) {
             int ok = 0;
@@ -775,20 +801,11 @@ __global__ void __launch_bounds__(NT, 4) k_frame(CrfDev c, FrameArgs a)
     }
     FL_STAMP();                                           // (no barrier: the next writer of val[.][1] is two barriers away)
 
-    if (a.label) {                                        // densecrf3d.h:116-129 with L = 2 (the labels arrived long ago)
-#pragma unroll
-        for (int s = 0; s < PPT; ++s) {
-            const int t = lab_raw[s];
-            const bool known = t >= 0 && t < 2;
-            pr.un[s].x = !known ? a.tbl[0] : (t == 0 ? a.tbl[3] : a.tbl[1 + t]);
-            pr.un[s].y = !known ? a.tbl[0] : (t == 1 ? a.tbl[4] : a.tbl[1 + t]);
-        }
-    }
-    start_inference<PPT, K, NT>(pr, N, tid);
+    if (!DUAL) begin_inference();
     float alpha[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) alpha[k] = a.alpha;
-    mean_field<PPT, K, 2, NT>(smem, lay, V, N, tid, pr, cl, alpha, a.n_iter, a.relax, ins);
+    mean_field<PPT, K, 2, NT>(smem, lay, V, N, tid, pr, cl, alpha, a.n_iter, a.relax, ins, first_p);
     store_results<PPT, K, NT>(c, f, N, tid, pr, a.with_map);
     if (tid < K && a.V_out[tid]) a.V_out[tid][f] = tid == 0 ? V[0] : V[K - 1];
     if (tid == 0 && a.frame_status) a.frame_status[f] = 0;
@@ -869,7 +886,7 @@ bool launch_frame(const CrfDev &c, const KernelDev *kds, int n_iter, int with_ma
     if (want_timing && !timing_buf) (void)hipMalloc(&timing_buf, 64 * sizeof(long long));
     a.timing = want_timing ? timing_buf : nullptr;
     a.timing_block = want_timing ? std::max(atoi(getenv("LCCRF_FRAME_TIMING")) - 1, 0) : 0;
-    if (a.timing_block >= c.F) a.timing_block = 0;
+    if (a.timing_block >= (dual ? 2 : 1) * c.F) a.timing_block = 0;     // (two-workgroup form: block 2f is frame f's main workgroup, 2f + 1 its helper)
     a.timing_lane = (want_timing && getenv("LCCRF_FRAME_TIMING_LANE")) ? atoi(getenv("LCCRF_FRAME_TIMING_LANE")) & (kNT - 1) : 0;
     // Small frames: 512 lanes and half the CU's LDS per frame, so that two frames share a CU.  A frame whose lattices
     // do not fit that plan (or whose long rows need more chain lanes than four wavefront pairs have) flags itself

@@ -506,12 +506,14 @@ __device__ __forceinline__ void start_inference(PointRegs<PPT, K> &pr, int N, in
 }
 
 // n_iter x stepInference (densecrf_base.h:82-91): splat, blur, then slice + apply + softmax per point.
+// first_p (bit k): with own product buffers the loop starts by writing every kernel's products of Q0; a caller that has
+// already put kernel k's in place (the frame kernel's two-workgroup form, while it waits for the other lattice) clears bit k.
 // No barrier is needed behind X: the next P only writes the product buffers, whose readers finished
 // two barriers ago.
 template <int PPT, int K, int CH, int NT = kNT>
 __device__ __forceinline__ void mean_field(unsigned char *smem, const FusedLayout &lay, const int (&V)[K], int N, int tid,
                                            PointRegs<PPT, K> &pr, const ChainLane &cl, const float (&alpha)[K], int n_iter,
-                                           float relax, Instr &ins)
+                                           float relax, Instr &ins, int first_p = -1)
 {
     // slice + apply + softmax of point slot s (X)
     auto point_update = [&](int s) {
@@ -529,9 +531,10 @@ __device__ __forceinline__ void mean_field(unsigned char *smem, const FusedLayou
         // point's LDS stores drain while the next point's slice and softmax occupy the VALU (X is VALU-bound, P is
         // bound by the LDS store path; back to back they cost the sum).  The barrier that used to follow P now
         // opens splat_blur; the pads behind the chain rows are written once (nothing else ever writes there).
-        if (n_iter > 0) {
+        if (n_iter > 0) {                                  // (first_p: the kernels whose first products are not in place yet)
 #pragma unroll
             for (int k = 0; k < K; ++k) {
+                if (!((first_p >> k) & 1)) continue;
 #pragma unroll
                 for (int s = 0; s < PPT; ++s)
                     if (tid + s * NT < N) point_products<PPT, K, CH>(smem, lay, pr, s, k);

@@ -6,7 +6,7 @@ cd "$GRAFT_REPO_ROOT"
 make -C lc-crf-slam_amd -j8 INSTRUMENT=1 >/dev/null || exit 1
 export LCCRF_LIB=$PWD/lc-crf-slam_amd/liblccrf_hip_instr.so
 for N in ${SIZES:-2000 500}; do
-LCCRF_FRAME_TIMING=1 python3 - "$N" 2>&1 <<'PY' | grep "frame timing" | tail -2
+LCCRF_FRAME_TIMING=${TIMING_BLOCK:-1} python3 - "$N" 2>&1 <<'PY' | grep "frame timing" | tail -2
 import importlib, sys, os
 sys.path.insert(0, os.getcwd())
 pkg = importlib.import_module("lc-crf-slam_amd"); wl = importlib.import_module("lc-crf-slam_amd.workloads")

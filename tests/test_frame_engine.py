@@ -316,6 +316,59 @@ def test_object_api_inference_is_one_launch_and_probes_still_work(po, wl):
     assert cc.same_bits(h.probability(), o.probability())
 
 
+def test_object_api_labels_are_taken_as_they_land(po, wl):
+    """getMap() right behind inference(n, true) reads the labels out of pinned memory as the kernel's last stores arrive
+    (no stream synchronisation); the handle goes back to the cache without one either.  A tracker's sequence: frames
+    of changing size, one handle after the other, map first, probabilities only sometimes -- every frame against the oracle."""
+    rng = np.random.default_rng(11)
+    for i in range(40):
+        N = int(rng.integers(1, 2600))
+        pb = wl.slam_problem(N, seed=300 + i)
+        o, h = cc.setup(po.OracleCRF, pb), cc.setup(pkg.DenseCRFHIP, pb)
+        o.inference_native(5, True)
+        h.inference(5, True)
+        assert np.array_equal(h.map(), o.map()), (i, N)
+        if i % 3 == 0:
+            assert cc.same_bits(h.probability(), o.probability()), (i, N)
+            assert np.array_equal(h.map(), o.map())            # (a second getMap: nothing in flight, the ordinary path)
+        h.close()
+
+
+def test_object_api_frame_that_does_not_fit_is_seen_through_the_label_array(po, wl):
+    """A frame whose lattices do not fit the one-launch kernel writes -2 where its first label would go: getMap() leaves the
+    early path and the two-kernel path re-runs the frame, same answers; the next frame on the cached handle is a normal one."""
+    for pb in (_shaped_problem(wl, 1200, "sparse", seed=5), wl.slam_problem(1200, seed=9), _shaped_problem(wl, 900, "sparse", seed=6)):
+        o, h = cc.setup(po.OracleCRF, pb), cc.setup(pkg.DenseCRFHIP, pb)
+        o.inference_native(4, True)
+        h.inference(4, True)
+        assert np.array_equal(h.map(), o.map())
+        assert cc.same_bits(h.probability(), o.probability())
+        h.close()
+
+
+def test_done_word_switch_gives_the_same_bits(wl):
+    """LCCRF_NO_DONE_WORD (wait on the stream instead of the pinned words) in a child process."""
+    import subprocess, sys, os, tempfile
+    code = (
+        "import importlib, sys, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "pkg = importlib.import_module('lc-crf-slam_amd'); wl = importlib.import_module('lc-crf-slam_amd.workloads')\n"
+        "out = []\n"
+        "for i, N in enumerate((7, 500, 2000, 3001)):\n"
+        "    pb = wl.slam_problem(N, seed=40 + i)\n"
+        "    h = pkg.DenseCRFHIP(N, 2); h.set_unary_from_label(pb['label'], pb['conf'])\n"
+        "    for f, w in pb['kernels']: h.add_pairwise(f, w)\n"
+        "    h.inference(5, True); out.append(h.map().astype(np.float32)); out.append(h.probability().ravel()); h.close()\n"
+        "np.save(sys.argv[1], np.concatenate(out))\n" % ROOT)
+    res = []
+    with tempfile.TemporaryDirectory() as td:
+        for j, env in enumerate(({}, {"LCCRF_NO_DONE_WORD": "1"})):
+            fn = os.path.join(td, "o%d.npy" % j)
+            subprocess.run([sys.executable, "-c", code, fn], check=True, env=dict(os.environ, **env), timeout=300)
+            res.append(np.load(fn))
+    assert cc.same_bits(res[0], res[1])
+
+
 def test_no_frame_switch_gives_the_same_bits(wl):
     """LCCRF_NO_FRAME (two-kernel path for the object API) in a child process."""
     code = r"""
