@@ -99,7 +99,10 @@ int  lccrf_build_map(lccrf_handle h);
 int  lccrf_inference(lccrf_handle h, int n_iterations, int with_map, float relax);
 
 /* DenseCRF::getMap() / getProbability()         densecrf_base.h:74-75
- * (copies out; the reference returns pointers into object-owned buffers)               */
+ * (copies out; the reference returns pointers into object-owned buffers)
+ * lccrf_get_map right behind lccrf_inference(h, n, 1, ...) is the tracker's sequence and the fast one: the frame kernel's
+ * last stores are the labels, into pinned host memory, and the call takes them as they arrive instead of waiting for the
+ * stream.  Same results as any other order of calls.                                    */
 int  lccrf_get_map(lccrf_handle h, int16_t *map_out);
 int  lccrf_get_probability(lccrf_handle h, float *prob_out);
 
