@@ -360,7 +360,8 @@ __device__ __forceinline__ void chain_pads(unsigned char *smem, const ChainLane 
 // iteration's products point by point right behind each point's softmax.
 // KMASK: the kernels that take part (bit k) -- all of them in the loop; the frame kernel's two-workgroup form normalises
 // its kernels one at a time (frame_engine.hip).
-template <int PPT, int K, int CH, bool WITH_P = true, int NT = kNT, int KMASK = (1 << K) - 1>
+// REV: see the blur passes.
+template <int PPT, int K, int CH, bool WITH_P = true, int NT = kNT, int KMASK = (1 << K) - 1, bool REV = false>
 __device__ __forceinline__ void splat_blur(unsigned char *smem, const FusedLayout &lay, const int (&V)[K], int N, int tid,
                                            const PointRegs<PPT, K> &pr, const ChainLane &cl, Instr &ins)
 {
@@ -446,7 +447,16 @@ __device__ __forceinline__ void splat_blur(unsigned char *smem, const FusedLayou
             const float2 *src = reinterpret_cast<const float2 *>(smem + lay.val[k][j & 1]);
             float2 *dst = reinterpret_cast<float2 *>(smem + lay.val[k][(j & 1) ^ 1]);
             const unsigned *nbr = reinterpret_cast<const unsigned *>(smem + lay.nbr[k]) + j * V[k];
-            for (int v = tid; v < V[k]; v += NT) {
+            // REV (k_fused, 1024 lanes, two kernels): the small lattice (kernel 0, ~120 vertices) goes to the LAST lanes -- the first
+            // ones have a second vertex of the large lattice (~1160), and a pass is as long as its busiest lane (+0.6 % C2, +1 % C4;
+            // with 512 lanes every lane has two or three vertices anyway and the reversal lost 5 % on C1; in k_frame the extra
+            // index pushed one variant into scratch)
+            int v0 = tid;
+            if (REV && K > 1 && k == 0 && NT == kNT) {
+                asm volatile("" : "+v"(v0));              // (recomputed per pass: hoisted, the reversed index would cost a register for the whole loop)
+                v0 = NT - 1 - v0;
+            }
+            for (int v = v0; v < V[k]; v += NT) {
                 const unsigned n = nbr[v];
                 const float2 o = src[v + 1], x = src[n & 0xffffu], y = src[n >> 16];
                 float2 r;
@@ -510,7 +520,7 @@ __device__ __forceinline__ void start_inference(PointRegs<PPT, K> &pr, int N, in
 // already put kernel k's in place (the frame kernel's two-workgroup form, while it waits for the other lattice) clears bit k.
 // No barrier is needed behind X: the next P only writes the product buffers, whose readers finished
 // two barriers ago.
-template <int PPT, int K, int CH, int NT = kNT>
+template <int PPT, int K, int CH, int NT = kNT, bool REV = false>
 __device__ __forceinline__ void mean_field(unsigned char *smem, const FusedLayout &lay, const int (&V)[K], int N, int tid,
                                            PointRegs<PPT, K> &pr, const ChainLane &cl, const float (&alpha)[K], int n_iter,
                                            float relax, Instr &ins, int first_p = -1)
@@ -543,7 +553,7 @@ __device__ __forceinline__ void mean_field(unsigned char *smem, const FusedLayou
         }
         for (int it = 0; it < n_iter; ++it) {
             opaque(pr);
-            splat_blur<PPT, K, CH, false, NT>(smem, lay, V, N, tid, pr, cl, ins);
+            splat_blur<PPT, K, CH, false, NT, (1 << K) - 1, REV>(smem, lay, V, N, tid, pr, cl, ins);
             const bool more = it + 1 < n_iter;
 #pragma unroll
             for (int s = 0; s < PPT; ++s) {
@@ -561,7 +571,7 @@ __device__ __forceinline__ void mean_field(unsigned char *smem, const FusedLayou
     }
     for (int it = 0; it < n_iter; ++it) {
         opaque(pr);
-        splat_blur<PPT, K, CH, true, NT>(smem, lay, V, N, tid, pr, cl, ins);
+        splat_blur<PPT, K, CH, true, NT, (1 << K) - 1, REV>(smem, lay, V, N, tid, pr, cl, ins);
 #pragma unroll
         for (int s = 0; s < PPT; ++s)
             if (tid + s * NT < N) point_update(s);
