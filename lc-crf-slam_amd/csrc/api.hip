@@ -89,7 +89,9 @@ struct Arena {
     int alloc_pinned(T **out, size_t count)
     {
         void *p = nullptr;
-        HIP_TRY(hipHostMalloc(&p, (count ? count : 1) * sizeof(T), hipHostMallocDefault));
+        // fine-grained (coherent) on purpose, not left to HIP_HOST_COHERENT: kernels publish status words, done words and labels
+        // here and the host reads them while the kernel is still running
+        HIP_TRY(hipHostMalloc(&p, (count ? count : 1) * sizeof(T), hipHostMallocCoherent));
         pinned.push_back(p);
         *out = static_cast<T *>(p);
         return LCCRF_OK;
