@@ -183,10 +183,8 @@ __global__ void __launch_bounds__(NT, 4) k_frame(CrfDev c, FrameArgs a)
     // the helper's way out when its lattice cannot be handed over: tell the main workgroup (which then flags the frame)
     auto helper_fail = [&]() {
         if (tid == 0) {
-            xs[2] = 1u;
-            __threadfence();
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __hip_atomic_store(&xs[0], a.dual_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(reinterpret_cast<unsigned long long *>(xs), (unsigned long long)a.dual_epoch | (0x80000000ull << 32),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);        // (nothing to publish but the word itself)
         }
     };
     const int Npad = (N + 3) & ~3;                       // blocks of four, permutohedral_cpu.h:294 (quirk Q1)
@@ -675,11 +673,12 @@ __global__ void __launch_bounds__(NT, 4) k_frame(CrfDev c, FrameArgs a)
         }
         __syncthreads();
         if (tid == 0) {                                   // plain stores -> barrier -> one agent-scope release -> drained -> relaxed flag store
-            xs[1] = (unsigned)Vk;
-            xs[2] = 0u;
             __threadfence();
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __hip_atomic_store(&xs[0], a.dual_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // ONE 8-byte word carries the epoch and the vertex count (bit 63: "could not be handed over"): the reader's
+            // poll is a single round trip to memory, not three
+            __hip_atomic_store(reinterpret_cast<unsigned long long *>(xs), (unsigned long long)a.dual_epoch | ((unsigned long long)(unsigned)Vk << 32),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         FL_STAMP();
         if (kInstr && a.timing && (int)blockIdx.x == a.timing_block && tid == a.timing_lane) a.timing[63] = ins.n;
@@ -716,13 +715,15 @@ __global__ void __launch_bounds__(NT, 4) k_frame(CrfDev c, FrameArgs a)
         FL_STAMP();
         if (tid == 0) {
             int ok = 0;
+            unsigned long long word = 0;
             for (int spin = 0; spin < (1 << 22); ++spin) {
-                if (dual_load(&xs[0]) == a.dual_epoch) { ok = 1; break; }
+                word = dual_load2(xs);
+                if ((unsigned)word == a.dual_epoch) { ok = 1; break; }
                 __builtin_amdgcn_s_sleep(2);
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            hdr->dual_ok = (ok && dual_load(&xs[2]) == 0u) ? 1 : 0;
-            hdr->dual_V = (int)dual_load(&xs[1]);
+            hdr->dual_ok = (ok && !(word >> 63)) ? 1 : 0;
+            hdr->dual_V = (int)((word >> 32) & 0x7fffffffu);
         }
         __syncthreads();
         const int Vk = __builtin_amdgcn_readfirstlane(hdr->dual_V);        // (scalar: every LDS offset below derives from it)
