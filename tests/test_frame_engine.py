@@ -396,7 +396,8 @@ def test_two_workgroup_form_gives_the_same_bits(wl):
     """Single frames through the object API run the frame kernel as TWO workgroups (one per lattice build, hand-off through
     device memory: frame_engine.hip DUAL).  LCCRF_NO_DUAL=1 in a child process is the one-workgroup form: same bits for every
     points-per-lane shape, a one-kernel CRF (not split), a sparse frame (the helper's lattice does not fit beside the main
-    workgroup's: fallback) and alternating sizes (the hand-off area is reused by every frame)."""
+    workgroup's: fallback) and alternating sizes (the hand-off area is reused by every frame); batches of 3 and 64 frames
+    (two workgroups per frame as well) and of 65 (one each)."""
     code = r"""
 import importlib, sys, numpy as np
 sys.path.insert(0, %r); sys.path.insert(0, %r)
@@ -415,6 +416,12 @@ for pb in (_shaped_problem(wl, 1200, "sparse", seed=5), _shaped_problem(wl, 2000
     h.inference(4, True); out.append(h.probability()); h.close()
     h = pkg.DenseCRFHIP(pb["N"], pb["L"]); h.set_unary_from_label(pb["label"], pb["conf"])
     h.add_pairwise(*pb["kernels"][1]); h.inference(3, True); out.append(h.probability()); h.close()
+# small batches take the same form (up to 64 frames); 65 frames do not
+from test_frame_engine import _batch_of
+for F in (3, 64, 65):
+    pbs = [wl.slam_problem(int(n), seed=900 + i) for i, n in enumerate(np.random.default_rng(F).integers(1, 2300, F))]
+    if F == 3: pbs[1] = _shaped_problem(wl, 1200, "sparse", seed=7)      # one frame of the batch falls back
+    b = _batch_of(pbs); b.run(5, True); out.append(b.probability()); out.append(b.map().astype(np.float32)); b.close()
 np.save(sys.argv[1], np.concatenate([o.ravel() for o in out]))
 """ % (ROOT, os.path.join(ROOT, "tests"))
     res = []
