@@ -63,6 +63,7 @@ struct FrameArgs {
     int *frame_status;                    // device [F] or null: 1 for exactly the frames that did not fit (they alone are re-run), else 0
     unsigned *dual;                       // DUAL launches: [F][kDualWords] hand-off area between a frame's two workgroups, else null
     unsigned dual_epoch;                  //   value the helper publishes in word 0 when its tables are complete (changes every launch)
+    int n_single;                         // >= 0: the point count of the launch's only frame (else c.n_points[f])
     unsigned *done;                       // single-frame launches: pinned host word that receives done_epoch when the frame's results (labels in
     unsigned done_epoch;                  //   pinned memory, status words) are visible to the host -- earlier than the runtime's completion signal
     long long *timing;                    // instrumented builds only
@@ -151,7 +152,8 @@ __global__ void __launch_bounds__(NT, 4) k_frame(CrfDev c, FrameArgs a)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int f = DUAL ? (int)(blockIdx.x >> 1) : (int)blockIdx.x, tid = threadIdx.x;
     const int role = DUAL ? (int)(blockIdx.x & 1) : 0;    // DUAL: 0 = the frame's main workgroup, 1 = the helper that builds kernel 1
-    const int N = c.n_points[f];
+    const int N = a.n_single >= 0 ? a.n_single : c.n_points[f];     // (a single frame's count rides in the kernel arguments:
+                                                                    //  c.n_points is pinned host memory there, a PCIe round trip away)
     Instr ins{a.timing, a.timing_block, 8, 0, a.timing_lane};
     FL_STAMP();
     // The last thing the frame's main workgroup does (uniform; every lane): results first, then the word the host polls.
@@ -881,6 +883,7 @@ bool launch_frame(const CrfDev &c, const KernelDev *kds, int n_iter, int with_ma
     a.dual = dual;
     a.dual_epoch = dual_epoch;
     a.done = c.F == 1 ? done : nullptr;
+    a.n_single = (c.F == 1 && done && c.activeN > 0) ? c.activeN : -1;   // (object API: activeN IS the frame's count)
     a.done_epoch = done_epoch;
     static long long *timing_buf = nullptr;
     static const bool want_timing = kInstr && getenv("LCCRF_FRAME_TIMING") != nullptr;
