@@ -718,7 +718,7 @@ __global__ void __launch_bounds__(NT, 4) k_frame(CrfDev c, FrameArgs a)
         if (tid == 0) {
             int ok = 0;
             unsigned long long word = 0;
-            for (int spin = 0; spin < (1 << 22); ++spin) {
+            for (int spin = 0; spin < (1 << 17); ++spin) {     // (~0.1 s at a memory round trip per poll: then the frame falls back)
                 word = dual_load2(xs);
                 if ((unsigned)word == a.dual_epoch) { ok = 1; break; }
                 __builtin_amdgcn_s_sleep(2);
