@@ -64,6 +64,7 @@ struct FrameArgs {
     unsigned *dual;                       // DUAL launches: [F][kDualWords] hand-off area between a frame's two workgroups, else null
     unsigned dual_epoch;                  //   value the helper publishes in word 0 when its tables are complete (changes every launch)
     int n_single;                         // >= 0: the point count of the launch's only frame (else c.n_points[f])
+    int drop_helper;                      // test aid (LCCRF_DUAL_DROP_HELPER): the helper workgroup leaves at once -- the main one must time out and fall back
     unsigned *done;                       // single-frame launches: pinned host word that receives done_epoch when the frame's results (labels in
     unsigned done_epoch;                  //   pinned memory, status words) are visible to the host -- earlier than the runtime's completion signal
     long long *timing;                    // instrumented builds only
@@ -181,6 +182,7 @@ __global__ void __launch_bounds__(NT, 4) k_frame(CrfDev c, FrameArgs a)
         }
         return;
     }
+    if (DUAL && role == 1 && a.drop_helper) return;
     unsigned *xs = DUAL ? a.dual + (size_t)f * kDualWords : nullptr;
     // the helper's way out when its lattice cannot be handed over: tell the main workgroup (which then flags the frame)
     auto helper_fail = [&]() {
@@ -883,6 +885,8 @@ bool launch_frame(const CrfDev &c, const KernelDev *kds, int n_iter, int with_ma
     a.dual = dual;
     a.dual_epoch = dual_epoch;
     a.done = c.F == 1 ? done : nullptr;
+    static const bool drop_helper = getenv("LCCRF_DUAL_DROP_HELPER") != nullptr;
+    a.drop_helper = drop_helper ? 1 : 0;
     a.n_single = (c.F == 1 && done && c.activeN > 0) ? c.activeN : -1;   // (object API: activeN IS the frame's count)
     a.done_epoch = done_epoch;
     static long long *timing_buf = nullptr;

@@ -433,6 +433,34 @@ np.save(sys.argv[1], np.concatenate([o.ravel() for o in out]))
     assert cc.same_bits(res[0], res[1])
 
 
+def test_a_helper_that_never_comes_cannot_hang_the_launch(po, wl):
+    """LCCRF_DUAL_DROP_HELPER (child process): the helper workgroup of the two-workgroup form leaves at once.  The main workgroup's
+    poll is bounded (~0.1 s), the frame flags itself and is re-run on the two-kernel path: same labels, same Q, no hang."""
+    code = r"""
+import importlib, sys, time, numpy as np
+sys.path.insert(0, %r)
+pkg = importlib.import_module("lc-crf-slam_amd"); wl = importlib.import_module("lc-crf-slam_amd.workloads")
+pb = wl.slam_problem(1500, seed=77)
+out = []
+t0 = time.perf_counter()
+for rep in range(2):
+    h = pkg.DenseCRFHIP(pb["N"], pb["L"]); h.set_unary_from_label(pb["label"], pb["conf"])
+    for f, w in pb["kernels"]: h.add_pairwise(f, w)
+    h.inference(5, True); out.append(h.map().astype(np.float32)); out.append(h.probability().ravel()); h.close()
+np.save(sys.argv[1], np.concatenate(out + [np.float32([time.perf_counter() - t0])]))
+""" % ROOT
+    path = os.path.join(ROOT, "gpurun_out", "drop_helper.npy")
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    subprocess.run([sys.executable, "-c", code, path], check=True, env=dict(os.environ, LCCRF_DUAL_DROP_HELPER="1"), timeout=120)
+    res = np.load(path)
+    pb = wl.slam_problem(1500, seed=77)
+    o = cc.setup(po.OracleCRF, pb)
+    o.inference_native(5, True)
+    want = np.concatenate([o.map().astype(np.float32), o.probability().ravel()])
+    assert cc.same_bits(res[:want.size], want) and cc.same_bits(res[want.size:2 * want.size], want)
+    assert res[-1] < 20.0                                   # two bounded waits + two re-runs + the child's start-up
+
+
 def test_frame_kernel_many_copies_are_identical(wl):
     """Race hunt: 1536 frames in flight (6 per CU), three distinct frames tiled, three runs -- every copy must equal its
     original bit for bit, every time (workgroups of different frames share nothing but the kernel's code)."""
