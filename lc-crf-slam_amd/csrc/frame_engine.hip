@@ -182,7 +182,6 @@ __global__ void __launch_bounds__(NT, 4) k_frame(CrfDev c, FrameArgs a)
         }
         return;
     }
-    if (DUAL && role == 1 && a.drop_helper) return;
     unsigned *xs = DUAL ? a.dual + (size_t)f * kDualWords : nullptr;
     // the helper's way out when its lattice cannot be handed over: tell the main workgroup (which then flags the frame)
     auto helper_fail = [&]() {
@@ -664,6 +663,7 @@ __global__ void __launch_bounds__(NT, 4) k_frame(CrfDev c, FrameArgs a)
         place_products<PPT, K, 2, NT, 2>(smem, lay, N, tid, pk, pr);
         normalise(std::integral_constant<int, 2>{});
         FL_STAMP();
+        if (a.drop_helper) return;                        // (test aid: the main workgroup must time out and fall back)
         const unsigned *nb = reinterpret_cast<const unsigned *>(smem + lay.nbr[1]);
         for (int u = tid; u < D1 * Vk; u += NT) xs[kDualNbr + u] = nb[u];
         const unsigned *rw = reinterpret_cast<const unsigned *>(smem + lay.row[1]);      // (Vk + 2) u16, the area is 4-byte aligned
