@@ -96,6 +96,67 @@ class CudaView:
                                              version=2)
 
 
+def check_distinct_frames(pbs, idx, M, Q, n_iter):
+    """Parity gate as a COVER: every distinct frame of the batch against the CPU checker -- labels identical,
+    max |dQ|.  Returns (frames checked, label match, max |dQ|)."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pyoracle as po
+    same = tot = 0
+    max_dq = 0.0
+    for i, pb in enumerate(pbs):
+        o = po.OracleCRF(pb["N"], pb["L"])
+        o.set_unary_from_label(pb["label"], pb["conf"])
+        for f, w in pb["kernels"]:
+            o.add_pairwise(f, w)
+        o.inference_native(n_iter, True)
+        fidx = idx.index(i)
+        same += int((M[fidx] == o.map()).sum())
+        tot += pb["N"]
+        max_dq = max(max_dq, float(np.abs(Q[fidx] - o.probability()).max()))
+        o.close()
+    return len(pbs), same / max(tot, 1), max_dq
+
+
+def longest_rows(pkg, pbs, kernel=0, limit=8):
+    """Mean over (up to `limit`) distinct frames of the longest splat row of `kernel` -- the number of products ONE lane adds
+    strictly left to right per label and iteration (quirk Q6) -- from this library's own lattice probe (lccrf_get_lattice)."""
+    import numpy as np
+    rows = []
+    for pb in pbs[:limit]:
+        h = pkg.DenseCRFHIP(pb["N"], pb["L"])
+        h.set_unary_from_label(pb["label"], pb["conf"])
+        for f, w in pb["kernels"]:
+            h.add_pairwise(f, w)
+        rows.append(int(np.bincount(h.kernel(kernel)["offset"].ravel()).max()))
+        h.close()
+    return float(np.mean(rows))
+
+
+def chain_floor(row, n_iter, F, N=2000):
+    """Latency floor of the ordered row sums: one dependent fp32 add per product, 5.1 cycles each
+    (scripts/ubench/chain.hip), the longest row once per mean-field iteration, one frame per CU at a time (two for the
+    512-lane shapes of frames up to 1024 points: their chains overlap)."""
+    return 5.1 * row * n_iter / CLK_HZ * F / (N_CU * (2 if N <= 1024 else 1)) * 1e3
+
+
+def tiles_identical(torch, b, dev, F, N, idx):
+    """... and every tiled slot of the batch against its source slot ON THE DEVICE, bit for bit (Q as int32 patterns, labels):
+    with the check above this covers all F frames of the timed batch, not a sample."""
+    map_ptr, prob_ptr = b.device_buffers()
+    Q = torch.as_tensor(CudaView(prob_ptr, (F, N * 2), "<i4"), device=dev)
+    M = torch.as_tensor(CudaView(map_ptr, (F, N), "<i2"), device=dev)
+    first = {}
+    for f, i in enumerate(idx):
+        first.setdefault(i, f)
+    src = torch.tensor([first[i] for i in idx], dtype=torch.int64, device=dev)
+    ok = True
+    for lo in range(0, F, 2048):                       # (chunks: the gathered copy stays small)
+        hi = min(lo + 2048, F)
+        ok = ok and bool(torch.equal(Q[lo:hi], Q[src[lo:hi]])) and bool(torch.equal(M[lo:hi], M[src[lo:hi]]))
+    return ok
+
+
 def make_batch(wl, name, F, rank, distinct):
     """F frames for this rank: `distinct` different synthetic frames, tiled."""
     import numpy as np
@@ -326,19 +387,8 @@ def slam_subrecord(pkg, wl, torch, dev, name, steps=10, warmup=3, distinct=32):
         ms.append(b.last_timing()["inference_ms"])
     inf_ms = float(np.median(ms))
     M, Q = b.map(), b.probability()
-    same = tot = 0
-    max_dq = 0.0
-    for i in range(2):
-        pb = pbs[i]
-        o = po.OracleCRF(pb["N"], pb["L"])
-        o.set_unary_from_label(pb["label"], pb["conf"])
-        for f, w in pb["kernels"]:
-            o.add_pairwise(f, w)
-        o.inference_native(n_iter, True)
-        same += int((M[idx.index(i)] == o.map()).sum())
-        tot += pb["N"]
-        max_dq = max(max_dq, float(np.abs(Q[idx.index(i)] - o.probability()).max()))
-        o.close()
+    frames_checked, label_match, max_dq = check_distinct_frames(pbs, idx, M, Q, n_iter)
+    tiles_ok = tiles_identical(torch, b, dev, F, N, idx)
     for _ in range(2):
         b.run(n_iter, True)
     b.synchronize()
@@ -349,6 +399,7 @@ def slam_subrecord(pkg, wl, torch, dev, name, steps=10, warmup=3, distinct=32):
     run_ms = (time.perf_counter() - t0) / max(steps // 2, 3) * 1e3
     run_engine, fb = b.engine(), b.fallback_frames()
     lds_bytes, lds_clocks, _ = fused_lds_model(N, dims, Vs, True)
+    row = longest_rows(pkg, pbs)
     t_floor = lds_clocks * n_iter * F / N_CU / CLK_HZ
     achieved = lds_bytes * n_iter * F / (inf_ms * 1e-3) / 1e9
     peak = lds_bytes * n_iter * F / t_floor / 1e9
@@ -356,11 +407,13 @@ def slam_subrecord(pkg, wl, torch, dev, name, steps=10, warmup=3, distinct=32):
            "engine": {1: "streaming", 2: "fused"}.get(engine, str(engine)), "mean_lattice_vertices": Vs,
            "roofline": {"bound": "lds" if engine == 2 else "hbm", "achieved": achieved, "peak": peak, "unit": "GB/s",
                         "frac": achieved / peak, "launch_ms": inf_ms, "lds_bytes_per_iteration_frame": lds_bytes,
+                        "lds_floor_ms": t_floor * 1e3, "longest_row": row, "chain_floor_ms": chain_floor(row, n_iter, F, N),
                         "algorithmic_hbm_bytes_per_iteration_frame": algorithmic_bytes_per_iter(N, 2, dims, Vs)},
            "build_ms_per_batch": build_ms,
            "end_to_end": {"one_launch_ms_per_batch": run_ms, "one_launch_engine": run_engine, "fallback_frames": fb,
                           "frames_per_s": F / (run_ms * 1e-3), "two_kernel_ms_per_batch": build_ms + inf_ms},
-           "label_match_vs_cpu_reference": same / tot, "max_abs_dQ_vs_cpu_reference": max_dq}
+           "label_match_vs_cpu_reference": label_match, "max_abs_dQ_vs_cpu_reference": max_dq,
+           "frames_checked": frames_checked, "tiles_identical": tiles_ok}
     b.close()
     del d_feats, d_label, d_np
     torch.cuda.empty_cache()
@@ -431,15 +484,14 @@ def c5_record(pkg, wl, torch, dev, steps=6, frames=8):
                                "requested_bytes_per_launch_gathers_included": 40.0 * nv,
                                "requested_gbs_gathers_included": 40.0 * nv / (blur_ms * 1e-3) / 1e9}
             M, Q = b.map(), b.probability()
-            o = po.OracleCRF(N, 2)
-            o.set_unary_from_label(pbs[0]["label"], pbs[0]["conf"])
-            o.add_pairwise(*pbs[0]["kernels"][0])
-            o.inference_native(n_iter, True)
-            rec["label_match_vs_cpu_reference"] = float((M[0] == o.map()).mean())
-            rec["max_abs_dQ_vs_cpu_reference"] = float(np.abs(Q[0] - o.probability()).max())
-            o.close()
+            fc, lm, dq = check_distinct_frames(pbs[:min(F, len(pbs))], idx, M, Q, n_iter)
+            rec["label_match_vs_cpu_reference"], rec["max_abs_dQ_vs_cpu_reference"] = lm, dq
+            rec["frames_checked"], rec["tiles_identical"] = fc, tiles_identical(torch, b, dev, F, N, idx)
             out.update(rec)
         else:
+            M, Q = b.map(), b.probability()
+            fc, lm, dq = check_distinct_frames(pbs[:1], idx, M, Q, n_iter)
+            rec["label_match_vs_cpu_reference"], rec["max_abs_dQ_vs_cpu_reference"], rec["frames_checked"] = lm, dq, fc
             out["single_frame"] = rec
         b.close()
         del f, lab, npt
@@ -660,26 +712,11 @@ def main():
     # parity gate on the timed configuration: labels vs the CPU reference path
     label_match = None
     max_dq = None
+    frames_checked = tiles_ok = None
     if rank == 0 and not args.no_check:
-        sys.path.insert(0, os.path.join(ROOT, "oracle"))
-        import pyoracle as po
         M, Q = b.map(), b.probability()
-        n_chk = min(distinct, 4 if name != "c5" else 1)
-        same = tot = 0
-        max_dq = 0.0
-        for i in range(n_chk):
-            pb = pbs[i]
-            o = po.OracleCRF(pb["N"], pb["L"])
-            o.set_unary_from_label(pb["label"], pb["conf"])
-            for f, w in pb["kernels"]:
-                o.add_pairwise(f, w)
-            o.inference_native(n_iter, True)
-            fidx = idx.index(i)
-            same += int((M[fidx] == o.map()).sum())
-            tot += pb["N"]
-            max_dq = max(max_dq, float(np.abs(Q[fidx] - o.probability()).max()))
-            o.close()
-        label_match = same / tot
+        frames_checked, label_match, max_dq = check_distinct_frames(pbs[:distinct], idx, M, Q, n_iter)   # EVERY distinct frame ...
+        tiles_ok = tiles_identical(torch, b, dev, F, N, idx)                                             # ... and every tile of each
 
     if rank == 0:
         total_iters = float(F) * n_iter * args.steps * world
@@ -692,6 +729,7 @@ def main():
             # per-frame records once per launch.  Its roof is the CU's LDS pipe.
             chain0 = True                                           # SLAM frames: the appearance kernel takes the chain path
             lds_bytes, lds_clocks, by = fused_lds_model(N, dims, Vs, chain0)
+            row = longest_rows(pkg, pbs)
             lds_launch = lds_bytes * n_iter * F
             t_floor = lds_clocks * n_iter * F / N_CU / CLK_HZ       # every CU streaming at the per-instruction peak
             achieved = lds_launch / launch_s / 1e9
@@ -702,6 +740,10 @@ def main():
                     "traffic": traffic,
                     "kernel": "inference launch (start + %d mean-field iterations + map), HIP events" % n_iter,
                     "launch_ms": inf_ms, "lds_bytes_per_iteration_frame": lds_bytes,
+                    "lds_floor_ms": t_floor * 1e3, "longest_row": row, "chain_floor_ms": chain_floor(row, n_iter, F, N),
+                    "chain_floor_note": "the appearance kernel's longest row is a strictly sequential fp32 sum (one lane per label): 5.1 cycles "
+                                        "x longest row x n_iter per frame / 2.4 GHz x frames / 256 CUs -- the latency floor next to the LDS "
+                                        "floor (lds_floor_ms); one frame per CU, so the two do not overlap across frames",
                     "lds_bytes_by_instruction": by,
                     "peak_note": "instruction-mix-weighted LDS peak: bytes / sum(bytes_i / rate_i), rates per CU and clock "
                                  "from MI355X_MICROARCH.md (ds_read_b64/b128 256, ds_read_b32 128, ds_write_b32 64, "
@@ -747,6 +789,8 @@ def main():
                                    "events of lccrf_batch_build + lccrf_batch_inference"},
             "label_match_vs_cpu_reference": label_match,
             "max_abs_dQ_vs_cpu_reference": max_dq,
+            "frames_checked": frames_checked,        # distinct frames compared with the CPU checker (all of them)
+            "tiles_identical": tiles_ok,             # every one of the F slots equals its source frame bit for bit (Q and labels, on the device)
         }
         if gather_ok is not None:
             out["label_gather_ok"] = gather_ok

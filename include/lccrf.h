@@ -68,6 +68,21 @@ int  lccrf_create(lccrf_handle *out, int device_id, int n_points, int n_labels);
 void lccrf_destroy(lccrf_handle h);
 int  lccrf_trim_cache(void);
 
+/* Options (no reference counterpart; none can change a result).
+ *   LCCRF_OPT_SINGLE_WORKGROUP   value != 0: a frame is never given two workgroups.  By default a single two-kernel frame (and a
+ *       batch of up to 64) runs as TWO workgroups on two CUs, one per lattice build, handing tables over through device memory
+ *       (-8 us at 2000 keypoints).  The main workgroup waits for its helper with a bounded poll: if the helper is not
+ *       co-scheduled -- a GPU shared with other processes or streams whose kernels hold every CU -- the frame stalls for up to
+ *       ~0.05-0.1 s (three frames of a 30 fps tracker) before it falls back to the ordinary path, with the same labels.  A tracker
+ *       that shares its GPU sets this option and pays the 8 us instead.
+ * lccrf_set_option applies to one handle (set it after lccrf_create: a handle taken from the cache starts from the defaults);
+ * lccrf_set_default_option to every handle and batch created afterwards in this process.                                      */
+typedef enum lccrf_option {
+    LCCRF_OPT_SINGLE_WORKGROUP = 1
+} lccrf_option;
+int  lccrf_set_option(lccrf_handle h, int option, int value);
+int  lccrf_set_default_option(int option, int value);
+
 /* DenseCRF::setUnaryEnergy(const float*)        densecrf3d.h:41-43                    */
 int  lccrf_set_unary(lccrf_handle h, const float *unary);
 /* DenseCRF::setUnaryEnergyFromLabel(const short*, float*)   densecrf3d.h:107-130;
@@ -154,6 +169,8 @@ typedef struct lccrf_batch_desc {
 
 int  lccrf_batch_create(lccrf_batch_handle *out, int device_id, const lccrf_batch_desc *desc);
 void lccrf_batch_destroy(lccrf_batch_handle b);
+/* lccrf_set_option for a batch (LCCRF_OPT_SINGLE_WORKGROUP: batches of up to 64 two-kernel frames take two workgroups per frame) */
+int  lccrf_batch_set_option(lccrf_batch_handle b, int option, int value);
 
 /* Host inputs (copied to the device).  n_points[f] <= max_points; arrays are strided by
  * max_points per frame.  Exactly one of unary / label must be non-NULL.                 */

@@ -353,6 +353,8 @@ public:
         lccrf_check(lccrf_get_lattice_size(h_, kernel, &V), "lccrf_get_lattice_size");
         return V;
     }
+    // lccrf_set_option (include/lccrf.h), e.g. setOption(LCCRF_OPT_SINGLE_WORKGROUP, 1) for a tracker on a shared GPU
+    void setOption(int option, int value) { lccrf_check(lccrf_set_option(h_, option, value), "lccrf_set_option"); }
     // see the header comment: true = every inference call ends with Q in the buffer DenseCRF::getProbability() returns
     void syncThroughBase(bool on) { base_sync_ = on; }
     bool syncsThroughBase() const { return base_sync_; }

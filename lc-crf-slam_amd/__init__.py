@@ -23,6 +23,7 @@ LIB_PATH = os.environ.get("LCCRF_LIB") or os.path.join(_HERE, "liblccrf_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "lccrf.h")
 
 MAX_KERNELS = 8
+OPT_SINGLE_WORKGROUP = 1        # lccrf_option (include/lccrf.h)
 OK = 0
 _STATUS = {0: "OK", -1: "E_INVALID", -2: "E_NO_DEVICE", -3: "E_HIP", -4: "E_NOMEM", -5: "E_STATE",
            -6: "E_CAPACITY"}
@@ -78,6 +79,9 @@ def lib():
     L.lccrf_destroy.argtypes = [vp]
     L.lccrf_destroy.restype = None
     L.lccrf_trim_cache.argtypes = []
+    L.lccrf_set_option.argtypes = [vp, C.c_int, C.c_int]
+    L.lccrf_batch_set_option.argtypes = [vp, C.c_int, C.c_int]
+    L.lccrf_set_default_option.argtypes = [C.c_int, C.c_int]
     L.lccrf_set_unary.argtypes = [vp, _f32p]
     L.lccrf_set_unary_from_label.argtypes = [vp, _i16p, _f32p]
     L.lccrf_add_pairwise.argtypes = [vp, _f32p, C.c_int, C.c_float]
@@ -137,6 +141,10 @@ def _check(rc):
         raise LccrfError(rc, lib().lccrf_last_error().decode("utf-8", "replace"))
 
 
+def set_default_option(option, value):
+    _check(lib().lccrf_set_default_option(int(option), int(value)))
+
+
 def device_count():
     n = C.c_int(0)
     _check(lib().lccrf_device_count(C.byref(n)))
@@ -167,6 +175,9 @@ class DenseCRFHIP:
             self.h = None
 
     __del__ = close
+
+    def set_option(self, option, value):
+        _check(lib().lccrf_set_option(self.h, int(option), int(value)))
 
     # -- unary -------------------------------------------------------------------------
     def set_unary(self, unary):
@@ -301,6 +312,9 @@ class BatchCRF:
             self.h = None
 
     __del__ = close
+
+    def set_option(self, option, value):
+        _check(lib().lccrf_batch_set_option(self.h, int(option), int(value)))
 
     def set_inputs_host(self, n_points, features, unary=None, label=None, conf=None):
         npts = np.ascontiguousarray(n_points, np.int32)

@@ -44,6 +44,16 @@ int fail(int code, const char *fmt, ...)
                         #expr, hipGetErrorString(e_));                                       \
     } while (0)
 
+// spin-wait hint of the host polls below (the library must build on non-x86 ROCm hosts too)
+inline void cpu_relax()
+{
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#elif defined(__aarch64__)
+    asm volatile("yield" ::: "memory");
+#endif
+}
+
 int next_pow2(long v)
 {
     long p = 16;
@@ -66,8 +76,10 @@ int use_device(int device_id)
 // Owns every device / pinned allocation of one engine.
 struct Arena {
     std::vector<void *> dev, pinned;
-    // Allocations are zeroed ON THE OWNER'S STREAM.  hipMemset on the null stream is asynchronous
-    // and the engine streams are non-blocking, i.e. unordered with the null stream: a null-stream
+    // Allocations are zeroed ON THE STREAM THE OWNER'S WORK IS ISSUED ON (StreamScope retargets this together with
+    // Engine::stream while a batch call runs on a caller's stream: a lazily allocated buffer zeroed on the engine's
+    // own stream would be unordered with the kernels of that call -- ADVICE r3).  hipMemset on the null stream is
+    // asynchronous and the engine streams are non-blocking, i.e. unordered with the null stream: a null-stream
     // memset could land after the first copy into the new buffer (seen as a one-in-hundreds lattice
     // of all-zero features).
     hipStream_t stream = nullptr;
@@ -175,6 +187,7 @@ struct Engine {
     bool frame_small_ok = true;        // small frames may run as 512-lane workgroups (two per CU); turned off for this engine when
     bool frame_small_used = false;     //   more than 1/8 of a batch's frames did not fit that plan
     static constexpr int kDualMaxFrames = 64;    // (measured, `scripts/small_batch_latency.py`: 4 frames 98 -> 86 us, 32 frames 93 -> 83 us, 128 frames 112 -> 114 us)
+    bool opt_single_wg = false;        // LCCRF_OPT_SINGLE_WORKGROUP: never the two-workgroup form (lccrf_set_option)
     unsigned *dual_area = nullptr;     // hand-off area of the two-workgroup form of the frame kernel (batches of up to kDualMaxFrames frames)
     unsigned dual_epoch = 0;
     // object API: the frame kernel's last act is a store of `done_epoch` into this pinned word, behind its results; the host
@@ -187,6 +200,8 @@ struct Engine {
     int16_t *map_host = nullptr;       // the handle's pinned label array (= crf.map), or null
     bool labels_armed = false;
     bool idle_by_done = false;         // the last call on the handle was a getMap() that saw the done word: nothing is in flight
+    bool idle_needs_done = false;      //   ... or every label (the stores right before the done word): the word itself is still to come
+    bool park_check = false;           // parked with that word still unseen: ensure_parked_idle() settles it for the next user
     int late_iter = 0, late_map = 0;
     float late_relax = 1.0f;
     bool timed_build = false, timed_inf = false;
@@ -267,6 +282,7 @@ struct Engine {
 
     void destroy()
     {
+        park_check = false;
         if (stream) (void)hipStreamSynchronize(stream);
         if (fb) {
             fb->destroy();
@@ -332,6 +348,9 @@ struct Engine {
         if ((rc = mem.alloc(&k.V, Fz))) return rc;
         if ((rc = mem.alloc(&k.rowmax, Fz))) return rc;
         if ((rc = mem.alloc(&k.nbr, Fz * k.D1 * E * 2))) return rc;
+        // one frame in flight, large frames (the object API's handles are sized for SLAM frames, which run on the one-workgroup engines):
+        // the blur passes go two per launch and read a two-hop neighbour table
+        if (Fcap == 1 && L == 2 && allow_perm && (rc = mem.alloc(&k.nbr2, (size_t)(k.D1 / 2) * E * 8))) return rc;
         if ((rc = mem.alloc(&k.rowptr, Fz * (E + 1)))) return rc;
         if ((rc = mem.alloc(&k.csr_pt, Fz * E))) return rc;
         if ((rc = mem.alloc(&k.csr_w, Fz * E))) return rc;
@@ -353,13 +372,34 @@ struct Engine {
         return LCCRF_OK;
     }
 
+    // A parked engine whose last frame was taken label by label: its kernel is over once the done word shows this frame's epoch
+    // (the kernel's very last store); normally that happened long ago, otherwise wait for the stream the ordinary way.
+    void ensure_parked_idle()
+    {
+        if (!park_check) return;
+        park_check = false;
+        const volatile unsigned *w = done_word;
+        const auto t0 = std::chrono::steady_clock::now();
+        bool seen = false;
+        for (unsigned spins = 1; !(seen = (*w == done_epoch)); ++spins) {
+            if ((spins & 0x3f) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(50)) break;
+            cpu_relax();
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+        if (!seen && stream) (void)hipStreamSynchronize(stream);
+    }
+
     // Park everything for the next user of this engine (object API handle cache).
     void recycle()
     {
         // (a synchronisation that starts after the kernel has ended costs ~10 us: the runtime queues a barrier packet and
         // waits for its round trip; the done word has already told us that nothing is in flight)
-        if (stream && !idle_by_done) (void)hipStreamSynchronize(stream);
-        idle_by_done = false;
+        // getMap() saw every label land: the kernel's last stores (V_out, frame_status, the done word) follow within a microsecond or
+        // two.  Nobody waits for them here (the tracker's next frame is 33 ms away); the next user of this handle settles it before it
+        // touches anything the kernel could still read or write (ensure_parked_idle, called by lccrf_create).
+        if (stream && idle_by_done && idle_needs_done) park_check = true;
+        else if (stream && !idle_by_done) (void)hipStreamSynchronize(stream);
+        idle_by_done = idle_needs_done = false;
         labels_armed = done_armed = false;
         for (auto &ks : kernels) spare.push_back(ks);
         kernels.clear();
@@ -431,9 +471,11 @@ struct Engine {
             const int NA = activeN > 0 ? activeN : maxN;
             if (!no_small && k + 1 < k0 + n && build_small_supported(&kdevs[k], 2, NA)) m = 2;
             if (!no_small && build_small_supported(&kdevs[k], m, NA)) {
+                for (int u = 0; u < m; ++u) kernels[k + u].dev.nbr2_ok = 0;
                 launch_build_small(&kdevs[k], m, NA, crf, stream);   // writes V / rowmax to the pinned mirrors itself
             } else {
                 m = 1;
+                kernels[k].dev.nbr2_ok = kernels[k].dev.nbr2 != nullptr;      // (the streaming build fills the two-hop table when there is one)
                 launch_build_kernel(kdevs[k], crf, kernels[k].maxV, stream);
                 launch_norm(kdevs[k], crf, kernels[k].maxV, stream);
                 HIP_TRY(hipMemcpyAsync(V_host + (size_t)k * Fcap, kernels[k].dev.V, sizeof(int) * F, hipMemcpyDeviceToHost, stream));
@@ -442,6 +484,7 @@ struct Engine {
             k += m;
         }
         HIP_TRY(hipGetLastError());
+        sync_views();                                       // (nbr2_ok)
         sizes_known = false;
         return LCCRF_OK;
     }
@@ -553,7 +596,7 @@ struct Engine {
         unsigned *dual = nullptr;
         // The tracker's case (one frame, 255 idle CUs) and small batches (a quarter as many frames as CUs, or fewer): every
         // frame gets two workgroups, one per lattice build.
-        if (crf.K == 2 && F <= kDualMaxFrames) {
+        if (crf.K == 2 && F <= kDualMaxFrames && !opt_single_wg) {
             if (!dual_area) {
                 int rc = mem.alloc(reinterpret_cast<char **>(&dual_area), frame_dual_bytes(std::min(Fcap, kDualMaxFrames)));
                 if (rc) return rc;
@@ -619,7 +662,9 @@ struct Engine {
             CrfDev cp = crf;
             cp.Q = Qp;
             if (!unary_is_label) {
-                if (!unary_p_valid) launch_permute_rows(crf, unary_p, crf.unary, L, 1, stream);
+                // a BOUND unary array ("bound, not copied") may have been updated in place since the last call: permute it
+                // afresh every time, as the other engines read it live; only the engine's own copy is cached
+                if (!unary_p_valid || crf.unary != unary_own) launch_permute_rows(crf, unary_p, crf.unary, L, 1, stream);
                 unary_p_valid = true;
                 cp.unary = unary_p;
             }
@@ -656,7 +701,7 @@ struct Engine {
             const auto t0 = std::chrono::steady_clock::now();
             for (unsigned spins = 1; !(seen = (*w == done_epoch)); ++spins) {
                 if ((spins & 0x3ff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
-                __builtin_ia32_pause();
+                cpu_relax();
             }
             std::atomic_thread_fence(std::memory_order_acquire);
         }
@@ -715,8 +760,8 @@ struct Engine {
         }
         Engine &g = *fb;
         const hipStream_t g_own = g.stream;
-        g.stream = stream;                                 // everything below is ordered on this engine's stream
-        struct Restore { Engine &g; hipStream_t s; ~Restore() { g.stream = s; } } restore{g, g_own};
+        g.stream = g.mem.stream = stream;                  // everything below (lazy allocations' zeroing included) is ordered on this engine's stream
+        struct Restore { Engine &g; hipStream_t s; ~Restore() { g.stream = g.mem.stream = s; } } restore{g, g_own};
         g.F = n;
         g.activeN = activeN;
         g.engine_pref = engine_pref == 1 ? 1 : 0;
@@ -807,6 +852,18 @@ struct lccrf_batch {
     const int32_t *d_pose_total = nullptr;   // lccrf_batch_pose_set_crf_counts
 };
 
+namespace {
+std::atomic<int> g_default_single_wg{0};
+
+int apply_option(Engine &e, int option, int value)
+{
+    switch (option) {
+    case LCCRF_OPT_SINGLE_WORKGROUP: e.opt_single_wg = value != 0; return LCCRF_OK;
+    default: return fail(LCCRF_E_INVALID, "unknown option %d", option);
+    }
+}
+}  // namespace
+
 extern "C" {
 
 int lccrf_abi_version(void) { return LCCRF_ABI_VERSION; }
@@ -864,14 +921,16 @@ int lccrf_create(lccrf_handle *out, int device_id, int n_points, int n_labels)
             return rc;
         }
     }
+    h->eng.ensure_parked_idle();                          // (a reused handle: its last kernel has stored its done word, or we wait for it)
     h->N = n_points;
+    h->eng.opt_single_wg = g_default_single_wg.load(std::memory_order_relaxed) != 0;   // (a recycled handle does not inherit its last user's options)
     h->eng.activeN = n_points;
     h->eng.crf.map = h->map_pin;
     h->eng.map_host = h->map_pin;
     h->eng.crf.map_bits = nullptr;                       // the packed copy is the batch API's gather payload only
     static const bool no_late = getenv("LCCRF_NO_LATE") != nullptr;   // debugging aid: always size the fused kernel on the host
     h->eng.late_ok = !no_late;
-    h->label_stage_busy = false;    // a parked engine's stream is idle (recycle() synchronised it)
+    h->label_stage_busy = false;    // a parked engine's stream is idle (recycle() synchronised it or saw the frame kernel's done word, its last store)
     // the kernels read the point count where the host wrote it (pinned, device-visible): no upload command on a path
     // whose every DMA packet costs microseconds of stream time (a parked engine's stream is idle, nothing reads the old value)
     *h->stage_n = n_points;
@@ -895,6 +954,26 @@ void lccrf_destroy(lccrf_handle h)
     }
     h->eng.destroy();
     delete h;
+}
+
+int lccrf_set_option(lccrf_handle h, int option, int value)
+{
+    if (!h) return fail(LCCRF_E_INVALID, "handle is NULL");
+    return apply_option(h->eng, option, value);
+}
+
+int lccrf_batch_set_option(lccrf_batch_handle b, int option, int value)
+{
+    if (!b) return fail(LCCRF_E_INVALID, "handle is NULL");
+    return apply_option(b->eng, option, value);
+}
+
+int lccrf_set_default_option(int option, int value)
+{
+    switch (option) {
+    case LCCRF_OPT_SINGLE_WORKGROUP: g_default_single_wg.store(value != 0, std::memory_order_relaxed); return LCCRF_OK;
+    default: return fail(LCCRF_E_INVALID, "unknown option %d", option);
+    }
 }
 
 int lccrf_trim_cache(void)
@@ -926,7 +1005,7 @@ int lccrf_trim_cache(void)
     do {                                                              \
         if (!(h)) return fail(LCCRF_E_INVALID, "handle is NULL");     \
         HIP_TRY(hipSetDevice((h)->eng.device));                       \
-        (h)->eng.idle_by_done = false;                                \
+        (h)->eng.idle_by_done = (h)->eng.idle_needs_done = false;     \
     } while (0)
 
 #define CHECK_K(h, k)                                                                      \
@@ -1162,13 +1241,13 @@ int lccrf_get_map(lccrf_handle h, int16_t *map_out)
         e.labels_armed = false;
         const volatile int16_t *m = h->map_pin;
         const auto t0 = std::chrono::steady_clock::now();
-        bool ok = true;
+        bool ok = true, timed_out = false;
         unsigned spins = 0;
         for (int i = 0; i < h->N && ok; ++i) {
             int16_t v;
             while ((v = m[i]) == (int16_t)-1) {           // (bounded: whatever goes wrong is left to the ordinary path below)
-                if ((++spins & 0x3ff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) { ok = false; break; }
-                __builtin_ia32_pause();
+                if ((++spins & 0x3ff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) { ok = false; timed_out = true; break; }
+                cpu_relax();
             }
             if (v < 0) ok = false;                        // -2: the frame did not fit the one-launch kernel
         }
@@ -1177,9 +1256,13 @@ int lccrf_get_map(lccrf_handle h, int16_t *map_out)
             memcpy(map_out, h->map_pin, (size_t)h->N * sizeof(int16_t));
             e.late_pending = false;                       // every label is there: the frame fitted and the kernel is past its last read
             e.done_armed = false;
+            // ... but not formally finished: V_out, frame_status and the done word are stored behind the labels (and a helper
+            // workgroup may be in its epilogue).  The handle counts as idle only once recycle() has seen the done word.
             e.idle_by_done = true;
+            e.idle_needs_done = true;
             return LCCRF_OK;
         }
+        if (timed_out) e.done_armed = false;              // (a delayed frame: do not spin another 2 ms on the done word, wait on the stream)
     }
     bool seen_done = false;
     { int rl = e.resolve_late(&seen_done); if (rl) return rl; }
@@ -1273,6 +1356,7 @@ int lccrf_batch_create(lccrf_batch_handle *out, int device_id, const lccrf_batch
     if (!b) return fail(LCCRF_E_NOMEM, "host allocation failed");
     b->desc = *desc;
     b->eng.allow_perm = true;
+    b->eng.opt_single_wg = g_default_single_wg.load(std::memory_order_relaxed) != 0;
     rc = b->eng.init(device_id, desc->max_frames, desc->max_points, desc->n_labels);
     for (int k = 0; k < desc->n_kernels && !rc; ++k) rc = b->eng.add_kernel(desc->feat_dims[k], desc->weights[k], true, false);
     if (!rc && hipStreamSynchronize(b->eng.stream) != hipSuccess)      // every allocation is zeroed before the handle is handed out
@@ -1398,12 +1482,12 @@ struct StreamScope {
             HIP_TRY(hipEventRecord(e.ev_order, own));
             HIP_TRY(hipStreamWaitEvent(use, e.ev_order, 0));
         }
-        e.stream = use;
+        e.stream = e.mem.stream = use;                    // lazy allocations of this call are zeroed on the stream its kernels run on
         return LCCRF_OK;
     }
     ~StreamScope()
     {
-        e.stream = own;
+        e.stream = e.mem.stream = own;
         if (use != own) {
             (void)hipEventRecord(e.ev_order, use);
             (void)hipStreamWaitEvent(own, e.ev_order, 0);

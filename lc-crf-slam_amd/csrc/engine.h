@@ -46,6 +46,11 @@ struct KernelDev {
     int *V;               // [F]               number of vertices (reference M_)
     int *rowmax;          // [F]               longest CSR row (splat contributions of one vertex)
     int *nbr;             // [F][D1][Epad][2]  blur neighbours {n1,n2} per (axis, vertex), -1 absent
+    int *nbr2;            // [F][D1/2][Epad][8] or null: two-hop table of the pass pairs (2p, 2p+1) for single-frame engines (one
+                          //   launch per TWO blur passes, stream_engine.hip: k_blur2x2t): {v1, v2, a, b, a1, a2, b1, b2} with
+                          //   (v1, v2) = axis-2p neighbours of v, (a, b) = its axis-(2p+1) neighbours, (a1, a2) / (b1, b2) = the
+                          //   axis-2p neighbours of a / b; -1 absent
+    int nbr2_ok;          // the streaming build filled nbr2 for the lattices now in HBM
     int *rowptr;          // [F][Epad+1]       CSR: vertex -> range of splat contributions
     int *csr_pt;          // [F][Epad]         contributing point, ascending within a row
     float *csr_w;         // [F][Epad]         its barycentric weight

@@ -64,7 +64,7 @@ struct FrameArgs {
     unsigned *dual;                       // DUAL launches: [F][kDualWords] hand-off area between a frame's two workgroups, else null
     unsigned dual_epoch;                  //   value the helper publishes in word 0 when its tables are complete (changes every launch)
     int n_single;                         // >= 0: the point count of the launch's only frame (else c.n_points[f])
-    int drop_helper;                      // test aid (LCCRF_DUAL_DROP_HELPER): the helper workgroup leaves at once -- the main one must time out and fall back
+    int drop_helper;                      // instrumented builds only (LCCRF_DUAL_DROP_HELPER): the helper workgroup leaves at once -- the main one must time out and fall back
     unsigned *done;                       // single-frame launches: pinned host word that receives done_epoch when the frame's results (labels in
     unsigned done_epoch;                  //   pinned memory, status words) are visible to the host -- earlier than the runtime's completion signal
     long long *timing;                    // instrumented builds only
@@ -663,7 +663,7 @@ __global__ void __launch_bounds__(NT, 4) k_frame(CrfDev c, FrameArgs a)
         place_products<PPT, K, 2, NT, 2>(smem, lay, N, tid, pk, pr);
         normalise(std::integral_constant<int, 2>{});
         FL_STAMP();
-        if (a.drop_helper) return;                        // (test aid: the main workgroup must time out and fall back)
+        if (kInstr && a.drop_helper) return;              // (fault injection, instrumented builds only: the main workgroup must time out and fall back)
         const unsigned *nb = reinterpret_cast<const unsigned *>(smem + lay.nbr[1]);
         for (int u = tid; u < D1 * Vk; u += NT) xs[kDualNbr + u] = nb[u];
         const unsigned *rw = reinterpret_cast<const unsigned *>(smem + lay.row[1]);      // (Vk + 2) u16, the area is 4-byte aligned
@@ -885,8 +885,10 @@ bool launch_frame(const CrfDev &c, const KernelDev *kds, int n_iter, int with_ma
     a.dual = dual;
     a.dual_epoch = dual_epoch;
     a.done = c.F == 1 ? done : nullptr;
-    static const bool drop_helper = getenv("LCCRF_DUAL_DROP_HELPER") != nullptr;
+#if LCCRF_INSTRUMENT
+    static const bool drop_helper = getenv("LCCRF_DUAL_DROP_HELPER") != nullptr;   // fault injection: not compiled into the release library
     a.drop_helper = drop_helper ? 1 : 0;
+#endif
     a.n_single = (c.F == 1 && done && c.activeN > 0) ? c.activeN : -1;   // (object API: activeN IS the frame's count)
     a.done_epoch = done_epoch;
     static long long *timing_buf = nullptr;

@@ -26,24 +26,45 @@ namespace {
 
 constexpr int kBlock = 256;
 
-// XCD-aware grids for the mean-field iteration of many frames in flight.  The chip's eight XCDs have private 4 MB L2s and
-// workgroup L of a launch runs on XCD L % 8 (observed dispatch order; used for speed only, never for correctness).  With the
-// frame in blockIdx.y every XCD touches every frame's lattice values; here workgroup L = 8 (g nb + x) + r handles block x of
-// frame 8 g + r, so ONE XCD owns a frame and that frame's value array (4.7 MB at C5) is what its L2 sees in the blur
-// gathers.  Used when there are at least 8 frames; `nb` = 0 selects the plain (x, frame) grid.
+// XCD-aware grids.  The chip's eight XCDs have private 4 MB L2s and workgroup L of a launch runs on XCD L % 8 (observed
+// dispatch order; used for speed only, never for correctness).  With the frame in blockIdx.y every XCD touches every frame's
+// lattice values.  Instead:
+//   8 frames or more (G = 1)   workgroup L = 8 (g nb + x) + r handles block x of frame 8 g + r: ONE XCD owns a frame, and that
+//                              frame's value array (4.7 MB at C5) is what its L2 sees in the blur gathers;
+//   fewer (G = 8 / F' XCDs per frame, F' = F rounded up to a power of two)   frame f owns the XCDs [f G, (f + 1) G) and XCD c
+//                              of them handles the CONTIGUOUS blocks [c nb, (c + 1) nb) of the frame -- a contiguous chunk of the
+//                              frame's Z-ordered vertex range (blur), row range (splat) or point range (slice): the neighbours a
+//                              blur gather wants are mostly the centre lines of nearby blocks, i.e. lines the same L2 is
+//                              fetching anyway (BASELINE config 5 as written is ONE frame: with the plain grid consecutive
+//                              blocks went round-robin over the XCDs and every L2 saw the gathers of the whole array).
+// `nb` = 0 selects the plain (x, frame) grid (empty launches only).
+struct XcdMap { int nb, G; };
 struct FrameBlock { int f, bx; };
-__device__ __forceinline__ FrameBlock frame_block(int nb)
+__device__ __forceinline__ FrameBlock frame_block(XcdMap m)
 {
-    if (nb == 0) return FrameBlock{(int)blockIdx.y, (int)blockIdx.x};
-    const int L = blockIdx.x, q = L >> 3, g = q / nb;
-    return FrameBlock{g * 8 + (L & 7), q - g * nb};
+    if (m.nb == 0) return FrameBlock{(int)blockIdx.y, (int)blockIdx.x};
+    const int L = blockIdx.x, xcd = L & 7, q = L >> 3;
+    if (m.G == 1) {
+        const int g = q / m.nb;
+        return FrameBlock{g * 8 + xcd, q - g * m.nb};
+    }
+    return FrameBlock{xcd / m.G, (xcd % m.G) * m.nb + q};  // (a block index beyond the frame's work fails the kernel's own range check)
 }
-inline dim3 grid_xcd(long work, int F, int *nb)
+inline dim3 grid_xcd(long work, int F, XcdMap *m)
 {
     const long n = (work + 256 - 1) / 256;
-    if (F < 8 || n < 1) { *nb = 0; return dim3((unsigned)(n > 0 ? n : 1), (unsigned)F); }
-    *nb = (int)n;
-    return dim3((unsigned)(8L * ((F + 7) / 8) * n));
+    if (n < 1) { *m = XcdMap{0, 1}; return dim3(1u, (unsigned)F); }
+    if (F >= 8) {
+        *m = XcdMap{(int)n, 1};
+        return dim3((unsigned)(8L * ((F + 7) / 8) * n));
+    }
+    static const bool no_chunk = getenv("LCCRF_NO_XCD_CHUNK") != nullptr;   // A/B switch (same results): plain (x, frame) grid below 8 frames
+    if (no_chunk) { *m = XcdMap{0, 1}; return dim3((unsigned)n, (unsigned)F); }
+    int Fp = 1;
+    while (Fp < F) Fp <<= 1;
+    const int G = 8 / Fp;
+    *m = XcdMap{(int)((n + G - 1) / G), G};
+    return dim3((unsigned)(8L * m->nb));
 }
 
 inline dim3 grid_for(long work, int F)
@@ -92,7 +113,7 @@ __global__ void __launch_bounds__(kBlock) k_points(KernelDev kd, const int *__re
 // holding the LOWEST entry id carrying that key, i.e. the entry at which the reference's
 // sequential HashTableCPU::find(create=true) would have created the vertex (:134-161,371-377).
 template <int D>
-__global__ void __launch_bounds__(kBlock) k_insert(KernelDev kd, const int *__restrict__ n_points, int F, int nb)
+__global__ void __launch_bounds__(kBlock) k_insert(KernelDev kd, const int *__restrict__ n_points, int F, XcdMap nb)
 {
     constexpr int D1 = D + 1;
     const FrameBlock fb = frame_block(nb);               // many frames: one XCD per frame, its table stays in that L2
@@ -461,7 +482,7 @@ __device__ __forceinline__ int find_vertex(const KernelDev &kd, int f, const int
 // iff A = n1_j(B) -- so one hash probe per (axis, vertex) finds n2 and fills both sides; the table was preset to
 // -1 (absent) by the caller.
 template <int D>
-__global__ void __launch_bounds__(kBlock) k_neighbors(KernelDev kd, int F, int nb)
+__global__ void __launch_bounds__(kBlock) k_neighbors(KernelDev kd, int F, XcdMap nb)
 {
     constexpr int D1 = D + 1;
     const FrameBlock fb = frame_block(nb);
@@ -495,6 +516,24 @@ __global__ void __launch_bounds__(kBlock) k_neighbors16(KernelDev kd)
     const int j = idx / V, v = idx - j * V;
     const int2 r = reinterpret_cast<const int2 *>(kd.nbr)[((size_t)f * kd.D1 + j) * kd.Epad + v];
     kd.nbr16[((size_t)f * kd.D1 + j) * kd.Epad + v] = (unsigned)(r.x + 1) | ((unsigned)(r.y + 1) << 16);
+}
+
+// two-hop table of the pass pair (2p, 2p + 1) for single-frame engines (KernelDev::nbr2): everything k_blur2x2 looks up on its way,
+// looked up once at build time, so that a launch of two passes is a table read and ONE level of gathers
+__global__ void __launch_bounds__(kBlock) k_neighbors_2hop(KernelDev kd, int npairs)
+{
+    const int f = blockIdx.y;
+    const int V = kd.V[f];
+    const int idx = blockIdx.x * kBlock + threadIdx.x;
+    if (idx >= V * npairs) return;
+    const int p = idx / V, v = idx - p * V;
+    const int2 *nj = reinterpret_cast<const int2 *>(kd.nbr) + ((size_t)f * kd.D1 + 2 * p) * kd.Epad;
+    const int2 *nj1 = nj + kd.Epad;
+    const int2 ab = nj1[v], nv = nj[v];
+    const int2 na = ab.x >= 0 ? nj[ab.x] : make_int2(-1, -1), nb = ab.y >= 0 ? nj[ab.y] : make_int2(-1, -1);
+    int4 *out = reinterpret_cast<int4 *>(kd.nbr2) + (((size_t)f * npairs + p) * kd.Epad + v) * 2;
+    out[0] = make_int4(nv.x, nv.y, ab.x, ab.y);
+    out[1] = make_int4(na.x, na.y, nb.x, nb.y);
 }
 
 // ---- CSR of splat contributions: vertex -> (point, weight), points ascending ------------
@@ -694,7 +733,7 @@ __global__ void __launch_bounds__(kBlock) k_slice(KernelDev kd, CrfDev c, const 
 
 // ---- two-label specialisations (the SLAM configuration, L = 2): one thread per vertex / point,
 // both labels in a float2.  Same operations per label as the generic kernels above.
-__global__ void __launch_bounds__(kBlock) k_splat2(KernelDev kd, const float2 *__restrict__ in, int in_stride, int F, int nb)
+__global__ void __launch_bounds__(kBlock) k_splat2(KernelDev kd, const float2 *__restrict__ in, int in_stride, int F, XcdMap nb)
 {
     const FrameBlock fb = frame_block(nb);
     const int f = fb.f;
@@ -714,17 +753,11 @@ __global__ void __launch_bounds__(kBlock) k_splat2(KernelDev kd, const float2 *_
     reinterpret_cast<float2 *>(kd.val0 + (size_t)f * kd.vstride + kd.vbase)[v] = make_float2(a0, a1);
 }
 
-#ifndef LCCRF_NT_NBR
-#define LCCRF_NT_NBR 1
-#endif
 typedef int lccrf_v4i __attribute__((ext_vector_type(4)));
+template <bool NT>
 __device__ __forceinline__ int4 load_nbr_pair(const int *p)
 {
-#if LCCRF_NT_NBR
-    const lccrf_v4i x = __builtin_nontemporal_load(reinterpret_cast<const lccrf_v4i *>(p));
-#else
-    const lccrf_v4i x = *reinterpret_cast<const lccrf_v4i *>(p);
-#endif
+    const lccrf_v4i x = NT ? __builtin_nontemporal_load(reinterpret_cast<const lccrf_v4i *>(p)) : *reinterpret_cast<const lccrf_v4i *>(p);
     return make_int4(x.x, x.y, x.z, x.w);
 }
 // Two vertices per thread: the neighbour pairs (int4), the centres (float4) and the results (float4) move as 16-byte
@@ -733,8 +766,12 @@ __device__ __forceinline__ int4 load_nbr_pair(const int *p)
 // 128-byte line it touches (scripts/ubench/tacost.hip), which is why locality mode -- fewer distinct lines per gather --
 // helps and why everything tried on top of it lost (notes/r3_experiments.md: 2-8 pairs per lane with all loads issued
 // first, a presence-bit + id-list neighbour table, a 4096/8192-vertex LDS tile serving the in-tile neighbours).
+// NT: the neighbour table is read once per pass -- with many frames in flight (a working set beyond every cache) it is
+// loaded non-temporally, out of the value array's way in L2; with a few frames everything lives in L2 / the Infinity Cache
+// and the plain load is the faster one (scripts/ubench/phasecost.hip: 7.2 -> 6.8 us per pass of one C5 frame).
+template <bool NT>
 __global__ void __launch_bounds__(kBlock) k_blur2(KernelDev kd, const float *__restrict__ src,
-                                                  float *__restrict__ dst, int j, int F, int nb)
+                                                  float *__restrict__ dst, int j, int F, XcdMap nb)
 {
     const FrameBlock fb = frame_block(nb);
     const int f = fb.f;
@@ -746,7 +783,7 @@ __global__ void __launch_bounds__(kBlock) k_blur2(KernelDev kd, const float *__r
     float2 *d = reinterpret_cast<float2 *>(dst + (size_t)f * kd.vstride + kd.vbase);
     const int *nbp = kd.nbr + (((size_t)f * kd.D1 + j) * kd.Epad + v) * 2;
     if (v + 1 < V) {
-        const int4 nb4 = load_nbr_pair(nbp);              // read once per pass: non-temporal, out of the value array's way in L2
+        const int4 nb4 = load_nbr_pair<NT>(nbp);
         const float4 c = *reinterpret_cast<const float4 *>(o + v);
         const float2 x0 = o[nb4.x], y0 = o[nb4.y], x1 = o[nb4.z], y1 = o[nb4.w];
         *reinterpret_cast<float4 *>(d + v) = make_float4(c.x + 0.5f * (x0.x + y0.x), c.y + 0.5f * (x0.y + y0.y),
@@ -758,17 +795,82 @@ __global__ void __launch_bounds__(kBlock) k_blur2(KernelDev kd, const float *__r
     }
 }
 
+// TWO passes (axes j, j + 1) in one launch, no extra tables -- for one or two frames in flight, where a pass is a chain of
+// latencies (launch ~2.5 us, table load, gather: ~7 us per pass of one C5 frame against ~0.5 us of streaming) and every launch
+// saved counts: out[v] = t[v] + 0.5 (t[a] + t[b]) with {a, b} = the axis-(j+1) neighbours of v and
+// t[x] = s[x] + 0.5 (s[n1_j(x)] + s[n2_j(x)]) recomputed for x = v, a, b.  The same operations in the same order as two
+// launches of k_blur2 (permutohedral_cpu.h:663-679), hence the same bits; the absent vertex (-1) has no neighbours and
+// t[-1] = 0 + 0.5 (0 + 0) = 0 exactly, which is what the separate passes leave in its slot.  9 gathers instead of 4, a
+// three-level chain instead of twice two levels + a launch: 13.6 -> 10.3 us per pair of passes (scripts/ubench/phasecost.hip).
+__global__ void __launch_bounds__(kBlock) k_blur2x2(KernelDev kd, const float *__restrict__ src, float *__restrict__ dst, int j, int F, XcdMap nb)
+{
+    const FrameBlock fb = frame_block(nb);
+    const int f = fb.f;
+    if (f >= F) return;
+    const int v = fb.bx * kBlock + threadIdx.x;
+    if (v >= kd.V[f]) return;
+    const float2 *o = reinterpret_cast<const float2 *>(src + (size_t)f * kd.vstride + kd.vbase);   // o[-1] = absent
+    float2 *d = reinterpret_cast<float2 *>(dst + (size_t)f * kd.vstride + kd.vbase);
+    const int2 *nj = reinterpret_cast<const int2 *>(kd.nbr) + ((size_t)f * kd.D1 + j) * kd.Epad;
+    const int2 *nj1 = nj + kd.Epad;
+    const int2 ab = nj1[v], nv = nj[v];
+    const float2 sv = o[v];
+    const int2 na = ab.x >= 0 ? nj[ab.x] : make_int2(-1, -1), nbb = ab.y >= 0 ? nj[ab.y] : make_int2(-1, -1);
+    const float2 sa = o[ab.x], sb = o[ab.y], v1 = o[nv.x], v2 = o[nv.y];
+    const float2 a1 = o[na.x], a2 = o[na.y], b1 = o[nbb.x], b2 = o[nbb.y];
+    const float2 tv = make_float2(sv.x + 0.5f * (v1.x + v2.x), sv.y + 0.5f * (v1.y + v2.y));
+    const float2 ta = make_float2(sa.x + 0.5f * (a1.x + a2.x), sa.y + 0.5f * (a1.y + a2.y));
+    const float2 tb = make_float2(sb.x + 0.5f * (b1.x + b2.x), sb.y + 0.5f * (b1.y + b2.y));
+    d[v] = make_float2(tv.x + 0.5f * (ta.x + tb.x), tv.y + 0.5f * (ta.y + tb.y));
+}
+
+// ... and with the two-hop table of the pair (KernelDev::nbr2, filled by the streaming build of single-frame engines) the launch is a
+// table read and one level of gathers: same operations, same order, same bits
+__global__ void __launch_bounds__(kBlock) k_blur2x2t(KernelDev kd, const float *__restrict__ src, float *__restrict__ dst, int pair, int npairs, int F,
+                                                     XcdMap nb)
+{
+    const FrameBlock fb = frame_block(nb);
+    const int f = fb.f;
+    if (f >= F) return;
+    const int v = fb.bx * kBlock + threadIdx.x;
+    if (v >= kd.V[f]) return;
+    const float2 *o = reinterpret_cast<const float2 *>(src + (size_t)f * kd.vstride + kd.vbase);   // o[-1] = absent
+    float2 *d = reinterpret_cast<float2 *>(dst + (size_t)f * kd.vstride + kd.vbase);
+    const int4 *tb = reinterpret_cast<const int4 *>(kd.nbr2) + (((size_t)f * npairs + pair) * kd.Epad + v) * 2;
+    const int4 h0 = tb[0], h1 = tb[1];                   // {v1, v2, a, b}, {a1, a2, b1, b2}
+    const float2 sv = o[v];
+    const float2 v1 = o[h0.x], v2 = o[h0.y], sa = o[h0.z], sb = o[h0.w];
+    const float2 a1 = o[h1.x], a2 = o[h1.y], b1 = o[h1.z], b2 = o[h1.w];
+    const float2 tv = make_float2(sv.x + 0.5f * (v1.x + v2.x), sv.y + 0.5f * (v1.y + v2.y));
+    const float2 ta = make_float2(sa.x + 0.5f * (a1.x + a2.x), sa.y + 0.5f * (a1.y + a2.y));
+    const float2 tbv = make_float2(sb.x + 0.5f * (b1.x + b2.x), sb.y + 0.5f * (b1.y + b2.y));
+    d[v] = make_float2(tv.x + 0.5f * (ta.x + tbv.x), tv.y + 0.5f * (ta.y + tbv.y));
+}
+
+constexpr int kPairFuseMaxFrames = 1;        // (measured, scripts/gpu_r4_pairs.sh: one C5 frame 52.5 -> 45.2 us per iteration; two or four frames in flight: +-0)
+inline bool pair_fuse(int F)
+{
+    static const bool off = getenv("LCCRF_NO_PAIR_FUSE") != nullptr;      // A/B switch: same results either way
+    static const char *force = getenv("LCCRF_PAIR_FUSE_MAX");             //  (A/B: frames-in-flight threshold)
+    return !off && F <= (force ? atoi(force) : kPairFuseMaxFrames);
+}
+
 inline void launch_blur2(const KernelDev &kd, const float *src, float *dst, int j, int F, int maxV, hipStream_t s)
 {
-    int nb;
+    XcdMap nb;
     const dim3 g = grid_xcd((maxV + 1) / 2, F, &nb);
-    k_blur2<<<g, kBlock, 0, s>>>(kd, src, dst, j, F, nb);
+    if (F >= 8) k_blur2<true><<<g, kBlock, 0, s>>>(kd, src, dst, j, F, nb);
+    else k_blur2<false><<<g, kBlock, 0, s>>>(kd, src, dst, j, F, nb);
 }
 
 // slice + apply for L = 2; the LAST kernel of the step also does the softmax (saves a pass over next).
-template <int D1>
+// BLUR (one frame in flight, odd d + 1: the pass that is left over when passes go two per launch): `val` holds the values BEFORE
+// the last blur pass and every point blurs its own d + 1 vertices on the way -- t = s[o] + 0.5 (s[n1(o)] + s[n2(o)]) along the last
+// axis, the operations of k_blur2 in the same order, so the same bits -- instead of a launch of its own for that pass (a vertex
+// shared by several points is blurred once per point: 1.2 x the work at C5, one launch and one chain of latencies less).
+template <int D1, bool BLUR = false>
 __global__ void __launch_bounds__(kBlock) k_slice2(KernelDev kd, CrfDev c, const float *__restrict__ val,
-                                                   int first, int last, float relax, int nb)
+                                                   int first, int last, float relax, XcdMap nb)
 {
     const FrameBlock fb = frame_block(nb);
     const int f = fb.f;
@@ -778,12 +880,32 @@ __global__ void __launch_bounds__(kBlock) k_slice2(KernelDev kd, CrfDev c, const
     const size_t fe = (size_t)f * kd.Epad;
     const float2 *vf = reinterpret_cast<const float2 *>(val + (size_t)f * kd.vstride + kd.vbase);
     float t0 = 0.0f, t1 = 0.0f;
+    if (BLUR) {
+        const int2 *nl = reinterpret_cast<const int2 *>(kd.nbr) + ((size_t)f * D1 + (D1 - 1)) * kd.Epad;
+        int o[D1];
+        int2 n[D1];
+        float2 x[D1], a[D1], b[D1];
 #pragma unroll
-    for (int j = 0; j < D1; ++j) {
-        const float wgt = kd.bary[fe + (size_t)i * D1 + j] * kd.alpha;
-        const float2 x = vf[kd.offset[fe + (size_t)i * D1 + j]];
-        t0 += wgt * x.x;
-        t1 += wgt * x.y;
+        for (int j = 0; j < D1; ++j) o[j] = kd.offset[fe + (size_t)i * D1 + j];
+#pragma unroll
+        for (int j = 0; j < D1; ++j) { n[j] = nl[o[j]]; x[j] = vf[o[j]]; }
+#pragma unroll
+        for (int j = 0; j < D1; ++j) { a[j] = vf[n[j].x]; b[j] = vf[n[j].y]; }
+#pragma unroll
+        for (int j = 0; j < D1; ++j) {
+            const float wgt = kd.bary[fe + (size_t)i * D1 + j] * kd.alpha;
+            const float bx = x[j].x + 0.5f * (a[j].x + b[j].x), by = x[j].y + 0.5f * (a[j].y + b[j].y);
+            t0 += wgt * bx;
+            t1 += wgt * by;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < D1; ++j) {
+            const float wgt = kd.bary[fe + (size_t)i * D1 + j] * kd.alpha;
+            const float2 x = vf[kd.offset[fe + (size_t)i * D1 + j]];
+            t0 += wgt * x.x;
+            t1 += wgt * x.y;
+        }
     }
     const size_t q = (size_t)f * c.maxN + i;
     float2 base;
@@ -876,7 +998,7 @@ void build_kernel_d(const KernelDev &kd, const CrfDev &c, hipStream_t s)
     (void)hipMemsetAsync(kd.slot, 0xff, (size_t)F * kd.cap * sizeof(int), s);
     k_points<D><<<grid_for(kd.maxNpad, F), kBlock, 0, s>>>(kd, c.n_points);
     {
-        int nb;
+        XcdMap nb;
         const dim3 g = grid_xcd(kd.Epad, F, &nb);
         k_insert<D><<<g, kBlock, 0, s>>>(kd, c.n_points, F, nb);
     }
@@ -885,11 +1007,12 @@ void build_kernel_d(const KernelDev &kd, const CrfDev &c, hipStream_t s)
     k_offsets<<<grid_for(kd.Epad, F), kBlock, 0, s>>>(kd, c.n_points);
     (void)hipMemsetAsync(kd.nbr, 0xff, (size_t)F * D1 * kd.Epad * 2 * sizeof(int), s);          // every neighbour absent (-1)
     {
-        int nb;
+        XcdMap nb;
         const dim3 g = grid_xcd((long)kd.Epad * D1, F, &nb);
         k_neighbors<D><<<g, kBlock, 0, s>>>(kd, F, nb);
     }
     if (kd.Epad < 65535) k_neighbors16<<<grid_for((long)kd.Epad * D1, F), kBlock, 0, s>>>(kd);
+    if (kd.nbr2) k_neighbors_2hop<<<grid_for((long)kd.Epad * (D1 / 2), F), kBlock, 0, s>>>(kd, D1 / 2);
     // CSR
     (void)hipMemsetAsync(kd.flag, 0, (size_t)F * (kd.Epad + 1) * sizeof(int), s);
     k_csr_count<<<grid_for(kd.Epad, F), kBlock, 0, s>>>(kd, c.n_points);
@@ -961,29 +1084,48 @@ void launch_step_stream(const CrfDev &c, const KernelDev *kds, const int *maxV, 
     if (L == 2) {
         for (int k = 0; k < c.K; ++k) {
             const KernelDev &kd = kds[k];
-            int nb;
+            XcdMap nb;
             dim3 g = grid_xcd(maxV[k], c.F, &nb);
             k_splat2<<<g, kBlock, 0, s>>>(kd, reinterpret_cast<const float2 *>(c.Q), c.maxN, c.F, nb);
             const float *src = kd.val0;
             float *dst = kd.val1;
-            for (int j = 0; j < kd.D1; ++j) {
-                launch_blur2(kd, src, dst, j, c.F, maxV[k], s);
+            const bool pairs = pair_fuse(c.F);
+            const bool blur_in_slice = pairs && (kd.D1 & 1) && kd.D1 >= 3 && kd.D1 <= 9;   // the pass left over by the pairs rides in the slice
+            const int n_own = blur_in_slice ? kd.D1 - 1 : kd.D1;                           // blur passes with a launch of their own
+            for (int j = 0; j < n_own;) {
+                if (pairs && j + 1 < n_own) {             // one frame in flight: two passes per launch
+                    const dim3 gp = grid_xcd(maxV[k], c.F, &nb);
+                    static const bool no_tbl = getenv("LCCRF_NO_2HOP_TABLE") != nullptr;      // A/B switch: same results either way
+                    if (kd.nbr2 && kd.nbr2_ok && !no_tbl) k_blur2x2t<<<gp, kBlock, 0, s>>>(kd, src, dst, j / 2, kd.D1 / 2, c.F, nb);
+                    else k_blur2x2<<<gp, kBlock, 0, s>>>(kd, src, dst, j, c.F, nb);
+                    j += 2;
+                } else {
+                    launch_blur2(kd, src, dst, j, c.F, maxV[k], s);
+                    j += 1;
+                }
                 const float *t = src;
                 src = dst;
                 dst = const_cast<float *>(t);
             }
             const int first = k == 0, last = k == c.K - 1;
             g = grid_xcd(c.maxN, c.F, &nb);
+#define LCCRF_SLICE_CASE(D)                                                                       \
+    case D:                                                                                      \
+        if (blur_in_slice) k_slice2<D, true><<<g, kBlock, 0, s>>>(kd, c, src, first, last, relax, nb); \
+        else k_slice2<D><<<g, kBlock, 0, s>>>(kd, c, src, first, last, relax, nb);               \
+        break;
             switch (kd.D1) {
             case 2: k_slice2<2><<<g, kBlock, 0, s>>>(kd, c, src, first, last, relax, nb); break;
-            case 3: k_slice2<3><<<g, kBlock, 0, s>>>(kd, c, src, first, last, relax, nb); break;
+            LCCRF_SLICE_CASE(3)
             case 4: k_slice2<4><<<g, kBlock, 0, s>>>(kd, c, src, first, last, relax, nb); break;
-            case 5: k_slice2<5><<<g, kBlock, 0, s>>>(kd, c, src, first, last, relax, nb); break;
+            LCCRF_SLICE_CASE(5)
             case 6: k_slice2<6><<<g, kBlock, 0, s>>>(kd, c, src, first, last, relax, nb); break;
-            case 7: k_slice2<7><<<g, kBlock, 0, s>>>(kd, c, src, first, last, relax, nb); break;
+            LCCRF_SLICE_CASE(7)
             case 8: k_slice2<8><<<g, kBlock, 0, s>>>(kd, c, src, first, last, relax, nb); break;
-            default: k_slice2<9><<<g, kBlock, 0, s>>>(kd, c, src, first, last, relax, nb); break;
+            LCCRF_SLICE_CASE(9)
+            default: break;
             }
+#undef LCCRF_SLICE_CASE
         }
         return;
     }

@@ -12,6 +12,7 @@ Version 2 (read and written here; version-1 files are still read): a frame may c
 each a dict of the arrays include/lccrf_record.h lists for that section; sections with an unknown tag are kept as
 (tag, flags, payload bytes) under `unknown_sections` and written back untouched.
 """
+import os
 import struct
 
 import numpy as np
@@ -140,7 +141,9 @@ class _Cursor:
         self.b, self.o = b, 0
 
     def take(self, dtype, shape):
-        cnt = int(np.prod(shape)) if len(shape) else 1
+        cnt = 1
+        for x in shape:                                 # (Python integers: header counts cannot wrap)
+            cnt *= int(x)
         nbytes = cnt * np.dtype(dtype).itemsize
         if self.o + nbytes > len(self.b):
             raise RecordError("section payload too short")
@@ -210,7 +213,8 @@ def file_origin(path):
 def read_records(path):
     """Yield the frames of `path`.  Raises RecordError on a malformed or truncated file."""
     with open(path, "rb") as fh:
-        raw = fh.read(_FILE_HDR.size)
+        fsize = os.fstat(fh.fileno()).st_size           # every size field of the file is checked against what is left of it BEFORE
+        raw = fh.read(_FILE_HDR.size)                   #   anything is read or allocated (a corrupt or hostile file must not drive memory)
         if len(raw) != _FILE_HDR.size:
             raise RecordError("truncated file header")
         magic, version, hb, fhb = _FILE_HDR.unpack(raw)[:4]
@@ -220,6 +224,8 @@ def read_records(path):
             raise RecordError("unsupported version %d" % version)
         if hb < _FILE_HDR.size or fhb < _FRAME_HDR.size:
             raise RecordError("header sizes smaller than version 1")
+        if hb > fsize or fhb > fsize:
+            raise RecordError("header sizes larger than the file")
         fh.seek(hb)
         while True:
             raw = fh.read(fhb)
@@ -236,8 +242,12 @@ def read_records(path):
 
             def take(dtype, shape):
                 nonlocal size
-                cnt = int(np.prod(shape))
+                cnt = 1
+                for x in shape:
+                    cnt *= int(x)
                 nbytes = cnt * np.dtype(dtype).itemsize
+                if nbytes > fsize - fh.tell():
+                    raise RecordError("truncated frame %d" % frame_id)
                 b = fh.read(nbytes)
                 if len(b) != nbytes:
                     raise RecordError("truncated frame %d" % frame_id)
@@ -261,6 +271,8 @@ def read_records(path):
                 if len(raw) != _SEC_HDR.size:
                     raise RecordError("truncated section header in frame %d" % frame_id)
                 tag, sflags, nbytes = _SEC_HDR.unpack(raw)
+                if nbytes > fsize - fh.tell():
+                    raise RecordError("section of frame %d claims %d bytes, %d left in the file" % (frame_id, nbytes, fsize - fh.tell()))
                 payload = fh.read(nbytes)
                 spad = -nbytes % 8
                 if len(payload) != nbytes or len(fh.read(spad)) != spad:

@@ -434,8 +434,12 @@ np.save(sys.argv[1], np.concatenate([o.ravel() for o in out]))
 
 
 def test_a_helper_that_never_comes_cannot_hang_the_launch(po, wl):
-    """LCCRF_DUAL_DROP_HELPER (child process): the helper workgroup of the two-workgroup form leaves at once.  The main workgroup's
-    poll is bounded (~0.1 s), the frame flags itself and is re-run on the two-kernel path: same labels, same Q, no hang."""
+    """LCCRF_DUAL_DROP_HELPER (child process, INSTRUMENTED library -- the release library carries no fault-injection hook): the helper
+    workgroup of the two-workgroup form leaves at once.  The main workgroup's poll is bounded (~0.1 s), the frame flags itself and is
+    re-run on the two-kernel path: same labels, same Q, no hang."""
+    instr = os.path.join(ROOT, "lc-crf-slam_amd", "liblccrf_hip_instr.so")
+    if not os.path.exists(instr):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "lc-crf-slam_amd"), "-j4", "INSTRUMENT=1"], check=True, stdout=subprocess.DEVNULL)
     code = r"""
 import importlib, sys, time, numpy as np
 sys.path.insert(0, %r)
@@ -451,7 +455,7 @@ np.save(sys.argv[1], np.concatenate(out + [np.float32([time.perf_counter() - t0]
 """ % ROOT
     path = os.path.join(ROOT, "gpurun_out", "drop_helper.npy")
     os.makedirs(os.path.dirname(path), exist_ok=True)
-    subprocess.run([sys.executable, "-c", code, path], check=True, env=dict(os.environ, LCCRF_DUAL_DROP_HELPER="1"), timeout=120)
+    subprocess.run([sys.executable, "-c", code, path], check=True, env=dict(os.environ, LCCRF_DUAL_DROP_HELPER="1", LCCRF_LIB=instr), timeout=120)
     res = np.load(path)
     pb = wl.slam_problem(1500, seed=77)
     o = cc.setup(po.OracleCRF, pb)
@@ -459,6 +463,64 @@ np.save(sys.argv[1], np.concatenate(out + [np.float32([time.perf_counter() - t0]
     want = np.concatenate([o.map().astype(np.float32), o.probability().ravel()])
     assert cc.same_bits(res[:want.size], want) and cc.same_bits(res[want.size:2 * want.size], want)
     assert res[-1] < 20.0                                   # two bounded waits + two re-runs + the child's start-up
+    assert res[-1] > 0.05                                   # ... and the hook did fire (the helper was really dropped)
+    # the release library neither reads the switch nor contains its name
+    rel = open(os.path.join(ROOT, "lc-crf-slam_amd", "liblccrf_hip.so"), "rb").read()
+    assert b"LCCRF_DUAL_DROP_HELPER" not in rel
+
+
+def test_single_workgroup_option_gives_the_same_bits(po, wl):
+    """lccrf_set_option(h, LCCRF_OPT_SINGLE_WORKGROUP, 1) / lccrf_batch_set_option / lccrf_set_default_option: a tracker on a shared
+    GPU opts out of the two-workgroup form through the API (no environment variable); results are the oracle's either way, and a
+    handle taken from the cache starts from the defaults again."""
+    pb = wl.slam_problem(1800, seed=91)
+    o = cc.setup(po.OracleCRF, pb)
+    o.inference_native(5, True)
+    for mode in ("default", "handle", "process"):
+        if mode == "process":
+            pkg.set_default_option(pkg.OPT_SINGLE_WORKGROUP, 1)
+        try:
+            h = pkg.DenseCRFHIP(pb["N"], pb["L"])
+            if mode == "handle":
+                h.set_option(pkg.OPT_SINGLE_WORKGROUP, 1)
+            h.set_unary_from_label(pb["label"], pb["conf"])
+            for f, w in pb["kernels"]:
+                h.add_pairwise(f, w)
+            h.inference(5, True)
+            assert np.array_equal(h.map(), o.map()) and cc.same_bits(h.probability(), o.probability()), mode
+            h.close()
+        finally:
+            pkg.set_default_option(pkg.OPT_SINGLE_WORKGROUP, 0)
+    with pytest.raises(pkg.LccrfError):
+        h = pkg.DenseCRFHIP(4, 2)
+        try:
+            h.set_option(99, 1)
+        finally:
+            h.close()
+    # batches of up to 64 two-kernel frames take the two-workgroup form too
+    F = 6
+    pbs = [wl.slam_problem(1500 + 7 * i, seed=92 + i) for i in range(F)]
+    res = []
+    for single in (0, 1):
+        b = pkg.BatchCRF(F, 1600, 2, [2, 2], [10.0, 30.0])
+        b.set_option(pkg.OPT_SINGLE_WORKGROUP, single)
+        feats = [np.zeros((F, 1600, 2), np.float32) for _ in range(2)]
+        label = np.zeros((F, 1600), np.int16)
+        for i, p in enumerate(pbs):
+            for k in range(2):
+                feats[k][i, :p["N"]] = p["kernels"][k][0]
+            label[i, :p["N"]] = p["label"]
+        b.set_inputs_host([p["N"] for p in pbs], feats, label=label, conf=0.7)
+        b.run(5, True)
+        res.append((b.probability(), b.map()))
+        assert b.engine() == 3
+        b.close()
+    assert cc.same_bits(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+    for i, p in enumerate(pbs):
+        oo = cc.setup(po.OracleCRF, p)
+        oo.inference_native(5, True)
+        assert cc.same_bits(res[1][0][i, :p["N"]], oo.probability()) and np.array_equal(res[1][1][i, :p["N"]], oo.map()), i
+        oo.close()
 
 
 def test_frame_kernel_many_copies_are_identical(wl):

@@ -437,6 +437,64 @@ def test_batch_on_a_caller_stream_right_after_create(wl):
             assert cc.same_bits(Q, ref[0]) and np.array_equal(M, ref[1])
 
 
+def test_lazy_allocations_are_zeroed_on_the_callers_stream(po, wl):
+    """buffers allocated lazily DURING a batch call -- the two-workgroup hand-off area of lccrf_batch_run for
+    up to 64 frames, the point sort's scratch of locality mode (>= 8192 points) -- must be zeroed on the stream the call's kernels
+    run on, not on the engine's own stream (a memset that lands late wipes hand-off records or the permutation).  Fresh handles,
+    caller streams, several rounds so that the first-use path runs each time; results against the oracle."""
+    import torch
+    dev = torch.device("cuda", 0)
+    # (1) two-workgroup form: 6 SLAM frames through lccrf_batch_run on a foreign stream, fresh handle every round
+    F, N = 6, 1900
+    pbs = [wl.slam_problem(N - 13 * i, seed=410 + i) for i in range(F)]
+    want = []
+    for pb in pbs:
+        o = cc.setup(po.OracleCRF, pb)
+        o.inference_native(5, True)
+        want.append((o.probability().copy(), o.map().copy()))
+        o.close()
+    feats = [np.zeros((F, N, 2), np.float32) for _ in range(2)]
+    label = np.full((F, N), -1, np.int16)
+    for f, pb in enumerate(pbs):
+        label[f, :pb["N"]] = pb["label"]
+        for k in range(2):
+            feats[k][f, :pb["N"]] = pb["kernels"][k][0]
+    d_feats = [torch.from_numpy(x).to(dev) for x in feats]
+    d_label = torch.from_numpy(label).to(dev)
+    d_np = torch.tensor([pb["N"] for pb in pbs], dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    for rnd in range(4):
+        st = torch.cuda.Stream(device=dev)
+        b = pkg.BatchCRF(F, N, 2, [2, 2], [10.0, 30.0])
+        b.bind_inputs_device(F, d_np.data_ptr(), [t.data_ptr() for t in d_feats], d_label=d_label.data_ptr(), conf=0.7)
+        b.run(5, True, stream=st.cuda_stream)
+        Q, M = b.probability(), b.map()
+        assert b.engine() == 3
+        b.close()
+        for f, pb in enumerate(pbs):
+            assert cc.same_bits(Q[f, :pb["N"]], want[f][0]) and np.array_equal(M[f, :pb["N"]], want[f][1]), (rnd, f)
+    # (2) locality mode: build + inference of two 9000-point frames on a foreign stream, fresh handle every round
+    N2 = 9000
+    pb2 = wl.bilateral_problem(N2, seed=415)
+    o = cc.setup(po.OracleCRF, pb2)
+    o.inference_native(3, True)
+    f2 = torch.from_numpy(np.repeat(pb2["kernels"][0][0][None], 2, 0)).to(dev)
+    l2 = torch.from_numpy(np.repeat(pb2["label"][None], 2, 0)).to(dev)
+    n2 = torch.full((2,), N2, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    for rnd in range(4):
+        st = torch.cuda.Stream(device=dev)
+        b = pkg.BatchCRF(2, N2, 2, [6], [float(pb2["kernels"][0][1])])
+        b.bind_inputs_device(2, n2.data_ptr(), [f2.data_ptr()], d_label=l2.data_ptr(), conf=pb2["conf"])
+        b.build(stream=st.cuda_stream)
+        b.inference(3, True, stream=st.cuda_stream)
+        Q, M = b.probability(), b.map()
+        b.close()
+        for g in range(2):
+            assert cc.same_bits(Q[g], o.probability()) and np.array_equal(M[g], o.map()), (rnd, g)
+    o.close()
+
+
 def test_bound_n_points_out_of_range_is_reported_not_followed(wl):
     """a device-bound n_points[f] > max_points must not make the kernels run past the frame stride."""
     import torch
@@ -528,6 +586,70 @@ def test_streaming_engine_xcd_aware_grid_with_many_frames(po, wl):
         o = cc.setup(po.OracleCRF, pb)
         o.inference_native(4, True)
         assert cc.same_bits(Q[f, :pb["N"]], o.probability()) and np.array_equal(M[f, :pb["N"]], o.map()), f
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("F", [1, 2, 3, 4, 5, 7])
+def test_streaming_engine_xcd_chunked_grid_below_eight_frames(po, wl, F):
+    """Fewer than 8 frames in flight (round 4): every frame owns 8 / F' XCDs and each of them a contiguous chunk of the frame's
+    vertex / row / point range (F' = F rounded up to a power of two: with 3, 5, 7 frames some XCDs stay idle).  Ragged frames, an
+    empty one, on engine 1 against the oracle -- and the plain grid (LCCRF_NO_XCD_CHUNK is read once per process, so the A/B
+    itself lives in scripts/gpu_r4_phase.sh; here the results must simply be the oracle's)."""
+    sizes = [700, 333, 0, 699, 5, 512, 257][:F]
+    maxN = 700
+    pbs = [wl.slam_problem(n, seed=640 + i) for i, n in enumerate(sizes)]
+    feats = [np.zeros((F, maxN, 2), np.float32) for _ in range(2)]
+    label = np.full((F, maxN), -1, np.int16)
+    for f, pb in enumerate(pbs):
+        n = pb["N"]
+        label[f, :n] = pb["label"]
+        for k in range(2):
+            feats[k][f, :n] = pb["kernels"][k][0]
+    b = pkg.BatchCRF(F, maxN, 2, [2, 2], [10.0, 30.0])
+    b.set_engine(1)
+    b.set_inputs_host(sizes, feats, label=label, conf=0.7)
+    b.build()
+    b.inference(4, True)
+    assert b.engine() == 1
+    Q, M = b.probability(), b.map()
+    b.close()
+    for f, pb in enumerate(pbs):
+        o = cc.setup(po.OracleCRF, pb)
+        o.inference_native(4, True)
+        assert cc.same_bits(Q[f, :pb["N"]], o.probability()) and np.array_equal(M[f, :pb["N"]], o.map()), f
+        o.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("d_list,N", [([6], 9000), ([1], 8200), ([2, 5], 8500), ([3], 5000), ([4, 2], 4500), ([8], 8192)])
+def test_single_frame_blur_passes_go_two_per_launch(po, wl, d_list, N):
+    """ONE frame in flight on the streaming engine (BASELINE config 5 as written; round 4): the blur passes go two per launch
+    (k_blur2x2t on the two-hop table the streaming build leaves for single-frame batches, k_blur2x2 without a table), and with an
+    odd number of passes the one left over is done inside the slice (k_slice2<D1, true>).  Every d + 1 from 2 to 9 (pairs only,
+    pairs + left-over), two kernels of different d, locality mode on (>= 8192 points) and off: lattice sizes, Q and labels against
+    the oracle, bit for bit, over two builds and a second inference."""
+    pb = wl.generic_problem(N, d_list, 2, seed=700 + N % 97 + len(d_list), spread=3.0)
+    ws = [float(w) for _, w in pb["kernels"]]
+    b = pkg.BatchCRF(1, N, 2, d_list, ws)
+    b.set_inputs_host([N], [f[None] for f, _ in pb["kernels"]], unary=pb["unary"][None])
+    b.build(); b.build()
+    b.inference(3, True, relax=0.9)
+    b.inference(3, True, relax=0.9)
+    assert b.engine() == 1
+    Q, M = b.probability()[0], b.map()[0]
+    o = cc.setup(po.OracleCRF, pb)
+    o.inference_native(3, True, 0.9)
+    for k in range(len(d_list)):
+        assert int(b.lattice_sizes(k)[0]) == o.kernel(k)["V"], k
+    assert cc.same_bits(Q, o.probability()) and np.array_equal(M, o.map())
+    # the same frame as one of two frames in flight takes the one-pass-per-launch kernels: same bits
+    b2 = pkg.BatchCRF(2, N, 2, d_list, ws)
+    b2.set_inputs_host([N, N], [np.repeat(f[None], 2, 0) for f, _ in pb["kernels"]], unary=np.repeat(pb["unary"][None], 2, 0))
+    b2.build()
+    b2.inference(3, True, relax=0.9)
+    Q2 = b2.probability()
+    assert cc.same_bits(Q2[0], Q) and cc.same_bits(Q2[1], Q)
+    b.close(); b2.close(); o.close()
 
 
 @pytest.mark.gpu

@@ -127,6 +127,35 @@ def test_malformed_files_are_rejected(tmp_path, wl):
         list(rec.read_records(tmp_path / "ver"))
     with pytest.raises(rec.RecordError):
         rec.encode_frame(dict(rec.synthetic_frame(wl, 5, 1), vobservs=np.zeros(4, np.float32)))
+    # size fields are checked against what is left of the file BEFORE anything is read or allocated --
+    # a frame header that claims 2^32 - 1 points, a section header that claims 2^62 payload bytes, section counts beyond the payload
+    hb = 32
+    (tmp_path / "npts").write_bytes(blob[:hb] + (0xffffffff).to_bytes(4, "little") + blob[hb + 4:])
+    with pytest.raises(rec.RecordError):
+        list(rec.read_records(tmp_path / "npts"))
+    v2 = (SAMPLE_V2 if os.path.exists(SAMPLE_V2) else None)
+    if v2:
+        b2 = bytearray(open(v2, "rb").read())
+        fr0 = next(rec.read_records(v2))
+        assert fr0["sections"]
+        import struct
+        npts = struct.unpack_from("<I", b2, 32)[0]
+        flags = struct.unpack_from("<I", b2, 36)[0]
+        size = 80 + npts * (4 * 3 + 8 + 2) + (8 * npts if flags & rec.HAS_MATCH_PROB else 0) + (2 * npts if flags & rec.HAS_REF_LABEL else 0) \
+            + (8 * npts if flags & rec.HAS_REF_PROB else 0)
+        sec = 32 + size + (-size % 8)                     # first section header of frame 0: tag, flags, payload bytes (u64)
+        tag, sflags, nbytes = struct.unpack_from("<IIQ", b2, sec)
+        assert tag in (rec.SEC_UNARY, rec.SEC_BFMATCH, rec.SEC_POSE) and 0 < nbytes < len(b2)
+        huge = bytearray(b2)
+        struct.pack_into("<Q", huge, sec + 8, 1 << 62)
+        (tmp_path / "huge").write_bytes(bytes(huge))
+        with pytest.raises(rec.RecordError):
+            list(rec.read_records(tmp_path / "huge"))
+        cnt = bytearray(b2)
+        struct.pack_into("<I", cnt, sec + 16, 0xfffffff0)  # the section's first count (n_cand / n_query / n)
+        (tmp_path / "cnt").write_bytes(bytes(cnt))
+        with pytest.raises(rec.RecordError):
+            list(rec.read_records(tmp_path / "cnt"))
 
 
 def test_sample_records_agree_with_the_oracle(po):
