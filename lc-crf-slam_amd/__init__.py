@@ -24,6 +24,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "lccrf.h")
 
 MAX_KERNELS = 8
 OPT_SINGLE_WORKGROUP = 1        # lccrf_option (include/lccrf.h)
+OPT_VERTEX_ORDER = 2
 OK = 0
 _STATUS = {0: "OK", -1: "E_INVALID", -2: "E_NO_DEVICE", -3: "E_HIP", -4: "E_NOMEM", -5: "E_STATE",
            -6: "E_CAPACITY"}

@@ -188,6 +188,7 @@ struct Engine {
     bool frame_small_used = false;     //   more than 1/8 of a batch's frames did not fit that plan
     static constexpr int kDualMaxFrames = 64;    // (measured, `scripts/small_batch_latency.py`: 4 frames 98 -> 86 us, 32 frames 93 -> 83 us, 128 frames 112 -> 114 us)
     bool opt_single_wg = false;        // LCCRF_OPT_SINGLE_WORKGROUP: never the two-workgroup form (lccrf_set_option)
+    bool opt_vertex_order = false;     // LCCRF_OPT_VERTEX_ORDER: locality mode also numbers the vertices along the lattice's axes (next build)
     unsigned *dual_area = nullptr;     // hand-off area of the two-workgroup form of the frame kernel (batches of up to kDualMaxFrames frames)
     unsigned dual_epoch = 0;
     // object API: the frame kernel's last act is a store of `done_epoch` into this pinned word, behind its results; the host
@@ -235,6 +236,22 @@ struct Engine {
         if ((rc = mem.alloc(&sort.iperm, Fz * maxNpad))) return rc;
         if ((rc = mem.alloc(&Qp, Fz * maxN * L))) return rc;
         if ((rc = mem.alloc(&unary_p, Fz * maxN * L))) return rc;
+        // the vertex order of every kernel (one kernel at a time on the engine's stream: one set of arrays sized for the largest)
+        int vcap = 0;
+        for (auto &ks : kernels) vcap = std::max(vcap, ks.dev.Epad);
+        for (auto &ks : spare) vcap = std::max(vcap, ks.dev.Epad);
+        sort.vcap = vcap;
+        int vbits = 10;
+        while (vbits < 21 && (1 << vbits) < 4 * vcap) ++vbits;
+        sort.vbits = vbits;
+        const size_t vnbk = ((size_t)1 << vbits) + 1;
+        if ((rc = mem.alloc(&sort.vcode, Fz * vcap))) return rc;
+        if ((rc = mem.alloc(&sort.vperm, Fz * vcap))) return rc;
+        if ((rc = mem.alloc(&sort.vhist, Fz * vnbk))) return rc;
+        if ((rc = mem.alloc(&sort.vstart, Fz * vnbk))) return rc;
+        if ((rc = mem.alloc(&sort.vtiles, Fz * ((vnbk + 4095) / 4096 + 1)))) return rc;
+        if ((rc = mem.alloc(&sort.vpartial, Fz * ((maxNpad + 255) / 256 + 1) * 2 * kMaxD))) return rc;
+        if ((rc = mem.alloc(&sort.vplan, Fz * (2 * kMaxD + 2)))) return rc;
         return LCCRF_OK;
     }
 
@@ -425,6 +442,8 @@ struct Engine {
             kernels[i].dev.rowmax_host = row_host + i * Fcap;
             kernels[i].dev.perm = perm_on ? sort.perm : nullptr;
             kernels[i].dev.iperm = perm_on ? sort.iperm : nullptr;
+            static const bool env_vsort = getenv("LCCRF_VERTEX_ORDER") != nullptr;   // A/B switch: as if LCCRF_OPT_VERTEX_ORDER were set (same results)
+            kernels[i].dev.vperm = (perm_on && (opt_vertex_order || env_vsort) && sort.vperm && kernels[i].dev.Epad <= sort.vcap) ? sort.vperm : nullptr;
             kdevs[i] = kernels[i].dev;
             maxV[i] = kernels[i].maxV;
             maxRow[i] = kernels[i].maxRow;
@@ -476,7 +495,7 @@ struct Engine {
             } else {
                 m = 1;
                 kernels[k].dev.nbr2_ok = kernels[k].dev.nbr2 != nullptr;      // (the streaming build fills the two-hop table when there is one)
-                launch_build_kernel(kdevs[k], crf, kernels[k].maxV, stream);
+                launch_build_kernel(kdevs[k], crf, kernels[k].maxV, stream, perm_on ? &sort : nullptr);
                 launch_norm(kdevs[k], crf, kernels[k].maxV, stream);
                 HIP_TRY(hipMemcpyAsync(V_host + (size_t)k * Fcap, kernels[k].dev.V, sizeof(int) * F, hipMemcpyDeviceToHost, stream));
                 HIP_TRY(hipMemcpyAsync(row_host + (size_t)k * Fcap, kernels[k].dev.rowmax, sizeof(int) * F, hipMemcpyDeviceToHost, stream));
@@ -859,6 +878,7 @@ int apply_option(Engine &e, int option, int value)
 {
     switch (option) {
     case LCCRF_OPT_SINGLE_WORKGROUP: e.opt_single_wg = value != 0; return LCCRF_OK;
+    case LCCRF_OPT_VERTEX_ORDER: e.opt_vertex_order = value != 0; return LCCRF_OK;      // (takes effect with the next build)
     default: return fail(LCCRF_E_INVALID, "unknown option %d", option);
     }
 }
@@ -924,6 +944,7 @@ int lccrf_create(lccrf_handle *out, int device_id, int n_points, int n_labels)
     h->eng.ensure_parked_idle();                          // (a reused handle: its last kernel has stored its done word, or we wait for it)
     h->N = n_points;
     h->eng.opt_single_wg = g_default_single_wg.load(std::memory_order_relaxed) != 0;   // (a recycled handle does not inherit its last user's options)
+    h->eng.opt_vertex_order = false;
     h->eng.activeN = n_points;
     h->eng.crf.map = h->map_pin;
     h->eng.map_host = h->map_pin;
@@ -972,7 +993,7 @@ int lccrf_set_default_option(int option, int value)
 {
     switch (option) {
     case LCCRF_OPT_SINGLE_WORKGROUP: g_default_single_wg.store(value != 0, std::memory_order_relaxed); return LCCRF_OK;
-    default: return fail(LCCRF_E_INVALID, "unknown option %d", option);
+    default: return fail(LCCRF_E_INVALID, "option %d has no process-wide default", option);
     }
 }
 

@@ -80,33 +80,74 @@ inline dim3 grid_for(long work, int F)
 // One thread per point (phantom lanes included): elevate, round, rank, barycentric.
 // ref: permutohedral_cpu.h:294-366.
 template <int D>
-__global__ void __launch_bounds__(kBlock) k_points(KernelDev kd, const int *__restrict__ n_points)
+__device__ __forceinline__ void vertex_grid_coords(const int16_t (&key)[D], int (&c)[D]);
+
+// VB: also leave, per workgroup, the bounds of the grid coordinates of every corner this workgroup's points touch (locality mode's
+// vertex order, see launch_sort_vertices below) in vpartial[f][blockIdx.x][2 * kMaxD]
+template <int D, bool VB>
+__global__ void __launch_bounds__(kBlock) k_points(KernelDev kd, const int *__restrict__ n_points, int *__restrict__ vpartial)
 {
     constexpr int D1 = D + 1;
+    __shared__ int red[VB ? kBlock / 64 : 1][2 * D];
     const int f = blockIdx.y;
     const int N = n_points[f];
     const int Npad = (N + 3) & ~3;                       // blocks of four, :294
     const int n = blockIdx.x * kBlock + threadIdx.x;
-    if (n >= Npad) return;
-
-    float feat[D];
-    const int src = (kd.perm && n < N) ? kd.perm[(size_t)f * kd.maxNpad + n] : n;   // locality mode: position n holds point perm[n]
-    const float *fp = kd.feat + ((size_t)f * kd.maxN + src) * D;
+    const bool live = n < Npad;
+    if (!VB && !live) return;
+    int lo[D], hi[D];
 #pragma unroll
-    for (int j = 0; j < D; ++j) feat[j] = (n < N) ? fp[j] : 0.0f;   // phantom lanes, :299
-
-    int16_t r0[D];
-    uint8_t rk[D];
-    float b[D1];
-    point_record<D>(feat, kd.scale, kd.inv_dp1, r0, rk, b);
-
-    int16_t *r0p = kd.rem0 + ((size_t)f * kd.maxNpad + n) * D;
-    uint8_t *rkp = kd.rank + ((size_t)f * kd.maxNpad + n) * D;
-    float *bp = kd.bary + (size_t)f * kd.Epad + (size_t)n * D1;
+    for (int j = 0; j < D; ++j) { lo[j] = 0x7fffffff; hi[j] = (int)0x80000000; }
+    if (live) {
+        float feat[D];
+        const int src = (kd.perm && n < N) ? kd.perm[(size_t)f * kd.maxNpad + n] : n;   // locality mode: position n holds point perm[n]
+        const float *fp = kd.feat + ((size_t)f * kd.maxN + src) * D;
 #pragma unroll
-    for (int i = 0; i < D; ++i) { r0p[i] = r0[i]; rkp[i] = rk[i]; }
+        for (int j = 0; j < D; ++j) feat[j] = (n < N) ? fp[j] : 0.0f;   // phantom lanes, :299
+
+        int16_t r0[D];
+        uint8_t rk[D];
+        float b[D1];
+        point_record<D>(feat, kd.scale, kd.inv_dp1, r0, rk, b);
+
+        int16_t *r0p = kd.rem0 + ((size_t)f * kd.maxNpad + n) * D;
+        uint8_t *rkp = kd.rank + ((size_t)f * kd.maxNpad + n) * D;
+        float *bp = kd.bary + (size_t)f * kd.Epad + (size_t)n * D1;
 #pragma unroll
-    for (int i = 0; i < D1; ++i) bp[i] = b[i];
+        for (int i = 0; i < D; ++i) { r0p[i] = r0[i]; rkp[i] = rk[i]; }
+#pragma unroll
+        for (int i = 0; i < D1; ++i) bp[i] = b[i];
+        if (VB) {
+#pragma unroll
+            for (int rem = 0; rem < D1; ++rem) {
+                int16_t key[D];
+                int c[D];
+#pragma unroll
+                for (int i = 0; i < D; ++i) key[i] = vertex_coord<D>(r0[i], rk[i], rem);
+                vertex_grid_coords<D>(key, c);
+#pragma unroll
+                for (int j = 0; j < D; ++j) { lo[j] = min(lo[j], c[j]); hi[j] = max(hi[j], c[j]); }
+            }
+        }
+    }
+    if (VB) {                                             // (every lane of the workgroup gets here: one barrier for all)
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            int l = lo[j], h = hi[j];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                l = min(l, __shfl_xor(l, o, 64));
+                h = max(h, __shfl_xor(h, o, 64));
+            }
+            if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][2 * j] = l; red[threadIdx.x >> 6][2 * j + 1] = h; }
+        }
+        __syncthreads();
+        if (threadIdx.x < 2 * D) {
+            int x = red[0][threadIdx.x];
+            for (int w = 1; w < kBlock / 64; ++w) x = (threadIdx.x & 1) ? max(x, red[w][threadIdx.x]) : min(x, red[w][threadIdx.x]);
+            vpartial[((size_t)f * gridDim.x + blockIdx.x) * 2 * kMaxD + threadIdx.x] = x;
+        }
+    }
 }
 
 // One thread per entry: insert its vertex key into the frame's hash table.  A slot ends up
@@ -443,6 +484,138 @@ void sort_points_d(const KernelDev &kd, const CrfDev &c, const SortScratch &ss, 
     k_sort_place<<<gp, kBlock, 0, s>>>(kd.maxNpad, c.n_points, ss);
 }
 
+// ---- locality mode, part two: the VERTICES in row-major order of the lattice's own axes --------------------------------------
+// A lattice vertex is x in Z^(d+1) with sum 0 and all coordinates congruent mod d+1 (its key = the first d of them).  In the basis
+// of the blur directions u_j = (1, .., 1) - (d+1) e_j it is the integer point c with c_j = (x_d - x_j) / (d+1), j < d: blur axis
+// j < d is the unit step along c_j and axis d the step along the main diagonal (permutohedral_cpu.h:408-421 in those
+// coordinates).  Numbering the vertices in ROW-MAJOR order of c makes the neighbours of consecutive ids consecutive ids of
+// another row: a wavefront's blur gather touches 9 distinct 128-byte lines instead of 19 (scripts/sim_vertex_order.py, the C5
+// lattice) and the pass takes 19.5 instead of 23.2 us per 8 frames (scripts/ubench/blurorder.hip on the real tables).  Only
+// locality depends on the numbering, never a result (a vertex's value is a sum over its own row, neighbours are matched by key).
+// One-pass bucket sort on the top ~20 bits of the code (a histogram, its scan, a scatter); a bucket is ~200 consecutive codes -- a
+// few lattice rows, one or two vertices -- and keeps its arrival order.
+
+template <int D>
+__device__ __forceinline__ void vertex_grid_coords(const int16_t (&key)[D], int (&c)[D])
+{
+    int xd = 0;
+#pragma unroll
+    for (int j = 0; j < D; ++j) xd -= key[j];
+#pragma unroll
+    for (int j = 0; j < D; ++j) c[j] = (xd - key[j]) / (D + 1);          // exact: the coordinates are congruent mod d+1
+}
+
+// One workgroup per frame: bounds of the grid coordinates -> row-major strides (coordinate 0 fastest) and the shift that maps a
+// code to its bucket.  vplan[f] = {lo[kMaxD], stride[kMaxD], shift, usable}; a lattice whose bounding box overflows 62 bits
+// (features spread over thousands of cells in every dimension) keeps its first-occurrence numbering.
+__global__ void __launch_bounds__(kBlock) k_vsort_plan(int D, int nblocks, SortScratch ss)
+{
+    __shared__ int red[kBlock / 64][2 * kMaxD];
+    __shared__ int bnd[2 * kMaxD];
+    const int f = blockIdx.x;
+    for (int j = 0; j < D; ++j) {
+        int lo = 0x7fffffff, hi = (int)0x80000000;
+        for (int b = threadIdx.x; b < nblocks; b += kBlock) {
+            const int *pp = ss.vpartial + ((size_t)f * nblocks + b) * 2 * kMaxD;
+            lo = min(lo, pp[2 * j]);
+            hi = max(hi, pp[2 * j + 1]);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            lo = min(lo, __shfl_xor(lo, o, 64));
+            hi = max(hi, __shfl_xor(hi, o, 64));
+        }
+        if ((threadIdx.x & 63) == 0) {
+            red[threadIdx.x >> 6][2 * j] = lo;
+            red[threadIdx.x >> 6][2 * j + 1] = hi;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * D) {
+        int x = red[0][threadIdx.x];
+        for (int w = 1; w < kBlock / 64; ++w) x = (threadIdx.x & 1) ? max(x, red[w][threadIdx.x]) : min(x, red[w][threadIdx.x]);
+        bnd[threadIdx.x] = x;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        long long *plan = ss.vplan + (size_t)f * (2 * kMaxD + 2);
+        unsigned long long range = 1;
+        bool ok = true;
+        for (int j = 0; j < D; ++j) {
+            const int lo = bnd[2 * j], hi = bnd[2 * j + 1];
+            const unsigned long long span = hi >= lo ? (unsigned long long)((long long)hi - lo + 1) : 1ull;   // (an empty frame has no vertices)
+            plan[j] = hi >= lo ? lo : 0;
+            plan[kMaxD + j] = (long long)range;
+            if (span > (1ull << 62) / range) ok = false;
+            else range *= span;
+        }
+        int shift = 0;
+        while (ok && (range >> shift) > (1ull << ss.vbits)) ++shift;
+        plan[2 * kMaxD] = shift;
+        plan[2 * kMaxD + 1] = ok ? 1 : 0;
+    }
+}
+
+template <int D>
+__global__ void __launch_bounds__(kBlock) k_vsort_code(KernelDev kd, const int *__restrict__ n_points, SortScratch ss)
+{
+    const int f = blockIdx.y;
+    const int live = ((n_points[f] + 3) & ~3) * (D + 1);
+    const int e = blockIdx.x * kBlock + threadIdx.x;
+    if (e >= live || !kd.flag[(size_t)f * (kd.Epad + 1) + e]) return;
+    const int id = kd.prefix[(size_t)f * (kd.Epad + 1) + e];              // first-occurrence id
+    const long long *plan = ss.vplan + (size_t)f * (2 * kMaxD + 2);
+    unsigned long long code = (unsigned long long)id;                     // (unusable plan: identity)
+    int shift = 0;
+    if (plan[2 * kMaxD + 1]) {
+        int16_t key[D];
+        int c[D];
+        load_entry_key<D>(kd, f, e, key);
+        vertex_grid_coords<D>(key, c);
+        code = 0;
+#pragma unroll
+        for (int j = 0; j < D; ++j) code += (unsigned long long)((long long)c[j] - plan[j]) * (unsigned long long)plan[kMaxD + j];
+        shift = (int)plan[2 * kMaxD];
+    } else {
+        while ((((unsigned long long)kd.Epad) >> shift) > (1ull << ss.vbits)) ++shift;
+    }
+    ss.vcode[(size_t)f * ss.vcap + id] = code;
+    atomicAdd(&ss.vhist[(size_t)f * ((1 << ss.vbits) + 1) + (int)(code >> shift)], 1);
+}
+
+__device__ __forceinline__ int vsort_shift(const KernelDev &kd, const SortScratch &ss, int f)
+{
+    const long long *plan = ss.vplan + (size_t)f * (2 * kMaxD + 2);
+    if (plan[2 * kMaxD + 1]) return (int)plan[2 * kMaxD];
+    int shift = 0;
+    while ((((unsigned long long)kd.Epad) >> shift) > (1ull << ss.vbits)) ++shift;
+    return shift;
+}
+
+__global__ void __launch_bounds__(kBlock) k_vsort_scatter(KernelDev kd, SortScratch ss)
+{
+    const int f = blockIdx.y;
+    const int id = blockIdx.x * kBlock + threadIdx.x;
+    if (id >= kd.V[f]) return;
+    const int b = (int)(ss.vcode[(size_t)f * ss.vcap + id] >> vsort_shift(kd, ss, f));
+    // the vertex's place = its bucket's start + its arrival number: buckets are ~200 consecutive codes (a few lattice rows) holding
+    // one or two vertices, so the order inside one is immaterial for locality (and for nothing else: numbering is free)
+    ss.vperm[(size_t)f * kd.Epad + id] = atomicAdd(&ss.vstart[(size_t)f * ((1 << ss.vbits) + 1) + b], 1);
+}
+
+template <int D>
+void sort_vertices_d(const KernelDev &kd, const CrfDev &c, const SortScratch &ss, hipStream_t s)
+{
+    const int F = c.F, nbk = (1 << ss.vbits) + 1;
+    const dim3 ge = grid_for(kd.Epad, F);
+    // (k_points left the per-workgroup bounds of the vertices' grid coordinates in ss.vpartial)
+    k_vsort_plan<<<F, kBlock, 0, s>>>(D, (int)grid_for(kd.maxNpad, F).x, ss);
+    (void)hipMemsetAsync(ss.vhist, 0, (size_t)F * nbk * sizeof(int), s);
+    k_vsort_code<D><<<ge, kBlock, 0, s>>>(kd, c.n_points, ss);
+    scan_frames(ss.vhist, ss.vstart, nbk, nbk, nullptr, ss.vtiles, F, s);
+    k_vsort_scatter<<<ge, kBlock, 0, s>>>(kd, ss);
+}
+
 // offset[e] = dense id of e's vertex; the first entry of each vertex registers as its
 // representative.  Ids come out in first-insertion order, exactly the reference's ids.
 __global__ void __launch_bounds__(kBlock) k_offsets(KernelDev kd, const int *__restrict__ n_points)
@@ -454,7 +627,8 @@ __global__ void __launch_bounds__(kBlock) k_offsets(KernelDev kd, const int *__r
     const size_t fe = (size_t)f * kd.Epad;
     const int *prefix = kd.prefix + (size_t)f * (kd.Epad + 1);
     const int r = kd.slot[(size_t)f * kd.cap + kd.slot_of[fe + e]];
-    const int id = prefix[r];
+    int id = prefix[r];
+    if (kd.vperm) id = kd.vperm[fe + id];                // locality mode: vertices numbered along the lattice's axes
     kd.offset[fe + e] = id;
     if (r == e) kd.rep[fe + id] = e;
 }
@@ -473,7 +647,10 @@ __device__ __forceinline__ int find_vertex(const KernelDev &kd, int f, const int
         bool same = true;
 #pragma unroll
         for (int i = 0; i < D; ++i) same &= (other[i] == key[i]);
-        if (same) return kd.prefix[(size_t)f * (kd.Epad + 1) + r];
+        if (same) {
+            const int id = kd.prefix[(size_t)f * (kd.Epad + 1) + r];
+            return kd.vperm ? kd.vperm[(size_t)f * kd.Epad + id] : id;   // (locality mode renumbers the vertices)
+        }
         h = (h + 1u) & mask;
     }
 }
@@ -992,11 +1169,12 @@ __global__ void __launch_bounds__(kBlock) k_validate_npoints(const int *__restri
 }
 
 template <int D>
-void build_kernel_d(const KernelDev &kd, const CrfDev &c, hipStream_t s)
+void build_kernel_d(const KernelDev &kd, const CrfDev &c, hipStream_t s, const SortScratch *vsort)
 {
     const int F = c.F, D1 = D + 1;
     (void)hipMemsetAsync(kd.slot, 0xff, (size_t)F * kd.cap * sizeof(int), s);
-    k_points<D><<<grid_for(kd.maxNpad, F), kBlock, 0, s>>>(kd, c.n_points);
+    if (vsort && kd.vperm) k_points<D, true><<<grid_for(kd.maxNpad, F), kBlock, 0, s>>>(kd, c.n_points, vsort->vpartial);
+    else k_points<D, false><<<grid_for(kd.maxNpad, F), kBlock, 0, s>>>(kd, c.n_points, nullptr);
     {
         XcdMap nb;
         const dim3 g = grid_xcd(kd.Epad, F, &nb);
@@ -1004,6 +1182,7 @@ void build_kernel_d(const KernelDev &kd, const CrfDev &c, hipStream_t s)
     }
     k_first_flag<<<grid_for(kd.Epad + 1, F), kBlock, 0, s>>>(kd, c.n_points);
     scan_frames(kd.flag, kd.prefix, kd.Epad + 1, kd.Epad + 1, kd.V, kd.rep, F, s);     // (rep is written later, by k_offsets: free scratch)
+    if (vsort && kd.vperm) sort_vertices_d<D>(kd, c, *vsort, s);                        // locality mode: ids along the lattice's axes
     k_offsets<<<grid_for(kd.Epad, F), kBlock, 0, s>>>(kd, c.n_points);
     (void)hipMemsetAsync(kd.nbr, 0xff, (size_t)F * D1 * kd.Epad * 2 * sizeof(int), s);          // every neighbour absent (-1)
     {
@@ -1026,17 +1205,17 @@ void build_kernel_d(const KernelDev &kd, const CrfDev &c, hipStream_t s)
 
 }  // namespace
 
-void launch_build_kernel(const KernelDev &kd, const CrfDev &c, int, hipStream_t s)
+void launch_build_kernel(const KernelDev &kd, const CrfDev &c, int, hipStream_t s, const SortScratch *vsort)
 {
     switch (kd.d) {
-    case 1: build_kernel_d<1>(kd, c, s); break;
-    case 2: build_kernel_d<2>(kd, c, s); break;
-    case 3: build_kernel_d<3>(kd, c, s); break;
-    case 4: build_kernel_d<4>(kd, c, s); break;
-    case 5: build_kernel_d<5>(kd, c, s); break;
-    case 6: build_kernel_d<6>(kd, c, s); break;
-    case 7: build_kernel_d<7>(kd, c, s); break;
-    case 8: build_kernel_d<8>(kd, c, s); break;
+    case 1: build_kernel_d<1>(kd, c, s, vsort); break;
+    case 2: build_kernel_d<2>(kd, c, s, vsort); break;
+    case 3: build_kernel_d<3>(kd, c, s, vsort); break;
+    case 4: build_kernel_d<4>(kd, c, s, vsort); break;
+    case 5: build_kernel_d<5>(kd, c, s, vsort); break;
+    case 6: build_kernel_d<6>(kd, c, s, vsort); break;
+    case 7: build_kernel_d<7>(kd, c, s, vsort); break;
+    case 8: build_kernel_d<8>(kd, c, s, vsort); break;
     default: break;
     }
 }

@@ -671,6 +671,7 @@ def test_large_ragged_batch_matches_oracle(po, wl, d_list, L):
             feats[k][f, :n] = pb["kernels"][k][0]
     ws = [float(pbs[0]["kernels"][k][1]) for k in range(len(d_list))]
     b = pkg.BatchCRF(F, maxN, L, d_list, ws)
+    b.set_option(pkg.OPT_VERTEX_ORDER, 1 if L == 2 else 0)   # (mixed dimensions, ragged and empty frames through the vertex sort too)
     b.set_inputs_host(sizes, feats, unary=unary)
     b.build()
     b.inference(3, True, relax=0.9)
@@ -717,11 +718,13 @@ def test_large_ragged_batch_matches_oracle(po, wl, d_list, L):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("vertex_order", [0, 1])
 @pytest.mark.parametrize("name", ["c5", "gen"])
-def test_locality_mode_on_reference_vectors(golden, name):
+def test_locality_mode_on_reference_vectors(golden, name, vertex_order):
     """Locality mode against vectors generated by the reference build itself (tests/golden/large.npz): a frame alone,
     and eight copies (XCD-aware grids), must reproduce the reference's V, norm, Q and labels bit for bit although the
-    points are processed in an internal order."""
+    points are processed in an internal order -- and, with LCCRF_OPT_VERTEX_ORDER, the vertices numbered in row-major order of
+    the lattice's own axes (round 4: a vertex sort inside the build; results must not depend on how vertices are numbered)."""
     from test_oracle_golden import _large_case
     z = golden["large"]
     pb, n_iter, relax = _large_case(z, name)
@@ -729,6 +732,7 @@ def test_locality_mode_on_reference_vectors(golden, name):
     f, w = pb["kernels"][0]
     for F in (1, 8):
         b = pkg.BatchCRF(F, N, L, [f.shape[1]], [float(w)])
+        b.set_option(pkg.OPT_VERTEX_ORDER, vertex_order)
         feats = [np.repeat(f[None], F, 0)]
         if "unary" in pb:
             b.set_inputs_host([N] * F, feats, unary=np.repeat(pb["unary"][None], F, 0))
@@ -765,6 +769,15 @@ def test_locality_mode_with_labels_and_device_inputs(po, wl):
     for rep in range(2):
         b.inference(4, True)
     Q, M, Vs = b.probability(), b.map(), b.lattice_sizes(0)
+    # the same batch with the vertices numbered along the lattice's axes (option set between two builds of one handle): same bits
+    b.set_option(pkg.OPT_VERTEX_ORDER, 1)
+    b.build()
+    b.inference(4, True)
+    assert cc.same_bits(b.probability(), Q) and np.array_equal(b.map(), M) and np.array_equal(b.lattice_sizes(0), Vs)
+    b.set_option(pkg.OPT_VERTEX_ORDER, 0)
+    b.build()
+    b.inference(4, True)
+    assert cc.same_bits(b.probability(), Q) and np.array_equal(b.map(), M)
     b.run(4, True)                                         # lccrf_batch_run on frames beyond the one-launch kernel: rebuild + infer
     assert b.engine() == 1 and cc.same_bits(b.probability(), Q) and np.array_equal(b.map(), M)
     for i, pb in enumerate(frames):
