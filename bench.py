@@ -414,6 +414,11 @@ def slam_subrecord(pkg, wl, torch, dev, name, steps=10, warmup=3, distinct=32):
                           "frames_per_s": F / (run_ms * 1e-3), "two_kernel_ms_per_batch": build_ms + inf_ms},
            "label_match_vs_cpu_reference": label_match, "max_abs_dQ_vs_cpu_reference": max_dq,
            "frames_checked": frames_checked, "tiles_identical": tiles_ok}
+    ptag = latest_profile({"c1": "small_c1", "c4": "fused_c4"}.get(name, "none"))      # committed rocprofv3 summary of `bench.py --workload <name>`
+    if ptag:
+        tr = pmc_traffic(ptag, "k_fused")
+        rec["roofline"].update({"profile": "profiles/%s (kernel_stats.csv: the launch duration; pmc_summary.csv: FETCH x2 + WRITE)" % ptag,
+                                "traffic": tr, "hbm_counter_frac": (tr / (inf_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if tr else None})
     b.close()
     del d_feats, d_label, d_np
     torch.cuda.empty_cache()
@@ -511,6 +516,13 @@ def c5_record(pkg, wl, torch, dev, steps=6, frames=8):
             M, Q = b.map(), b.probability()
             fc, lm, dq = check_distinct_frames(pbs[:1], idx, M, Q, n_iter)
             rec["label_match_vs_cpu_reference"], rec["max_abs_dQ_vs_cpu_reference"], rec["frames_checked"] = lm, dq, fc
+            ptag = latest_profile("stream_c5_f1")
+            if ptag:                                    # per iteration: 3 two-pass launches + the slice (with the 7th pass) + the splat
+                per_it = [pmc_traffic(ptag, k) for k in ("k_blur2x2t", "k_slice2", "k_splat2")]
+                if all(per_it):
+                    tr = 3 * per_it[0] + per_it[1] + per_it[2]
+                    rec["roofline_whole_iteration"].update({"traffic": tr, "traffic_over_algorithmic": tr / bytes_iter,
+                                                            "profile": "profiles/%s (kernel_stats.csv, pmc_summary.csv: FETCH x2 + WRITE per launch)" % ptag})
             out["single_frame"] = rec
         b.close()
         del f, lab, npt

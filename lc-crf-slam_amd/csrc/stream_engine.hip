@@ -1024,6 +1024,7 @@ __global__ void __launch_bounds__(kBlock) k_blur2x2t(KernelDev kd, const float *
     d[v] = make_float2(tv.x + 0.5f * (ta.x + tbv.x), tv.y + 0.5f * (ta.y + tbv.y));
 }
 
+constexpr int kSliceBlurMaxFrames = 2;       // the last blur pass inside the slice (k_slice2<D1, true>) up to this many frames in flight (scripts/gpu_r4_sliceblur.sh: 2 frames -2 %, 4 and 8 +-0)
 constexpr int kPairFuseMaxFrames = 1;        // (measured, scripts/gpu_r4_pairs.sh: one C5 frame 52.5 -> 45.2 us per iteration; two or four frames in flight: +-0)
 inline bool pair_fuse(int F)
 {
@@ -1269,7 +1270,9 @@ void launch_step_stream(const CrfDev &c, const KernelDev *kds, const int *maxV, 
             const float *src = kd.val0;
             float *dst = kd.val1;
             const bool pairs = pair_fuse(c.F);
-            const bool blur_in_slice = pairs && (kd.D1 & 1) && kd.D1 >= 3 && kd.D1 <= 9;   // the pass left over by the pairs rides in the slice
+            // the pass left over by the pairs rides in the slice; with a few frames in flight (one pass per launch) the last pass does
+            static const char *sf = getenv("LCCRF_SLICE_BLUR_MAX");                          // (A/B: frames-in-flight threshold)
+            const bool blur_in_slice = kd.D1 <= 9 && (pairs ? (kd.D1 & 1) && kd.D1 >= 3 : c.F <= (sf ? atoi(sf) : kSliceBlurMaxFrames));
             const int n_own = blur_in_slice ? kd.D1 - 1 : kd.D1;                           // blur passes with a launch of their own
             for (int j = 0; j < n_own;) {
                 if (pairs && j + 1 < n_own) {             // one frame in flight: two passes per launch
@@ -1294,13 +1297,13 @@ void launch_step_stream(const CrfDev &c, const KernelDev *kds, const int *maxV, 
         else k_slice2<D><<<g, kBlock, 0, s>>>(kd, c, src, first, last, relax, nb);               \
         break;
             switch (kd.D1) {
-            case 2: k_slice2<2><<<g, kBlock, 0, s>>>(kd, c, src, first, last, relax, nb); break;
+            LCCRF_SLICE_CASE(2)
             LCCRF_SLICE_CASE(3)
-            case 4: k_slice2<4><<<g, kBlock, 0, s>>>(kd, c, src, first, last, relax, nb); break;
+            LCCRF_SLICE_CASE(4)
             LCCRF_SLICE_CASE(5)
-            case 6: k_slice2<6><<<g, kBlock, 0, s>>>(kd, c, src, first, last, relax, nb); break;
+            LCCRF_SLICE_CASE(6)
             LCCRF_SLICE_CASE(7)
-            case 8: k_slice2<8><<<g, kBlock, 0, s>>>(kd, c, src, first, last, relax, nb); break;
+            LCCRF_SLICE_CASE(8)
             LCCRF_SLICE_CASE(9)
             default: break;
             }
