@@ -25,6 +25,7 @@ namespace lccrf {
 namespace {
 
 constexpr int kBlock = 256;
+constexpr int kSmallFBlock = 64;          // lanes per workgroup of the iteration kernels with one or two frames in flight (iter_block)
 
 // XCD-aware grids.  The chip's eight XCDs have private 4 MB L2s and workgroup L of a launch runs on XCD L % 8 (observed
 // dispatch order; used for speed only, never for correctness).  With the frame in blockIdx.y every XCD touches every frame's
@@ -50,9 +51,18 @@ __device__ __forceinline__ FrameBlock frame_block(XcdMap m)
     }
     return FrameBlock{xcd / m.G, (xcd % m.G) * m.nb + q};  // (a block index beyond the frame's work fails the kernel's own range check)
 }
-inline dim3 grid_xcd(long work, int F, XcdMap *m)
+// lanes per workgroup of the iteration kernels: 256; with one or two frames in flight a pass is a chain of latencies and smaller
+// workgroups drain sooner (scripts/ubench/phasecost.hip: 256 -> 64 lanes 6.8 -> 6.4 us per pass of one C5 frame; in the engine,
+// scripts/gpu_r4_block.sh: one frame 41.0 -> 40.2 us per iteration, two 32.8 -> 32.1, four +-0)
+inline int iter_block(int F)
 {
-    const long n = (work + 256 - 1) / 256;
+    static const char *e = getenv("LCCRF_SMALL_F_BLOCK");             // A/B switch: same results
+    static const int small = e ? std::min(std::max(atoi(e), 64), 256) & ~63 : kSmallFBlock;
+    return F <= 2 ? small : 256;
+}
+inline dim3 grid_xcd(long work, int F, XcdMap *m, int block = 256)
+{
+    const long n = (work + block - 1) / block;
     if (n < 1) { *m = XcdMap{0, 1}; return dim3(1u, (unsigned)F); }
     if (F >= 8) {
         *m = XcdMap{(int)n, 1};
@@ -915,7 +925,7 @@ __global__ void __launch_bounds__(kBlock) k_splat2(KernelDev kd, const float2 *_
     const FrameBlock fb = frame_block(nb);
     const int f = fb.f;
     if (f >= F) return;
-    const int v = fb.bx * kBlock + threadIdx.x;
+    const int v = fb.bx * (int)blockDim.x + threadIdx.x;
     if (v >= kd.V[f]) return;
     const size_t fe = (size_t)f * kd.Epad, f1 = (size_t)f * (kd.Epad + 1);
     const float2 *x = in + (size_t)f * in_stride;
@@ -954,7 +964,7 @@ __global__ void __launch_bounds__(kBlock) k_blur2(KernelDev kd, const float *__r
     const int f = fb.f;
     if (f >= F) return;
     const int V = kd.V[f];
-    const int v = 2 * (fb.bx * kBlock + threadIdx.x);
+    const int v = 2 * (fb.bx * (int)blockDim.x + threadIdx.x);
     if (v >= V) return;
     const float2 *o = reinterpret_cast<const float2 *>(src + (size_t)f * kd.vstride + kd.vbase);   // o[-1] = absent
     float2 *d = reinterpret_cast<float2 *>(dst + (size_t)f * kd.vstride + kd.vbase);
@@ -984,7 +994,7 @@ __global__ void __launch_bounds__(kBlock) k_blur2x2(KernelDev kd, const float *_
     const FrameBlock fb = frame_block(nb);
     const int f = fb.f;
     if (f >= F) return;
-    const int v = fb.bx * kBlock + threadIdx.x;
+    const int v = fb.bx * (int)blockDim.x + threadIdx.x;
     if (v >= kd.V[f]) return;
     const float2 *o = reinterpret_cast<const float2 *>(src + (size_t)f * kd.vstride + kd.vbase);   // o[-1] = absent
     float2 *d = reinterpret_cast<float2 *>(dst + (size_t)f * kd.vstride + kd.vbase);
@@ -1009,7 +1019,7 @@ __global__ void __launch_bounds__(kBlock) k_blur2x2t(KernelDev kd, const float *
     const FrameBlock fb = frame_block(nb);
     const int f = fb.f;
     if (f >= F) return;
-    const int v = fb.bx * kBlock + threadIdx.x;
+    const int v = fb.bx * (int)blockDim.x + threadIdx.x;
     if (v >= kd.V[f]) return;
     const float2 *o = reinterpret_cast<const float2 *>(src + (size_t)f * kd.vstride + kd.vbase);   // o[-1] = absent
     float2 *d = reinterpret_cast<float2 *>(dst + (size_t)f * kd.vstride + kd.vbase);
@@ -1036,9 +1046,10 @@ inline bool pair_fuse(int F)
 inline void launch_blur2(const KernelDev &kd, const float *src, float *dst, int j, int F, int maxV, hipStream_t s)
 {
     XcdMap nb;
-    const dim3 g = grid_xcd((maxV + 1) / 2, F, &nb);
-    if (F >= 8) k_blur2<true><<<g, kBlock, 0, s>>>(kd, src, dst, j, F, nb);
-    else k_blur2<false><<<g, kBlock, 0, s>>>(kd, src, dst, j, F, nb);
+    const int blk = iter_block(F);
+    const dim3 g = grid_xcd((maxV + 1) / 2, F, &nb, blk);
+    if (F >= 8) k_blur2<true><<<g, blk, 0, s>>>(kd, src, dst, j, F, nb);
+    else k_blur2<false><<<g, blk, 0, s>>>(kd, src, dst, j, F, nb);
 }
 
 // slice + apply for L = 2; the LAST kernel of the step also does the softmax (saves a pass over next).
@@ -1053,7 +1064,7 @@ __global__ void __launch_bounds__(kBlock) k_slice2(KernelDev kd, CrfDev c, const
     const FrameBlock fb = frame_block(nb);
     const int f = fb.f;
     if (f >= c.F) return;
-    const int i = fb.bx * kBlock + threadIdx.x;
+    const int i = fb.bx * (int)blockDim.x + threadIdx.x;
     if (i >= c.n_points[f]) return;
     const size_t fe = (size_t)f * kd.Epad;
     const float2 *vf = reinterpret_cast<const float2 *>(val + (size_t)f * kd.vstride + kd.vbase);
@@ -1265,8 +1276,9 @@ void launch_step_stream(const CrfDev &c, const KernelDev *kds, const int *maxV, 
         for (int k = 0; k < c.K; ++k) {
             const KernelDev &kd = kds[k];
             XcdMap nb;
-            dim3 g = grid_xcd(maxV[k], c.F, &nb);
-            k_splat2<<<g, kBlock, 0, s>>>(kd, reinterpret_cast<const float2 *>(c.Q), c.maxN, c.F, nb);
+            const int blk = iter_block(c.F);
+            dim3 g = grid_xcd(maxV[k], c.F, &nb, blk);
+            k_splat2<<<g, blk, 0, s>>>(kd, reinterpret_cast<const float2 *>(c.Q), c.maxN, c.F, nb);
             const float *src = kd.val0;
             float *dst = kd.val1;
             const bool pairs = pair_fuse(c.F);
@@ -1276,10 +1288,10 @@ void launch_step_stream(const CrfDev &c, const KernelDev *kds, const int *maxV, 
             const int n_own = blur_in_slice ? kd.D1 - 1 : kd.D1;                           // blur passes with a launch of their own
             for (int j = 0; j < n_own;) {
                 if (pairs && j + 1 < n_own) {             // one frame in flight: two passes per launch
-                    const dim3 gp = grid_xcd(maxV[k], c.F, &nb);
+                    const dim3 gp = grid_xcd(maxV[k], c.F, &nb, blk);
                     static const bool no_tbl = getenv("LCCRF_NO_2HOP_TABLE") != nullptr;      // A/B switch: same results either way
-                    if (kd.nbr2 && kd.nbr2_ok && !no_tbl) k_blur2x2t<<<gp, kBlock, 0, s>>>(kd, src, dst, j / 2, kd.D1 / 2, c.F, nb);
-                    else k_blur2x2<<<gp, kBlock, 0, s>>>(kd, src, dst, j, c.F, nb);
+                    if (kd.nbr2 && kd.nbr2_ok && !no_tbl) k_blur2x2t<<<gp, blk, 0, s>>>(kd, src, dst, j / 2, kd.D1 / 2, c.F, nb);
+                    else k_blur2x2<<<gp, blk, 0, s>>>(kd, src, dst, j, c.F, nb);
                     j += 2;
                 } else {
                     launch_blur2(kd, src, dst, j, c.F, maxV[k], s);
@@ -1290,11 +1302,11 @@ void launch_step_stream(const CrfDev &c, const KernelDev *kds, const int *maxV, 
                 dst = const_cast<float *>(t);
             }
             const int first = k == 0, last = k == c.K - 1;
-            g = grid_xcd(c.maxN, c.F, &nb);
+            g = grid_xcd(c.maxN, c.F, &nb, blk);
 #define LCCRF_SLICE_CASE(D)                                                                       \
     case D:                                                                                      \
-        if (blur_in_slice) k_slice2<D, true><<<g, kBlock, 0, s>>>(kd, c, src, first, last, relax, nb); \
-        else k_slice2<D><<<g, kBlock, 0, s>>>(kd, c, src, first, last, relax, nb);               \
+        if (blur_in_slice) k_slice2<D, true><<<g, blk, 0, s>>>(kd, c, src, first, last, relax, nb); \
+        else k_slice2<D><<<g, blk, 0, s>>>(kd, c, src, first, last, relax, nb);                  \
         break;
             switch (kd.D1) {
             LCCRF_SLICE_CASE(2)

@@ -56,11 +56,15 @@ def check(b, pbs, sizes, n_iter, relax, tag):
 
 def large_case(rng):
     K, L = int(rng.integers(1, 3)), int(rng.integers(2, 4))
-    dims = [int(rng.integers(1, 7)) for _ in range(K)]
+    dims = [int(rng.integers(1, 9)) for _ in range(K)]
     F = int(rng.integers(1, 10))
-    maxN = int(rng.integers(8192, 20000))
-    sizes = [int(rng.integers(8192, maxN + 1)) if rng.random() > 0.15 else int(rng.integers(0, 5)) for _ in range(F)]
+    # round 4: below 8 frames the XCD-chunked grids, one frame: two blur passes per launch (+ two-hop table, + the left-over pass in
+    # the slice); sizes from 4200 points (streaming build, no permutation) to 20000 (locality mode); the vertex order option at random
+    lo = 4200 if rng.random() < 0.3 else 8192
+    maxN = int(rng.integers(lo, 20000 if lo == 8192 else 8192))
+    sizes = [int(rng.integers(lo, maxN + 1)) if rng.random() > 0.15 else int(rng.integers(0, 5)) for _ in range(F)]
     sizes[0] = maxN
+    vertex_order = int(rng.random() < 0.5)
     use_label = L == 2 and rng.random() < 0.5
     ws = [float(rng.uniform(1, 12)) for _ in range(K)]
     kind = int(rng.integers(0, 3))
@@ -83,6 +87,7 @@ def large_case(rng):
         pbs.append(pb)
     n_iter, relax = int(rng.integers(1, 4)), float(rng.choice([1.0, 0.8]))
     b = pkg.BatchCRF(F, maxN, L, dims, ws)
+    b.set_option(pkg.OPT_VERTEX_ORDER, vertex_order)
     if use_label:
         b.set_inputs_host(sizes, feats, label=label, conf=0.7)
     else:
@@ -91,7 +96,7 @@ def large_case(rng):
     if rng.random() < 0.5:
         b.build()
     b.inference(n_iter, True, relax=relax)
-    ok = check(b, pbs, sizes, n_iter, relax, "large K=%d L=%d dims=%s F=%d kind=%d label=%s" % (K, L, dims, F, kind, use_label))
+    ok = check(b, pbs, sizes, n_iter, relax, "large K=%d L=%d dims=%s F=%d kind=%d label=%s maxN=%d vertex_order=%d" % (K, L, dims, F, kind, use_label, maxN, vertex_order))
     b.close()
     return ok
 
