@@ -435,16 +435,16 @@ def c5_record(pkg, wl, torch, dev, steps=6, frames=8):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import pyoracle as po
     out = {"workload": desc, "unit": "iters/s"}
-    for F in (frames, 1, -frames):                        # (-frames: the same frames once more with LCCRF_OPT_VERTEX_ORDER)
-        vertex_order = F < 0
+    for F in (frames, 1, -frames):                        # (-frames: the same frames once more on the HASH build, LCCRF_OPT_VERTEX_ORDER = 2)
+        hash_build = F < 0
         F = abs(F)
         idx = [i % len(pbs) for i in range(F)]
         f = torch.from_numpy(np.stack([pbs[i]["kernels"][0][0] for i in idx])).to(dev)
         lab = torch.from_numpy(np.stack([pbs[i]["label"] for i in idx])).to(dev)
         npt = torch.full((F,), N, dtype=torch.int32, device=dev)
         b = pkg.BatchCRF(F, N, 2, [6], [float(pbs[0]["kernels"][0][1])], device=dev.index)
-        if vertex_order:
-            b.set_option(pkg.OPT_VERTEX_ORDER, 1)
+        if hash_build:
+            b.set_option(pkg.OPT_VERTEX_ORDER, 2)
         b.bind_inputs_device(F, npt.data_ptr(), [f.data_ptr()], d_label=lab.data_ptr(), conf=pbs[0]["conf"])
         b.build(); b.synchronize(); b.build(); b.synchronize()
         build_ms = b.last_timing()["build_ms"]
@@ -471,21 +471,18 @@ def c5_record(pkg, wl, torch, dev, steps=6, frames=8):
                                             "inference_ms": inf_ms,
                                             "note": "algorithmic bytes (SURVEY 8d) x frames / HIP-event time of the 20-iteration "
                                                     "inference (9 launches per iteration: splat, 7 blur passes, slice + softmax)"}}
-        if vertex_order:
-            # the opt-in vertex numbering (lccrf.h: LCCRF_OPT_VERTEX_ORDER): what it buys per iteration and what it costs per build
+        if hash_build:
+            # what the sorted build of locality mode (default with 8 or more frames in flight) changes: the same frames on the hash build
             blur_ms, nv = b.time_blur_pass(0, 40)
             M, Q = b.map(), b.probability()
             fc, lm, dq = check_distinct_frames(pbs[:min(F, len(pbs))], idx, M, Q, n_iter)
-            base = out
-            out["with_vertex_order_option"] = {
+            out["with_hash_build"] = {
                 "frames_in_flight": F, "value": rec["value"], "us_per_iteration_per_frame": rec["us_per_iteration_per_frame"],
                 "build_ms_per_batch": build_ms, "roofline_whole_iteration_frac": rec["roofline_whole_iteration"]["frac"],
                 "blur_pass_ms": blur_ms, "blur_pass_frac": 24.0 * nv / (blur_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "label_match_vs_cpu_reference": lm, "max_abs_dQ_vs_cpu_reference": dq,
-                "break_even_iterations_per_build": ((build_ms - base["build_ms_per_batch"]) * 1e3 /
-                                                    max((base["us_per_iteration_per_frame"] - rec["us_per_iteration_per_frame"]) * F, 1e-9)),
-                "note": "LCCRF_OPT_VERTEX_ORDER: vertices numbered in row-major order of the lattice's own axes (a vertex sort inside the "
-                        "build); off by default because at this configuration's 20 iterations the sort costs more than the passes save"}
+                "note": "LCCRF_OPT_VERTEX_ORDER = 2: hash-table build, vertices numbered by first occurrence along the points' Z-order curve "
+                        "(round 3's locality mode); the default above sorts the entries on the row-major code of their vertex instead"}
         elif F == frames:
             blur_ms, nv = b.time_blur_pass(0, 40)
             # (d+1) x (8 V L + 8 V) per iteration = 24 B per vertex and pass at L = 2 (values read + written once,

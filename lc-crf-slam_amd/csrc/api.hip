@@ -188,7 +188,9 @@ struct Engine {
     bool frame_small_used = false;     //   more than 1/8 of a batch's frames did not fit that plan
     static constexpr int kDualMaxFrames = 64;    // (measured, `scripts/small_batch_latency.py`: 4 frames 98 -> 86 us, 32 frames 93 -> 83 us, 128 frames 112 -> 114 us)
     bool opt_single_wg = false;        // LCCRF_OPT_SINGLE_WORKGROUP: never the two-workgroup form (lccrf_set_option)
-    bool opt_vertex_order = false;     // LCCRF_OPT_VERTEX_ORDER: locality mode also numbers the vertices along the lattice's axes (next build)
+    int opt_vertex_order = 0;          // LCCRF_OPT_VERTEX_ORDER: 0 automatic (8 or more frames in flight), 1 on, 2 off -- locality mode's sorted build
+    bool vorder_on = false;            // ... as decided by the last build of every kernel
+    bool vorder_broken = false;        // a frame's code space overflowed (*sort.vbad): this engine keeps to the hash build
     unsigned *dual_area = nullptr;     // hand-off area of the two-workgroup form of the frame kernel (batches of up to kDualMaxFrames frames)
     unsigned dual_epoch = 0;
     // object API: the frame kernel's last act is a store of `done_epoch` into this pinned word, behind its results; the host
@@ -246,12 +248,15 @@ struct Engine {
         sort.vbits = vbits;
         const size_t vnbk = ((size_t)1 << vbits) + 1;
         if ((rc = mem.alloc(&sort.vcode, Fz * vcap))) return rc;
-        if ((rc = mem.alloc(&sort.vperm, Fz * vcap))) return rc;
+        if ((rc = mem.alloc(&sort.vkey, Fz * vcap))) return rc;
+        if ((rc = mem.alloc(&sort.vph, Fz * 64))) return rc;
+        if ((rc = mem.alloc_pinned(&sort.vbad, 1))) return rc;
+        *sort.vbad = 0;
         if ((rc = mem.alloc(&sort.vhist, Fz * vnbk))) return rc;
         if ((rc = mem.alloc(&sort.vstart, Fz * vnbk))) return rc;
         if ((rc = mem.alloc(&sort.vtiles, Fz * ((vnbk + 4095) / 4096 + 1)))) return rc;
         if ((rc = mem.alloc(&sort.vpartial, Fz * ((maxNpad + 255) / 256 + 1) * 2 * kMaxD))) return rc;
-        if ((rc = mem.alloc(&sort.vplan, Fz * (2 * kMaxD + 2)))) return rc;
+        if ((rc = mem.alloc(&sort.vplan, Fz * (2 * kMaxD + 3)))) return rc;
         return LCCRF_OK;
     }
 
@@ -442,8 +447,7 @@ struct Engine {
             kernels[i].dev.rowmax_host = row_host + i * Fcap;
             kernels[i].dev.perm = perm_on ? sort.perm : nullptr;
             kernels[i].dev.iperm = perm_on ? sort.iperm : nullptr;
-            static const bool env_vsort = getenv("LCCRF_VERTEX_ORDER") != nullptr;   // A/B switch: as if LCCRF_OPT_VERTEX_ORDER were set (same results)
-            kernels[i].dev.vperm = (perm_on && (opt_vertex_order || env_vsort) && sort.vperm && kernels[i].dev.Epad <= sort.vcap) ? sort.vperm : nullptr;
+            kernels[i].dev.vorder = (perm_on && vorder_on && sort.vkey && kernels[i].dev.Epad <= sort.vcap) ? 1 : 0;
             kdevs[i] = kernels[i].dev;
             maxV[i] = kernels[i].maxV;
             maxRow[i] = kernels[i].maxRow;
@@ -470,6 +474,12 @@ struct Engine {
                 unary_p_valid = false;
             }
             perm_on = false;
+            // ... and, with the points permuted, whether the lattices are built by SORTING the entries on the row-major code of their
+            // vertex (ids along the lattice's axes: the blur pass of many frames in flight touches half as many lines; one to four
+            // frames in flight are latency-bound and lose a little -- notes/r4_experiments.md -- hence "automatic" = 8 frames or more)
+            static const char *env_vo = getenv("LCCRF_VERTEX_ORDER");               // A/B switch: 1 on, 0 off (same results)
+            const int vo = env_vo ? (atoi(env_vo) ? 1 : 2) : opt_vertex_order;
+            vorder_on = want && !vorder_broken && (vo == 1 || (vo == 0 && F >= 8));
             sync_views();
             if (want) {
                 int rcs = ensure_sort_scratch();
@@ -529,6 +539,13 @@ struct Engine {
         if (*npoints_bad) {
             *npoints_bad = 0;
             return fail(LCCRF_E_CAPACITY, "a bound n_points[f] lies outside [0, max_points=%d] (the kernels clamped it)", maxN);
+        }
+        if (sort.vbad && *sort.vbad) {                     // a frame's vertices do not fit a 62-bit row-major code: hash build from now on
+            *sort.vbad = 0;
+            vorder_broken = true;
+            int rcb = build_kernels(0, (int)kernels.size());
+            if (rcb) return rcb;
+            HIP_TRY(hipStreamSynchronize(stream));
         }
         for (size_t k = 0; k < kernels.size(); ++k) {
             int m = 0, r = 0;
@@ -878,7 +895,10 @@ int apply_option(Engine &e, int option, int value)
 {
     switch (option) {
     case LCCRF_OPT_SINGLE_WORKGROUP: e.opt_single_wg = value != 0; return LCCRF_OK;
-    case LCCRF_OPT_VERTEX_ORDER: e.opt_vertex_order = value != 0; return LCCRF_OK;      // (takes effect with the next build)
+    case LCCRF_OPT_VERTEX_ORDER:                                                         // (takes effect with the next build)
+        if (value < 0 || value > 2) return fail(LCCRF_E_INVALID, "LCCRF_OPT_VERTEX_ORDER takes 0 (automatic), 1 (on) or 2 (off)");
+        e.opt_vertex_order = value;
+        return LCCRF_OK;
     default: return fail(LCCRF_E_INVALID, "unknown option %d", option);
     }
 }
@@ -944,7 +964,7 @@ int lccrf_create(lccrf_handle *out, int device_id, int n_points, int n_labels)
     h->eng.ensure_parked_idle();                          // (a reused handle: its last kernel has stored its done word, or we wait for it)
     h->N = n_points;
     h->eng.opt_single_wg = g_default_single_wg.load(std::memory_order_relaxed) != 0;   // (a recycled handle does not inherit its last user's options)
-    h->eng.opt_vertex_order = false;
+    h->eng.opt_vertex_order = 0;
     h->eng.activeN = n_points;
     h->eng.crf.map = h->map_pin;
     h->eng.map_host = h->map_pin;

@@ -67,10 +67,10 @@ struct KernelDev {
     // not depend on it: CSR rows stay ordered by ORIGINAL point index (quirk Q6), vertices are matched by key.  Null = off.
     const int *perm;      // [F][maxNpad]      position -> original point (identity on the phantom lanes)
     const int *iperm;     // [F][maxNpad]      original point -> position
-    // ... and the VERTICES are numbered along the lattice's own axes (round 4; stream_engine.hip: launch_sort_vertices): in the basis
-    // of the blur directions the lattice is the integer grid Z^d, and ids in row-major order of those coordinates make the two
-    // neighbours a blur gather wants consecutive ids of another row.  vperm maps first-occurrence id -> id.  Null = off.
-    const int *vperm;     // [F][Epad]
+    // ... and the VERTICES are numbered along the lattice's own axes (round 4; stream_engine.hip: the sorted build): in the basis of
+    // the blur directions the lattice is the integer grid Z^d, and ids in row-major order of those coordinates make the two
+    // neighbours a blur gather wants consecutive ids of another row.
+    int vorder;           // the lattice is built by sorting the entries on the row-major code of their vertex (no hash table)
 };
 
 // Device view of the CRF state of a batch.
@@ -101,20 +101,20 @@ struct SortScratch {
     int *perm, *iperm;    // [F][maxNpad]        the result
     // vertex order (per kernel, one after the other on the engine's stream)
     int vcap;                   // entries per frame the arrays below are sized for (>= Epad of every kernel)
-    int vbits;                  // bucket bits of the vertex sort (<= 21): ~4 buckets per possible vertex
-    unsigned long long *vcode;  // [F][vcap]           row-major code of every vertex (by first-occurrence id)
-    int *vperm;                 // [F][vcap]           first-occurrence id -> id
+    int vbits;                  // bucket bits of the entry sort (<= 21): ~4 buckets per entry
+    unsigned long long *vcode;  // [F][vcap]           row-major code of every ENTRY's vertex
+    unsigned long long *vkey;   // [F][vcap]           ... of every vertex, by id (ids are in code order bucket by bucket)
+    int *vph;                   // [F][64]             positions of the phantom points' entries in the sorted order: count, then the list
+    int *vbad;                  // pinned host word: raised when a frame's code space overflows 62 bits (the host then rebuilds with the hash)
     int *vhist, *vstart;        // [F][2^vbits + 1]    bucket counts, their scan (advanced to the bucket ends by the scatter)
     int *vtiles;                // [F][ceil((2^vbits+1)/4096)] scan scratch
     int *vpartial;              // [F][ceil(maxNpad/256)][2*kMaxD] per-workgroup min / max of the vertices' grid coordinates (k_points)
-    long long *vplan;           // [F][2*kMaxD+2]      per dimension: lowest coordinate, stride; then shift, usable
+    long long *vplan;           // [F][2*kMaxD+3]      per dimension: lowest coordinate, stride; then bucket scale, usable, range
 };
 
 // ---- streaming engine (any size; every array in HBM) ---------------------------------
 // locality mode: Z-order buckets of the points' lattice cells under kernel kd -> ss.perm / ss.iperm
 void launch_sort_points(const KernelDev &kd, const CrfDev &c, const SortScratch &ss, hipStream_t s);
-// locality mode, inside the build of kernel kd (between the first-occurrence scan and k_offsets): ss.vperm
-void launch_sort_vertices(const KernelDev &kd, const CrfDev &c, const SortScratch &ss, hipStream_t s);
 // dst[f][i][0..width) = src[f][perm[i]][0..width) (gather = 1) or dst[f][perm[i]][..] = src[f][i][..] (gather = 0), i < n_points[f]
 void launch_permute_rows(const CrfDev &c, float *dst, const float *src, int width, int gather, hipStream_t s);
 void launch_build_kernel(const KernelDev &kd, const CrfDev &c, int maxV_hint, hipStream_t s, const SortScratch *vsort = nullptr);

@@ -516,8 +516,9 @@ __device__ __forceinline__ void vertex_grid_coords(const int16_t (&key)[D], int 
 }
 
 // One workgroup per frame: bounds of the grid coordinates -> row-major strides (coordinate 0 fastest) and the shift that maps a
-// code to its bucket.  vplan[f] = {lo[kMaxD], stride[kMaxD], shift, usable}; a lattice whose bounding box overflows 62 bits
-// (features spread over thousands of cells in every dimension) keeps its first-occurrence numbering.
+// code to its bucket.  vplan[f] = {lo[kMaxD], stride[kMaxD], bucket scale, usable, range}; a lattice whose bounding box overflows 62 bits
+// (features spread over thousands of cells in every dimension) raises *vbad and is rebuilt with the hash table.
+constexpr int kVPlan = 2 * kMaxD + 3;
 __global__ void __launch_bounds__(kBlock) k_vsort_plan(int D, int nblocks, SortScratch ss)
 {
     __shared__ int red[kBlock / 64][2 * kMaxD];
@@ -548,35 +549,56 @@ __global__ void __launch_bounds__(kBlock) k_vsort_plan(int D, int nblocks, SortS
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        long long *plan = ss.vplan + (size_t)f * (2 * kMaxD + 2);
+        long long *plan = ss.vplan + (size_t)f * kVPlan;
         unsigned long long range = 1;
         bool ok = true;
         for (int j = 0; j < D; ++j) {
             const int lo = bnd[2 * j], hi = bnd[2 * j + 1];
-            const unsigned long long span = hi >= lo ? (unsigned long long)((long long)hi - lo + 1) : 1ull;   // (an empty frame has no vertices)
+            // one EMPTY guard column per dimension: a step of +-1 off the edge of the box lands in it (or beyond `range`) and finds no
+            // vertex, so the neighbour search needs no coordinate arithmetic (k_eneighbors)
+            const unsigned long long span = hi >= lo ? (unsigned long long)((long long)hi - lo + 2) : 2ull;   // (an empty frame has no vertices)
             plan[j] = hi >= lo ? lo : 0;
             plan[kMaxD + j] = (long long)range;
             if (span > (1ull << 62) / range) ok = false;
             else range *= span;
         }
-        int shift = 0;
-        while (ok && (range >> shift) > (1ull << ss.vbits)) ++shift;
-        plan[2 * kMaxD] = shift;
+        // bucket of a code = floor(code * buckets / range) as a multiply-high: the whole histogram is used whatever the range (a
+        // shift would leave up to half of it empty and make the buckets twice as long).  0 = the code itself (range <= buckets).
+        // An unusable plan "codes" the entries by their own index (k_ecode): the same formula over [0, vcap) keeps them inside.
+        const unsigned long long reff = ok ? range : (unsigned long long)ss.vcap, nbuckets = 1ull << ss.vbits;
+        plan[2 * kMaxD] = reff <= nbuckets ? 0ll : (long long)((~0ull / reff) << ss.vbits);
         plan[2 * kMaxD + 1] = ok ? 1 : 0;
+        plan[2 * kMaxD + 2] = (long long)reff;             // (unusable plan: whatever k_eneighbors derives from the meaningless strides stays inside too)
+        if (!ok && ss.vbad) *ss.vbad = 1;                 // pinned host word: the host rebuilds these lattices with the hash
     }
 }
 
+// ---- the SORTED build of locality mode (round 4): vertices found and numbered by sorting the entries ---------------------------
+// Every entry e = (point, remainder) gets the row-major code of its vertex; a bucket sort on the code's top ~21 bits + an exact
+// order inside each bucket by (code, entry) makes the entries of one vertex a RUN whose first element is the vertex's first
+// occurrence: run starts -> scan -> ids in row-major order, with no hash table, no first-occurrence pass and no separate vertex
+// sort; blur neighbours are then found by CODE (the neighbour along axis j has code +- stride_j) among the few vertices of the
+// bucket that code falls in -- one contiguous read instead of a hash probe plus a key recomputation.  Everything downstream
+// (offset, rep, V, nbr, the CSR kernels) sees the same arrays as after the hash build, with other ids.
+constexpr int kLongBucket = 128;          // buckets beyond this are sorted by a workgroup of their own (identical or clustered features)
+constexpr int kVPh = 64;                  // ints per frame of the phantom-entry list: count, then up to 3 (d+1) <= 27 positions
+__device__ __forceinline__ void csr_emit(const KernelDev &kd, size_t fe, int pos, int e, int v);   // (with the CSR kernels below)
+
+__device__ __forceinline__ int vsort_bucket(const SortScratch &ss, int f, unsigned long long code)
+{
+    const unsigned long long scale = (unsigned long long)ss.vplan[(size_t)f * kVPlan + 2 * kMaxD];
+    return scale ? (int)__umul64hi(code, scale) : (int)code;
+}
+
 template <int D>
-__global__ void __launch_bounds__(kBlock) k_vsort_code(KernelDev kd, const int *__restrict__ n_points, SortScratch ss)
+__global__ void __launch_bounds__(kBlock) k_ecode(KernelDev kd, const int *__restrict__ n_points, SortScratch ss)
 {
     const int f = blockIdx.y;
     const int live = ((n_points[f] + 3) & ~3) * (D + 1);
     const int e = blockIdx.x * kBlock + threadIdx.x;
-    if (e >= live || !kd.flag[(size_t)f * (kd.Epad + 1) + e]) return;
-    const int id = kd.prefix[(size_t)f * (kd.Epad + 1) + e];              // first-occurrence id
-    const long long *plan = ss.vplan + (size_t)f * (2 * kMaxD + 2);
-    unsigned long long code = (unsigned long long)id;                     // (unusable plan: identity)
-    int shift = 0;
+    if (e >= live) return;
+    const long long *plan = ss.vplan + (size_t)f * kVPlan;
+    unsigned long long code = (unsigned long long)e;                      // (unusable plan: the host rebuilds with the hash; stay in bounds)
     if (plan[2 * kMaxD + 1]) {
         int16_t key[D];
         int c[D];
@@ -585,45 +607,181 @@ __global__ void __launch_bounds__(kBlock) k_vsort_code(KernelDev kd, const int *
         code = 0;
 #pragma unroll
         for (int j = 0; j < D; ++j) code += (unsigned long long)((long long)c[j] - plan[j]) * (unsigned long long)plan[kMaxD + j];
-        shift = (int)plan[2 * kMaxD];
-    } else {
-        while ((((unsigned long long)kd.Epad) >> shift) > (1ull << ss.vbits)) ++shift;
     }
-    ss.vcode[(size_t)f * ss.vcap + id] = code;
-    atomicAdd(&ss.vhist[(size_t)f * ((1 << ss.vbits) + 1) + (int)(code >> shift)], 1);
+    ss.vcode[(size_t)f * ss.vcap + e] = code;
+    // the histogram's atomic hands back the entry's arrival number inside its bucket: the scatter below needs no second round of atomics
+    kd.csr_pos[(size_t)f * kd.Epad + e] = atomicAdd(&ss.vhist[(size_t)f * ((1 << ss.vbits) + 1) + vsort_bucket(ss, f, code)], 1);
 }
 
-__device__ __forceinline__ int vsort_shift(const KernelDev &kd, const SortScratch &ss, int f)
-{
-    const long long *plan = ss.vplan + (size_t)f * (2 * kMaxD + 2);
-    if (plan[2 * kMaxD + 1]) return (int)plan[2 * kMaxD];
-    int shift = 0;
-    while ((((unsigned long long)kd.Epad) >> shift) > (1ull << ss.vbits)) ++shift;
-    return shift;
-}
-
-__global__ void __launch_bounds__(kBlock) k_vsort_scatter(KernelDev kd, SortScratch ss)
+// bucket b = positions [vstart[b], vstart[b+1]).  slot_of takes the entries bucket by bucket (unordered inside), rep -- free until
+// k_eoffsets -- the same entries under their ORIGINAL id: a vertex's row is ordered by original point index whatever the internal
+// order of the points (quirk Q6), and that is the order the runs are given.
+__global__ void __launch_bounds__(kBlock) k_escatter(KernelDev kd, const int *__restrict__ n_points, SortScratch ss)
 {
     const int f = blockIdx.y;
-    const int id = blockIdx.x * kBlock + threadIdx.x;
-    if (id >= kd.V[f]) return;
-    const int b = (int)(ss.vcode[(size_t)f * ss.vcap + id] >> vsort_shift(kd, ss, f));
-    // the vertex's place = its bucket's start + its arrival number: buckets are ~200 consecutive codes (a few lattice rows) holding
-    // one or two vertices, so the order inside one is immaterial for locality (and for nothing else: numbering is free)
-    ss.vperm[(size_t)f * kd.Epad + id] = atomicAdd(&ss.vstart[(size_t)f * ((1 << ss.vbits) + 1) + b], 1);
+    const int live = ((n_points[f] + 3) & ~3) * kd.D1;
+    const int e = blockIdx.x * kBlock + threadIdx.x;
+    if (e >= live) return;
+    const size_t fe = (size_t)f * kd.Epad;
+    const int b = vsort_bucket(ss, f, ss.vcode[(size_t)f * ss.vcap + e]);
+    const int pos = ss.vstart[(size_t)f * ((1 << ss.vbits) + 1) + b] + kd.csr_pos[fe + e];
+    const int pt = e / kd.D1;
+    kd.slot_of[fe + pos] = e;
+    kd.rep[fe + pos] = kd.perm[(size_t)f * kd.maxNpad + pt] * kd.D1 + (e - pt * kd.D1);
 }
 
-template <int D>
-void sort_vertices_d(const KernelDev &kd, const CrfDev &c, const SortScratch &ss, hipStream_t s)
+__device__ __forceinline__ bool entry_less(unsigned long long ca, int oa, unsigned long long cb, int ob) { return ca < cb || (ca == cb && oa < ob); }
+
+// exact order inside every bucket: (code, original entry id).  kd.slot (the hash table of the other build) takes the sorted entries.
+__global__ void __launch_bounds__(kBlock) k_eorder(KernelDev kd, const int *__restrict__ n_points, SortScratch ss)
 {
-    const int F = c.F, nbk = (1 << ss.vbits) + 1;
-    const dim3 ge = grid_for(kd.Epad, F);
-    // (k_points left the per-workgroup bounds of the vertices' grid coordinates in ss.vpartial)
-    k_vsort_plan<<<F, kBlock, 0, s>>>(D, (int)grid_for(kd.maxNpad, F).x, ss);
-    (void)hipMemsetAsync(ss.vhist, 0, (size_t)F * nbk * sizeof(int), s);
-    k_vsort_code<D><<<ge, kBlock, 0, s>>>(kd, c.n_points, ss);
-    scan_frames(ss.vhist, ss.vstart, nbk, nbk, nullptr, ss.vtiles, F, s);
-    k_vsort_scatter<<<ge, kBlock, 0, s>>>(kd, ss);
+    const int f = blockIdx.y;
+    const int live = ((n_points[f] + 3) & ~3) * kd.D1;
+    const int pos = blockIdx.x * kBlock + threadIdx.x;
+    if (pos >= live) return;
+    const int *tmp = kd.slot_of + (size_t)f * kd.Epad, *toe = kd.rep + (size_t)f * kd.Epad;
+    const unsigned long long *code = ss.vcode + (size_t)f * ss.vcap;
+    const int *start = ss.vstart + (size_t)f * ((1 << ss.vbits) + 1);
+    const int e = tmp[pos], oe = toe[pos];
+    const unsigned long long ce = code[e];
+    const int b = vsort_bucket(ss, f, ce);
+    const int lo = start[b], hi = start[b + 1];
+    int *sorted = kd.slot + (size_t)f * kd.cap;
+    if (hi - lo > kLongBucket) {
+        if (pos == lo) sorted[kd.Epad + atomicAdd(&kd.rowmax[f], 1)] = b;                 // (second half of the table: the list of long buckets)
+        return;
+    }
+    int r = 0;
+    for (int q = lo; q < hi; ++q) r += entry_less(code[tmp[q]], toe[q], ce, oe);
+    sorted[lo + r] = e;
+}
+
+// One workgroup per long bucket: bitonic sort of its entries by (code, original id) in place, then out (as k_csr_sort_long).
+__global__ void __launch_bounds__(kBlock) k_esort_long(KernelDev kd, SortScratch ss)
+{
+    const int f = blockIdx.y;
+    const int nlong = kd.rowmax[f];
+    int *tmp = kd.slot_of + (size_t)f * kd.Epad, *toe = kd.rep + (size_t)f * kd.Epad;
+    int *sorted = kd.slot + (size_t)f * kd.cap;
+    const unsigned long long *code = ss.vcode + (size_t)f * ss.vcap;
+    const int *start = ss.vstart + (size_t)f * ((1 << ss.vbits) + 1);
+    for (int li = blockIdx.x; li < nlong; li += gridDim.x) {
+        const int b = sorted[kd.Epad + li];
+        const int lo = start[b], n = start[b + 1] - lo;
+        int *r = tmp + lo, *ro = toe + lo;
+        int np2 = 1;
+        while (np2 < n) np2 <<= 1;
+        for (int k = 2; k <= np2; k <<= 1) {
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int i = threadIdx.x; i < np2; i += kBlock) {
+                    const int l = (j == (k >> 1)) ? (i ^ (k - 1)) : (i ^ j);
+                    if (l > i && l < n) {
+                        const int a = r[i], c = r[l], oa = ro[i], oc = ro[l];
+                        if (entry_less(code[c], oc, code[a], oa)) { r[i] = c; r[l] = a; ro[i] = oc; ro[l] = oa; }
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        for (int i = threadIdx.x; i < n; i += kBlock) sorted[lo + i] = r[i];
+        __syncthreads();
+    }
+}
+
+// flag[pos] = 1 where a run (= a vertex) starts; the (at most 3 (d+1)) entries of the phantom points are listed by position --
+// they make vertices but no products, and sit at the END of their runs (their original ids are the largest)
+__global__ void __launch_bounds__(kBlock) k_eflag(KernelDev kd, const int *__restrict__ n_points, SortScratch ss)
+{
+    const int f = blockIdx.y;
+    const int N = n_points[f], live = ((N + 3) & ~3) * kd.D1;
+    const int pos = blockIdx.x * kBlock + threadIdx.x;
+    if (pos > kd.Epad) return;
+    int v = 0;
+    if (pos < live) {
+        const int *sorted = kd.slot + (size_t)f * kd.cap;
+        const unsigned long long *code = ss.vcode + (size_t)f * ss.vcap;
+        const int e = sorted[pos];
+        v = pos == 0 || code[sorted[pos - 1]] != code[e];
+        if (e >= N * kd.D1) ss.vph[(size_t)f * kVPh + 1 + atomicAdd(&ss.vph[(size_t)f * kVPh], 1)] = pos;
+    }
+    kd.flag[(size_t)f * (kd.Epad + 1) + pos] = v;
+}
+
+// ids, representatives, and the CSR of splat contributions straight from the sorted runs: a run minus its trailing phantom entries
+// IS the vertex's row in ascending original point order (what k_csr_count / fill / order / sort_long produce for the hash build)
+__global__ void __launch_bounds__(kBlock) k_eoffsets(KernelDev kd, const int *__restrict__ n_points, SortScratch ss)
+{
+    const int f = blockIdx.y;
+    const int N = n_points[f], live = ((N + 3) & ~3) * kd.D1;
+    const int pos = blockIdx.x * kBlock + threadIdx.x;
+    if (pos >= live) return;
+    const size_t fe = (size_t)f * kd.Epad, f1 = (size_t)f * (kd.Epad + 1);
+    const int e = kd.slot[(size_t)f * kd.cap + pos];
+    const int first = kd.flag[f1 + pos];
+    const int id = kd.prefix[f1 + pos] + first - 1;                       // (exclusive scan of the run starts)
+    const int *ph = ss.vph + (size_t)f * kVPh;
+    const int nph = ph[0];
+    int before = 0;
+    for (int u = 0; u < nph; ++u) before += ph[1 + u] < pos;               // phantom entries ahead of this position
+    const int cpos = pos - before;
+    kd.offset[fe + e] = id;
+    if (first) {
+        kd.rep[fe + id] = e;                                              // the run's first element = the vertex's first occurrence
+        ss.vkey[(size_t)f * ss.vcap + id] = ss.vcode[(size_t)f * ss.vcap + e];
+        kd.rowptr[f1 + id] = cpos;
+    }
+    if (pos == 0) kd.rowptr[f1 + kd.V[f]] = live - nph;
+    if (e < N * kd.D1) csr_emit(kd, fe, cpos, e, id);
+}
+
+// vhist (free after its scan) takes, per bucket, the id of the bucket's first vertex: ids are bucket-major, so bucket b holds the
+// vertices [bvert[b], bvert[b+1]) and the neighbour search reads one 8-byte pair instead of two positions and two prefixes
+__global__ void __launch_bounds__(kBlock) k_ebucket_vertices(KernelDev kd, SortScratch ss)
+{
+    const int f = blockIdx.y, nbk = (1 << ss.vbits) + 1;
+    const int b = blockIdx.x * kBlock + threadIdx.x;
+    if (b >= nbk) return;
+    ss.vhist[(size_t)f * nbk + b] = kd.prefix[(size_t)f * (kd.Epad + 1) + ss.vstart[(size_t)f * nbk + b]];   // (prefix[live] = V)
+}
+
+// One thread per (axis j, vertex v): n2_j(v) by code -- +1 along grid coordinate j (j < d), -1 along every coordinate (j = d) --
+// among the vertices of the bucket the code falls in (ids are bucket-major, a bucket's vertices are prefix[start] .. prefix[end]);
+// the relation is mutual, so finding n2 fills both sides (the table was preset to -1).  ref: permutohedral_cpu.h:408-421.
+template <int D>
+__global__ void __launch_bounds__(kBlock) k_eneighbors(KernelDev kd, int F, XcdMap nb, SortScratch ss)
+{
+    constexpr int D1 = D + 1;
+    const FrameBlock fb = frame_block(nb);
+    const int f = fb.f;
+    if (f >= F) return;
+    const int V = kd.V[f];
+    const int idx = fb.bx * kBlock + threadIdx.x;
+    if (idx >= V * D1) return;
+    const int j = idx / V, v = idx - j * V;
+    const long long *plan = ss.vplan + (size_t)f * kVPlan;
+    const unsigned long long *vkey = ss.vkey + (size_t)f * ss.vcap;
+    const unsigned long long code = vkey[v], range = (unsigned long long)plan[2 * kMaxD + 2];
+    unsigned long long target;
+    if (j < D) {
+        target = code + (unsigned long long)plan[kMaxD + j];               // + 1 along c_j (off the edge: the guard column, or beyond the range)
+    } else {
+        unsigned long long sum = 0;
+#pragma unroll
+        for (int t = 0; t < D; ++t) sum += (unsigned long long)plan[kMaxD + t];
+        if (code < sum) return;
+        target = code - sum;                                              // - 1 along every coordinate
+    }
+    if (target >= range) return;
+    const int b = vsort_bucket(ss, f, target);
+    const int *bvert = ss.vhist + (size_t)f * ((1 << ss.vbits) + 1);
+    const int v0 = bvert[b], v1 = bvert[b + 1];
+    int found = -1;
+    for (int u = v0; u < v1; ++u)
+        if (vkey[u] == target) { found = u; break; }
+    if (found < 0) return;
+    int *nbp = kd.nbr + ((size_t)f * D1 + j) * kd.Epad * 2;
+    nbp[2 * v + 1] = found;              // my n2
+    nbp[2 * found] = v;                  // its n1
 }
 
 // offset[e] = dense id of e's vertex; the first entry of each vertex registers as its
@@ -637,8 +795,7 @@ __global__ void __launch_bounds__(kBlock) k_offsets(KernelDev kd, const int *__r
     const size_t fe = (size_t)f * kd.Epad;
     const int *prefix = kd.prefix + (size_t)f * (kd.Epad + 1);
     const int r = kd.slot[(size_t)f * kd.cap + kd.slot_of[fe + e]];
-    int id = prefix[r];
-    if (kd.vperm) id = kd.vperm[fe + id];                // locality mode: vertices numbered along the lattice's axes
+    const int id = prefix[r];
     kd.offset[fe + e] = id;
     if (r == e) kd.rep[fe + id] = e;
 }
@@ -657,10 +814,7 @@ __device__ __forceinline__ int find_vertex(const KernelDev &kd, int f, const int
         bool same = true;
 #pragma unroll
         for (int i = 0; i < D; ++i) same &= (other[i] == key[i]);
-        if (same) {
-            const int id = kd.prefix[(size_t)f * (kd.Epad + 1) + r];
-            return kd.vperm ? kd.vperm[(size_t)f * kd.Epad + id] : id;   // (locality mode renumbers the vertices)
-        }
+        if (same) return kd.prefix[(size_t)f * (kd.Epad + 1) + r];
         h = (h + 1u) & mask;
     }
 }
@@ -1184,33 +1338,56 @@ template <int D>
 void build_kernel_d(const KernelDev &kd, const CrfDev &c, hipStream_t s, const SortScratch *vsort)
 {
     const int F = c.F, D1 = D + 1;
-    (void)hipMemsetAsync(kd.slot, 0xff, (size_t)F * kd.cap * sizeof(int), s);
-    if (vsort && kd.vperm) k_points<D, true><<<grid_for(kd.maxNpad, F), kBlock, 0, s>>>(kd, c.n_points, vsort->vpartial);
-    else k_points<D, false><<<grid_for(kd.maxNpad, F), kBlock, 0, s>>>(kd, c.n_points, nullptr);
-    {
+    const dim3 ge = grid_for(kd.Epad, F);
+    if (vsort && kd.vorder) {
+        // the sorted build (locality mode): entries sorted by the row-major code of their vertex
+        const SortScratch &ss = *vsort;
+        const int nbk = (1 << ss.vbits) + 1;
+        k_points<D, true><<<grid_for(kd.maxNpad, F), kBlock, 0, s>>>(kd, c.n_points, ss.vpartial);
+        k_vsort_plan<<<F, kBlock, 0, s>>>(D, (int)grid_for(kd.maxNpad, F).x, ss);
+        (void)hipMemsetAsync(ss.vhist, 0, (size_t)F * nbk * sizeof(int), s);
+        (void)hipMemsetAsync(kd.rowmax, 0, (size_t)F * sizeof(int), s);                 // (the count of long buckets, until k_row_max)
+        k_ecode<D><<<ge, kBlock, 0, s>>>(kd, c.n_points, ss);
+        scan_frames(ss.vhist, ss.vstart, nbk, nbk, nullptr, ss.vtiles, F, s);
+        k_escatter<<<ge, kBlock, 0, s>>>(kd, c.n_points, ss);
+        k_eorder<<<ge, kBlock, 0, s>>>(kd, c.n_points, ss);
+        k_esort_long<<<dim3(64, F), kBlock, 0, s>>>(kd, ss);
+        (void)hipMemsetAsync(ss.vph, 0, (size_t)F * kVPh * sizeof(int), s);
+        k_eflag<<<grid_for(kd.Epad + 1, F), kBlock, 0, s>>>(kd, c.n_points, ss);
+        scan_frames(kd.flag, kd.prefix, kd.Epad + 1, kd.Epad + 1, kd.V, kd.rep, F, s); // (rep: the original ids are no longer needed, k_eoffsets rewrites it)
+        k_eoffsets<<<ge, kBlock, 0, s>>>(kd, c.n_points, ss);
+        (void)hipMemsetAsync(kd.nbr, 0xff, (size_t)F * D1 * kd.Epad * 2 * sizeof(int), s);      // every neighbour absent (-1)
+        k_ebucket_vertices<<<grid_for(nbk, F), kBlock, 0, s>>>(kd, ss);
         XcdMap nb;
-        const dim3 g = grid_xcd(kd.Epad, F, &nb);
-        k_insert<D><<<g, kBlock, 0, s>>>(kd, c.n_points, F, nb);
-    }
-    k_first_flag<<<grid_for(kd.Epad + 1, F), kBlock, 0, s>>>(kd, c.n_points);
-    scan_frames(kd.flag, kd.prefix, kd.Epad + 1, kd.Epad + 1, kd.V, kd.rep, F, s);     // (rep is written later, by k_offsets: free scratch)
-    if (vsort && kd.vperm) sort_vertices_d<D>(kd, c, *vsort, s);                        // locality mode: ids along the lattice's axes
-    k_offsets<<<grid_for(kd.Epad, F), kBlock, 0, s>>>(kd, c.n_points);
-    (void)hipMemsetAsync(kd.nbr, 0xff, (size_t)F * D1 * kd.Epad * 2 * sizeof(int), s);          // every neighbour absent (-1)
-    {
+        const dim3 g = grid_xcd((long)kd.Epad * D1, F, &nb);
+        k_eneighbors<D><<<g, kBlock, 0, s>>>(kd, F, nb, ss);
+    } else {
+        (void)hipMemsetAsync(kd.slot, 0xff, (size_t)F * kd.cap * sizeof(int), s);
+        k_points<D, false><<<grid_for(kd.maxNpad, F), kBlock, 0, s>>>(kd, c.n_points, nullptr);
+        {
+            XcdMap nb;
+            const dim3 g = grid_xcd(kd.Epad, F, &nb);
+            k_insert<D><<<g, kBlock, 0, s>>>(kd, c.n_points, F, nb);
+        }
+        k_first_flag<<<grid_for(kd.Epad + 1, F), kBlock, 0, s>>>(kd, c.n_points);
+        scan_frames(kd.flag, kd.prefix, kd.Epad + 1, kd.Epad + 1, kd.V, kd.rep, F, s); // (rep is written later, by k_offsets: free scratch)
+        k_offsets<<<ge, kBlock, 0, s>>>(kd, c.n_points);
+        (void)hipMemsetAsync(kd.nbr, 0xff, (size_t)F * D1 * kd.Epad * 2 * sizeof(int), s);      // every neighbour absent (-1)
         XcdMap nb;
         const dim3 g = grid_xcd((long)kd.Epad * D1, F, &nb);
         k_neighbors<D><<<g, kBlock, 0, s>>>(kd, F, nb);
     }
     if (kd.Epad < 65535) k_neighbors16<<<grid_for((long)kd.Epad * D1, F), kBlock, 0, s>>>(kd);
     if (kd.nbr2) k_neighbors_2hop<<<grid_for((long)kd.Epad * (D1 / 2), F), kBlock, 0, s>>>(kd, D1 / 2);
-    // CSR
-    (void)hipMemsetAsync(kd.flag, 0, (size_t)F * (kd.Epad + 1) * sizeof(int), s);
-    k_csr_count<<<grid_for(kd.Epad, F), kBlock, 0, s>>>(kd, c.n_points);
-    scan_frames(kd.flag, kd.rowptr, kd.Epad + 1, kd.Epad + 1, nullptr, kd.csr_pos, F, s);   // (csr_pos is written later, by k_csr_order)
-    k_csr_fill<<<grid_for(kd.Epad, F), kBlock, 0, s>>>(kd, c.n_points);
-    k_csr_order<<<grid_for(kd.Epad, F), kBlock, 0, s>>>(kd, c.n_points);
-    k_csr_sort_long<<<dim3(64, F), kBlock, 0, s>>>(kd);                     // rows of more than kLongRow entries, if any
+    if (!(vsort && kd.vorder)) {
+        // CSR (the sorted build's runs are the rows already)
+        (void)hipMemsetAsync(kd.flag, 0, (size_t)F * (kd.Epad + 1) * sizeof(int), s);
+        k_csr_count<<<grid_for(kd.Epad, F), kBlock, 0, s>>>(kd, c.n_points);
+        scan_frames(kd.flag, kd.rowptr, kd.Epad + 1, kd.Epad + 1, nullptr, kd.csr_pos, F, s);   // (csr_pos is written later, by k_csr_order)
+        k_csr_fill<<<grid_for(kd.Epad, F), kBlock, 0, s>>>(kd, c.n_points);
+        k_csr_order<<<grid_for(kd.Epad, F), kBlock, 0, s>>>(kd, c.n_points);
+        k_csr_sort_long<<<dim3(64, F), kBlock, 0, s>>>(kd);                     // rows of more than kLongRow entries, if any
+    }
     (void)hipMemsetAsync(kd.rowmax, 0, (size_t)F * sizeof(int), s);
     if (kd.Epad < 65535) k_row_max<<<grid_for(kd.Epad, F), kBlock, 0, s>>>(kd);   // only the one-workgroup engines ask (u16 ids)
 }

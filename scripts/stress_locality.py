@@ -64,7 +64,7 @@ def large_case(rng):
     maxN = int(rng.integers(lo, 20000 if lo == 8192 else 8192))
     sizes = [int(rng.integers(lo, maxN + 1)) if rng.random() > 0.15 else int(rng.integers(0, 5)) for _ in range(F)]
     sizes[0] = maxN
-    vertex_order = int(rng.random() < 0.5)
+    vertex_order = int(rng.integers(0, 3))
     use_label = L == 2 and rng.random() < 0.5
     ws = [float(rng.uniform(1, 12)) for _ in range(K)]
     kind = int(rng.integers(0, 3))

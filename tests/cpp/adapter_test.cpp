@@ -87,6 +87,11 @@ int main(int argc, char **argv)
             const DenseCRFHIP<M> &cref = *static_cast<DenseCRFHIP<M> *>(crf);
             bad += !same(cref.getProbability(), o->current, (size_t)N * M);    // const getters
             bad += cref.getMap()[0] != o->map[0];
+            // a tracker on a shared GPU opts out of the two-workgroup form through the adapter (lccrf_set_option): same bits
+            static_cast<DenseCRFHIP<M> *>(crf)->setOption(LCCRF_OPT_SINGLE_WORKGROUP, 1);
+            crf->inference(5, true);
+            bad += !same(cref.getProbability(), o->current, (size_t)N * M);
+            for (int i = 0; i < N; ++i) bad += cref.getMap()[i] != o->map[i];
             delete crf;                              // deletes both potentials
             printf("base-pointer use: %s\n", bad ? "MISMATCH" : "ok");
         }

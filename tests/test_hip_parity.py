@@ -671,7 +671,7 @@ def test_large_ragged_batch_matches_oracle(po, wl, d_list, L):
             feats[k][f, :n] = pb["kernels"][k][0]
     ws = [float(pbs[0]["kernels"][k][1]) for k in range(len(d_list))]
     b = pkg.BatchCRF(F, maxN, L, d_list, ws)
-    b.set_option(pkg.OPT_VERTEX_ORDER, 1 if L == 2 else 0)   # (mixed dimensions, ragged and empty frames through the vertex sort too)
+    b.set_option(pkg.OPT_VERTEX_ORDER, 1 if L == 2 else 2)   # (mixed dimensions, ragged and empty frames through the sorted build / the hash build)
     b.set_inputs_host(sizes, feats, unary=unary)
     b.build()
     b.inference(3, True, relax=0.9)
@@ -718,13 +718,14 @@ def test_large_ragged_batch_matches_oracle(po, wl, d_list, L):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("vertex_order", [0, 1])
+@pytest.mark.parametrize("vertex_order", [0, 1, 2])
 @pytest.mark.parametrize("name", ["c5", "gen"])
 def test_locality_mode_on_reference_vectors(golden, name, vertex_order):
     """Locality mode against vectors generated by the reference build itself (tests/golden/large.npz): a frame alone,
     and eight copies (XCD-aware grids), must reproduce the reference's V, norm, Q and labels bit for bit although the
-    points are processed in an internal order -- and, with LCCRF_OPT_VERTEX_ORDER, the vertices numbered in row-major order of
-    the lattice's own axes (round 4: a vertex sort inside the build; results must not depend on how vertices are numbered)."""
+    points are processed in an internal order -- and the lattice built by sorting the entries on the row-major code of their vertex
+    (round 4: the sorted build, no hash table; LCCRF_OPT_VERTEX_ORDER 0 = automatic: the eight copies, 1 = on: the single frame
+    too, 2 = off: the hash build for both; results must not depend on how vertices are found or numbered)."""
     from test_oracle_golden import _large_case
     z = golden["large"]
     pb, n_iter, relax = _large_case(z, name)
@@ -749,6 +750,30 @@ def test_locality_mode_on_reference_vectors(golden, name, vertex_order):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("d,spread", [(8, 60.0), (6, 1200.0)])
+def test_sorted_build_falls_back_to_the_hash_when_codes_overflow(po, wl, d, spread):
+    """The sorted build of locality mode codes a vertex by its row-major position in the bounding box of the frame's lattice (62
+    bits).  Features spread over hundreds of cells in each of 8 dimensions (or thousands in 6) overflow that: the plan kernel
+    raises a flag in pinned memory and the engine rebuilds those lattices with the hash table -- same results, no error."""
+    N, F = 8300, 8
+    pb = wl.generic_problem(N, [d], 2, seed=77 + d, spread=spread)
+    w = float(pb["kernels"][0][1])
+    o = cc.setup(po.OracleCRF, pb)
+    o.inference_native(2, True)
+    b = pkg.BatchCRF(F, N, 2, [d], [w])
+    b.set_inputs_host([N] * F, [np.repeat(pb["kernels"][0][0][None], F, 0)], unary=np.repeat(pb["unary"][None], F, 0))
+    b.build()
+    b.inference(2, True)
+    Q, M, V = b.probability(), b.map(), b.lattice_sizes(0)
+    for f in range(F):
+        assert int(V[f]) == o.kernel(0)["V"] and cc.same_bits(Q[f], o.probability()) and np.array_equal(M[f], o.map()), f
+    b.build()                                              # (the engine remembers: straight to the hash build)
+    b.inference(2, True)
+    assert cc.same_bits(b.probability(), Q)
+    b.close(); o.close()
+
+
+@pytest.mark.gpu
 def test_locality_mode_with_labels_and_device_inputs(po, wl):
     """Locality mode end to end the way bench.py drives C5: device-bound inputs, unaries from labels (derived in the
     internal order), 8 frames (XCD-aware grids), two builds, against the oracle -- and one adversarial frame whose
@@ -769,15 +794,14 @@ def test_locality_mode_with_labels_and_device_inputs(po, wl):
     for rep in range(2):
         b.inference(4, True)
     Q, M, Vs = b.probability(), b.map(), b.lattice_sizes(0)
-    # the same batch with the vertices numbered along the lattice's axes (option set between two builds of one handle): same bits
-    b.set_option(pkg.OPT_VERTEX_ORDER, 1)
-    b.build()
-    b.inference(4, True)
-    assert cc.same_bits(b.probability(), Q) and np.array_equal(b.map(), M) and np.array_equal(b.lattice_sizes(0), Vs)
-    b.set_option(pkg.OPT_VERTEX_ORDER, 0)
-    b.build()
-    b.inference(4, True)
-    assert cc.same_bits(b.probability(), Q) and np.array_equal(b.map(), M)
+    # the same batch built by the hash table instead of the sort, and back (option set between two builds of one handle): same bits
+    for vo in (2, 1, 0):
+        b.set_option(pkg.OPT_VERTEX_ORDER, vo)
+        b.build()
+        b.inference(4, True)
+        assert cc.same_bits(b.probability(), Q) and np.array_equal(b.map(), M) and np.array_equal(b.lattice_sizes(0), Vs), vo
+    with pytest.raises(pkg.LccrfError):
+        b.set_option(pkg.OPT_VERTEX_ORDER, 3)
     b.run(4, True)                                         # lccrf_batch_run on frames beyond the one-launch kernel: rebuild + infer
     assert b.engine() == 1 and cc.same_bits(b.probability(), Q) and np.array_equal(b.map(), M)
     for i, pb in enumerate(frames):
