@@ -487,6 +487,10 @@ struct Engine {
                 int src = 0;                               // one order for the whole CRF (Q is shared): the kernel with most dimensions decides
                 for (int k = 1; k < n; ++k)
                     if (kernels[k].dev.d > kernels[src].dev.d) src = k;
+                // with the sorted build the points follow the vertices: (coarse) row-major order of their cells in the lattice's own basis
+                // instead of the Z-order curve (C5 x 8: splat 30.5 -> 27.7, slice 24.2 -> 19.5 us, build 1.93 -> 1.76 ms)
+                static const bool env_z = getenv("LCCRF_POINTS_ZORDER") != nullptr;        // A/B switch (same results)
+                sort.rm_points = (vorder_on && !env_z) ? 1 : 0;
                 launch_sort_points(kdevs[src], crf, sort, stream);
                 HIP_TRY(hipGetLastError());
                 perm_on = true;

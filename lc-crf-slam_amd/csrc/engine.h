@@ -91,6 +91,7 @@ struct CrfDev {
 // scratch of the point sort (locality mode), owned by the engine
 struct SortScratch {
     int bits;             // bucket bits of the counting sort (8..16)
+    int rm_points;        // order the points row-major over their cells in the lattice's own basis (with the sorted build) instead of along a Z-order curve
     int *cells;           // [F][maxNpad][kMaxD] lattice cell of every point (int32); later the unordered buckets
     int *partial;         // [F][ceil(maxNpad/256)][2*kMaxD] per-workgroup min / max of the cells
     int *plan;            // [F][3*kMaxD]        per dimension: lowest cell, span, code bits

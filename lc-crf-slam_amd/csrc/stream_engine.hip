@@ -335,6 +335,11 @@ __global__ void __launch_bounds__(kBlock) k_sort_cells(KernelDev kd, const int *
         el[0] = sm;
 #pragma unroll
         for (int j = 0; j < D; ++j) cell[j] = __float2int_rn(kd.inv_dp1 * el[j]);
+        if (ss.rm_points) {                               // the sorted build's companion: cells in the lattice's own basis, c_j ~ v_d - v_j
+            const int vd = __float2int_rn(kd.inv_dp1 * el[D]);
+#pragma unroll
+            for (int j = 0; j < D; ++j) cell[j] = vd - cell[j];
+        }
     }
     if (live) {
         int *cp = ss.cells + ((size_t)f * kd.maxNpad + n) * kMaxD;
@@ -426,6 +431,21 @@ __global__ void __launch_bounds__(kBlock) k_sort_code(KernelDev kd, const int *_
     if (n >= N) return;
     const int *plan = ss.plan + (size_t)f * 3 * kMaxD;
     const int *cp = ss.cells + ((size_t)f * kd.maxNpad + n) * kMaxD;
+    if (ss.rm_points) {
+        // points in (coarse) ROW-MAJOR order of their cell in the lattice's own basis -- the order the sorted build gives the vertices:
+        // the points of consecutive vertices' rows are then close together too (splat), and so are the corners of consecutive points
+        unsigned long long code = 0, range = 1;
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            code += (unsigned long long)(unsigned)(cp[j] - plan[j]) * range;
+            range *= (unsigned long long)(unsigned)plan[kMaxD + j];          // (spans of cells: a product beyond 2^64 only scrambles an order)
+        }
+        unsigned b = range >> ss.bits ? (unsigned)(code / ((range >> ss.bits) + 1)) : (unsigned)code;
+        b = min(b, (1u << ss.bits) - 1u);                 // (a product of spans beyond 2^64 wraps: any bucket will do, inside the histogram)
+        ss.code[(size_t)f * kd.maxNpad + n] = (int)b;
+        atomicAdd(&ss.hist[(size_t)f * ((1 << ss.bits) + 1) + b], 1);
+        return;
+    }
     unsigned q[D];
     int nb[D];
 #pragma unroll

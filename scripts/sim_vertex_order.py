@@ -255,6 +255,27 @@ def main():
             l = np.sort(l, axis=1)
             tot += (np.diff(l, axis=1) != 0).sum() + nw
         print("   slice: %-28s lines per gather instruction %.2f" % (name, tot / (D1 * nw)))
+    # splat side: the Q gathers of 64 consecutive VERTICES' rows (first entry of every row: one gather instruction), by point order
+    def splat_lines(name, ids, porder):
+        ppos = np.empty(N, np.int64)
+        ppos[porder] = np.arange(N)                 # original point -> internal position
+        ent_v = ids[inv]                            # vertex id of every entry (point-major)
+        order = np.lexsort((np.arange(N * D1), ent_v))
+        first = np.ones(len(order), bool)
+        first[1:] = ent_v[order][1:] != ent_v[order][:-1]
+        fpt = ppos[order[first] // D1]              # internal position of the first point of every row, by vertex id
+        nw = (V + 63) // 64
+        l = np.concatenate([fpt // 16, np.full(nw * 64 - V, -1)]).reshape(nw, 64)
+        l = np.sort(l, axis=1)
+        print("   splat: %-28s lines per first-entry gather %.2f" % (name, ((np.diff(l, axis=1) != 0).sum() + nw) / nw))
+    splat_lines("zpoints ids, zpoints order", ids_zp, zp)
+    ids_rm0 = order_ids([cs[:, j] for j in range(d)])
+    splat_lines("rowmajor ids, zpoints order", ids_rm0, zp)
+    pm0 = ids_rm0[inv].reshape(N, D1).min(1)
+    splat_lines("rowmajor ids, points by min id", ids_rm0, np.lexsort((ident, pm0)))
+    pm1 = np.sort(ids_rm0[inv].reshape(N, D1), axis=1)[:, D1 // 2]
+    splat_lines("rowmajor ids, points by median id", ids_rm0, np.lexsort((ident, pm1)))
+    slice_lines("rowmajor ids, points by median id", ids_rm0, np.lexsort((ident, pm1)))
     slice_lines("zpoints ids, zpoints order", ids_zp, zp)
     for nm, ii in (("h2", order_ids([cs[:, 0], cs[:, 1], zcode(cs[:, 2:], 20)])), ("h3", order_ids([cs[:, 0], cs[:, 1], cs[:, 2], zcode(cs[:, 3:], 15)])),
                    ("h1", order_ids([cs[:, 0], zcode(cs[:, 1:], 25)])), ("zc30", order_ids([zcode(cs, 30)]))):
