@@ -75,12 +75,12 @@ int  lccrf_trim_cache(void);
  *       co-scheduled -- a GPU shared with other processes or streams whose kernels hold every CU -- the frame stalls for up to
  *       ~0.05-0.1 s (three frames of a 30 fps tracker) before it falls back to the ordinary path, with the same labels.  A tracker
  *       that shares its GPU sets this option and pays the 8 us instead.
- *   LCCRF_OPT_VERTEX_ORDER   (batches; 0 automatic, 1 on, 2 off; from the next lccrf_batch_build on) large frames (>= 8192 points, streaming
- *       engine): besides processing the points along a space-filling curve, build the lattice by SORTING the (point, corner) entries on the
- *       row-major code of their vertex in the basis of the lattice's own axes -- no hash table -- which numbers the vertices along those
- *       axes.  A blur pass (permutohedral_cpu.h:663-679) then touches half as many cache lines per gather: 23 -> 19.5 us per pass over 8
- *       frames of 100 000 points (0.61 -> 0.72 of the HBM peak).  Frames in flight below 8 are latency-bound and lose a few per cent with
- *       it, which is what "automatic" looks at (on with 8 or more frames).  Results never depend on how vertices are numbered.
+ *   LCCRF_OPT_VERTEX_ORDER   (batches; 0 automatic = on, 1 on, 2 off; from the next lccrf_batch_build on) large frames (>= 8192 points,
+ *       streaming engine) are built by SORTING the (point, corner) entries on the row-major code of their vertex in the basis of the
+ *       lattice's own axes -- no hash table -- with the points processed in the same order: the vertices are numbered along those axes
+ *       and a blur pass (permutohedral_cpu.h:663-679) touches half as many cache lines per gather (23 -> 19.5 us per pass over 8 frames of
+ *       100 000 points, 0.61 -> 0.72 of the HBM peak).  2 selects round 3's build (hash table, vertices by first occurrence along a
+ *       Z-order curve of the points).  Results never depend on how vertices are found or numbered.
  * lccrf_set_option applies to one handle (set it after lccrf_create: a handle taken from the cache starts from the defaults);
  * lccrf_set_default_option to every handle and batch created afterwards in this process.                                      */
 typedef enum lccrf_option {

@@ -188,7 +188,7 @@ struct Engine {
     bool frame_small_used = false;     //   more than 1/8 of a batch's frames did not fit that plan
     static constexpr int kDualMaxFrames = 64;    // (measured, `scripts/small_batch_latency.py`: 4 frames 98 -> 86 us, 32 frames 93 -> 83 us, 128 frames 112 -> 114 us)
     bool opt_single_wg = false;        // LCCRF_OPT_SINGLE_WORKGROUP: never the two-workgroup form (lccrf_set_option)
-    int opt_vertex_order = 0;          // LCCRF_OPT_VERTEX_ORDER: 0 automatic (8 or more frames in flight), 1 on, 2 off -- locality mode's sorted build
+    int opt_vertex_order = 0;          // LCCRF_OPT_VERTEX_ORDER: 0 automatic (= on), 1 on, 2 off -- locality mode's sorted build
     bool vorder_on = false;            // ... as decided by the last build of every kernel
     bool vorder_broken = false;        // a frame's code space overflowed (*sort.vbad): this engine keeps to the hash build
     unsigned *dual_area = nullptr;     // hand-off area of the two-workgroup form of the frame kernel (batches of up to kDualMaxFrames frames)
@@ -475,11 +475,11 @@ struct Engine {
             }
             perm_on = false;
             // ... and, with the points permuted, whether the lattices are built by SORTING the entries on the row-major code of their
-            // vertex (ids along the lattice's axes: the blur pass of many frames in flight touches half as many lines; one to four
-            // frames in flight are latency-bound and lose a little -- notes/r4_experiments.md -- hence "automatic" = 8 frames or more)
+            // vertex (ids along the lattice's axes: the blur pass touches half as many lines) -- yes unless switched off: with the
+            // points in row-major order too it wins at every number of frames in flight (notes/r4_experiments.md section 2)
             static const char *env_vo = getenv("LCCRF_VERTEX_ORDER");               // A/B switch: 1 on, 0 off (same results)
             const int vo = env_vo ? (atoi(env_vo) ? 1 : 2) : opt_vertex_order;
-            vorder_on = want && !vorder_broken && (vo == 1 || (vo == 0 && F >= 8));
+            vorder_on = want && !vorder_broken && vo != 2;
             sync_views();
             if (want) {
                 int rcs = ensure_sort_scratch();
