@@ -1208,7 +1208,7 @@ __global__ void __launch_bounds__(kBlock) k_blur2x2t(KernelDev kd, const float *
     d[v] = make_float2(tv.x + 0.5f * (ta.x + tbv.x), tv.y + 0.5f * (ta.y + tbv.y));
 }
 
-constexpr int kSliceBlurMaxFrames = 2;       // the last blur pass inside the slice (k_slice2<D1, true>) up to this many frames in flight (scripts/gpu_r4_sliceblur.sh: 2 frames -2 %, 4 and 8 +-0)
+constexpr int kSliceBlurMaxFrames = 1;       // the last blur pass inside the slice (k_slice2<D1, true>) when passes go one per launch, up to this many frames in flight (with the sorted build: two frames +2 % without it, four and eight +-0, scripts/gpu_r4_sliceblur.sh)
 constexpr int kPairFuseMaxFrames = 1;        // (measured, scripts/gpu_r4_pairs.sh: one C5 frame 52.5 -> 45.2 us per iteration; two or four frames in flight: +-0)
 inline bool pair_fuse(int F)
 {
