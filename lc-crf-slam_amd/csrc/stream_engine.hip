@@ -1092,6 +1092,28 @@ __global__ void __launch_bounds__(kBlock) k_slice(KernelDev kd, CrfDev c, const 
     }
 }
 
+// the normalisation's slice with d + 1 known at compile time: every load of a point issued before the first use (the generic kernel
+// above walks its corners one dependent gather at a time: 92 -> 35 us per 8 C5 frames).  Same operations, same order.
+template <int D1>
+__global__ void __launch_bounds__(kBlock) k_slice_norm(KernelDev kd, CrfDev c, const float *__restrict__ val)
+{
+    const int f = blockIdx.y;
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= c.n_points[f]) return;
+    const size_t fe = (size_t)f * kd.Epad;
+    const float *vf = val + (size_t)f * kd.vstride + kd.vbase;
+    int o[D1];
+    float w[D1], x[D1];
+#pragma unroll
+    for (int j = 0; j < D1; ++j) { o[j] = kd.offset[fe + (size_t)i * D1 + j]; w[j] = kd.bary[fe + (size_t)i * D1 + j]; }
+#pragma unroll
+    for (int j = 0; j < D1; ++j) x[j] = vf[o[j]];
+    float t = 0.0f;
+#pragma unroll
+    for (int j = 0; j < D1; ++j) t += (w[j] * kd.alpha) * x[j];
+    kd.norm[(size_t)f * kd.maxN + i] = 1.0f / (t + 1e-20f);
+}
+
 // ---- two-label specialisations (the SLAM configuration, L = 2): one thread per vertex / point,
 // both labels in a float2.  Same operations per label as the generic kernels above.
 __global__ void __launch_bounds__(kBlock) k_splat2(KernelDev kd, const float2 *__restrict__ in, int in_stride, int F, XcdMap nb)
@@ -1448,7 +1470,18 @@ void launch_norm(const KernelDev &kd, const CrfDev &c, int maxV, hipStream_t s)
     k_splat<<<grid_for(maxV, c.F), kBlock, 0, s>>>(kd, nullptr, 0, 1);
     const float *res;
     filter_passes(kd, c.F, maxV, 1, s, &res);
-    k_slice<<<grid_for(c.maxN, c.F), kBlock, 0, s>>>(kd, c, res, 1, SLICE_NORM);
+    const dim3 g = grid_for(c.maxN, c.F);
+    switch (kd.D1) {
+    case 2: k_slice_norm<2><<<g, kBlock, 0, s>>>(kd, c, res); break;
+    case 3: k_slice_norm<3><<<g, kBlock, 0, s>>>(kd, c, res); break;
+    case 4: k_slice_norm<4><<<g, kBlock, 0, s>>>(kd, c, res); break;
+    case 5: k_slice_norm<5><<<g, kBlock, 0, s>>>(kd, c, res); break;
+    case 6: k_slice_norm<6><<<g, kBlock, 0, s>>>(kd, c, res); break;
+    case 7: k_slice_norm<7><<<g, kBlock, 0, s>>>(kd, c, res); break;
+    case 8: k_slice_norm<8><<<g, kBlock, 0, s>>>(kd, c, res); break;
+    case 9: k_slice_norm<9><<<g, kBlock, 0, s>>>(kd, c, res); break;
+    default: k_slice<<<g, kBlock, 0, s>>>(kd, c, res, 1, SLICE_NORM); break;
+    }
 }
 
 void launch_unary_from_label_tbl(const CrfDev &c, const int16_t *label, const UnaryTable &tbl, hipStream_t s)
