@@ -594,7 +594,7 @@ def test_streaming_engine_xcd_chunked_grid_below_eight_frames(po, wl, F):
     """Fewer than 8 frames in flight (round 4): every frame owns 8 / F' XCDs and each of them a contiguous chunk of the frame's
     vertex / row / point range (F' = F rounded up to a power of two: with 3, 5, 7 frames some XCDs stay idle).  Ragged frames, an
     empty one, on engine 1 against the oracle -- and the plain grid (LCCRF_NO_XCD_CHUNK is read once per process, so the A/B
-    itself lives in scripts/gpu_r4_phase.sh; here the results must simply be the oracle's)."""
+    itself is `FRAMES=1 scripts/gpu_c5_env_ab.sh LCCRF_NO_XCD_CHUNK=1 ""`; here the results must simply be the oracle's)."""
     sizes = [700, 333, 0, 699, 5, 512, 257][:F]
     maxN = 700
     pbs = [wl.slam_problem(n, seed=640 + i) for i, n in enumerate(sizes)]
