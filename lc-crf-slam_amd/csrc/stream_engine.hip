@@ -625,8 +625,18 @@ __global__ void __launch_bounds__(kBlock) k_ecode(KernelDev kd, const int *__res
         load_entry_key<D>(kd, f, e, key);
         vertex_grid_coords<D>(key, c);
         code = 0;
+        int xd = 0;
+        bool exact = true;
 #pragma unroll
-        for (int j = 0; j < D; ++j) code += (unsigned long long)((long long)c[j] - plan[j]) * (unsigned long long)plan[kMaxD + j];
+        for (int j = 0; j < D; ++j) xd -= key[j];
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            code += (unsigned long long)((long long)c[j] - plan[j]) * (unsigned long long)plan[kMaxD + j];
+            exact &= (xd - key[j]) == c[j] * (D + 1);
+        }
+        // keys that wrapped around int16 (features thousands of cells wide: the reference's short arithmetic wraps the same way) are no
+        // lattice points any more and the code would not tell them apart: such a frame is rebuilt with the hash, which compares keys
+        if (!exact && ss.vbad) *ss.vbad = 1;
     }
     ss.vcode[(size_t)f * ss.vcap + e] = code;
     // the histogram's atomic hands back the entry's arrival number inside its bucket: the scatter below needs no second round of atomics

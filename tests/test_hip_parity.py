@@ -774,6 +774,28 @@ def test_sorted_build_falls_back_to_the_hash_when_codes_overflow(po, wl, d, spre
 
 
 @pytest.mark.gpu
+def test_sorted_build_leaves_wrapped_keys_to_the_hash(wl):
+    """Features thousands of lattice cells wide make the int16 keys wrap (the reference's `short` arithmetic wraps the same way); such
+    keys are no lattice points any more and a row-major code cannot tell them apart, but 3 dimensions of them still fit 62 bits.  The
+    sorted build notices (a key whose grid coordinates are not integers) and the engine rebuilds with the hash table, which compares
+    the keys themselves: automatic == the hash build, bit for bit.  (No oracle here: out-of-range float -> short conversions are
+    outside what the reference's own tests pin.)"""
+    N, F, d = 8300, 2, 3
+    pb = wl.generic_problem(N, [d], 2, seed=99, spread=6000.0)
+    f = np.clip(pb["kernels"][0][0], -20000, 20000).astype(np.float32)
+    res = []
+    for vo in (0, 2):
+        b = pkg.BatchCRF(F, N, 2, [d], [3.0])
+        b.set_option(pkg.OPT_VERTEX_ORDER, vo)
+        b.set_inputs_host([N] * F, [np.repeat(f[None], F, 0)], unary=np.repeat(pb["unary"][None], F, 0))
+        b.build()
+        b.inference(2, True)
+        res.append((b.probability(), b.map(), b.lattice_sizes(0)))
+        b.close()
+    assert cc.same_bits(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])
+
+
+@pytest.mark.gpu
 def test_locality_mode_with_labels_and_device_inputs(po, wl):
     """Locality mode end to end the way bench.py drives C5: device-bound inputs, unaries from labels (derived in the
     internal order), 8 frames (XCD-aware grids), two builds, against the oracle -- and one adversarial frame whose
