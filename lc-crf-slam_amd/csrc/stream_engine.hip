@@ -1255,11 +1255,16 @@ __global__ void __launch_bounds__(kBlock) k_blur2x2t(KernelDev kd, const float *
 
 constexpr int kSliceBlurMaxFrames = 1;       // the last blur pass inside the slice (k_slice2<D1, true>) when passes go one per launch, up to this many frames in flight (with the sorted build: two frames +2 % without it, four and eight +-0: `FRAMES=2 scripts/gpu_c5_env_ab.sh LCCRF_SLICE_BLUR_MAX=8 ""`)
 constexpr int kPairFuseMaxFrames = 1;        // (measured, `FRAMES=1 scripts/gpu_c5_env_ab.sh LCCRF_NO_PAIR_FUSE=1 ""`: one C5 frame 52.5 -> 45.2 us per iteration; two or four frames in flight: +-0)
-inline bool pair_fuse(int F)
+// ... or, whatever the number of frames, when the launch is SMALL: up to ~0.7 M vertices over all frames (one C5 frame: 0.59 M; two: +-0)
+// the passes are launch- and latency-bound, e.g. 8 frames of 5000 points (30 000 vertices each): 9 launches of ~3.8 us per iteration
+constexpr long kPairFuseMaxVertices = 700000;
+inline bool pair_fuse(int F, int maxV)
 {
     static const bool off = getenv("LCCRF_NO_PAIR_FUSE") != nullptr;      // A/B switch: same results either way
     static const char *force = getenv("LCCRF_PAIR_FUSE_MAX");             //  (A/B: frames-in-flight threshold)
-    return !off && F <= (force ? atoi(force) : kPairFuseMaxFrames);
+    if (off) return false;
+    if (force) return F <= atoi(force);
+    return F <= kPairFuseMaxFrames || (long)F * maxV <= kPairFuseMaxVertices;
 }
 
 inline void launch_blur2(const KernelDev &kd, const float *src, float *dst, int j, int F, int maxV, hipStream_t s)
@@ -1534,7 +1539,7 @@ void launch_step_stream(const CrfDev &c, const KernelDev *kds, const int *maxV, 
             k_splat2<<<g, blk, 0, s>>>(kd, reinterpret_cast<const float2 *>(c.Q), c.maxN, c.F, nb);
             const float *src = kd.val0;
             float *dst = kd.val1;
-            const bool pairs = pair_fuse(c.F);
+            const bool pairs = pair_fuse(c.F, maxV[k]);
             // the pass left over by the pairs rides in the slice; with a few frames in flight (one pass per launch) the last pass does
             static const char *sf = getenv("LCCRF_SLICE_BLUR_MAX");                          // (A/B: frames-in-flight threshold)
             const bool blur_in_slice = kd.D1 <= 9 && (pairs ? (kd.D1 & 1) && kd.D1 >= 3 : c.F <= (sf ? atoi(sf) : kSliceBlurMaxFrames));
