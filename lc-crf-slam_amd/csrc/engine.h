@@ -17,6 +17,12 @@ namespace lccrf {
 constexpr int kMaxD = LCCRF_MAX_DIMS;
 constexpr int kEmpty = -1;
 
+constexpr int kNbrcBlock = 64;      // vertices per base of the compact neighbour table (KernelDev::nbrc): one wavefront
+constexpr int kNbrcMinFrames = 3;   // ... which is built and read with 3 to 5 frames in flight (one frame: the passes go two per launch off the
+constexpr int kNbrcMaxFrames = 5;   //   two-hop table; two frames: +-0) (C5, per frame and iteration: 3 / 4 / 5 frames
+                                    //   28.4 -> 26.6 / 30.0 -> 24.3 / 29.1 -> 23.7 us; 6 / 7 / 8 / 16 frames, with the table loaded
+                                    //   non-temporally: +-0 / +-0 / -0.3 / -1 % -- there the pass is bound by the gathers' lines, not bytes)
+
 // Device view of one pairwise kernel across all frames of a batch.
 // All per-frame arrays are strided by the capacities below (not by the actual N / V).
 struct KernelDev {
@@ -51,6 +57,13 @@ struct KernelDev {
                           //   (v1, v2) = axis-2p neighbours of v, (a, b) = its axis-(2p+1) neighbours, (a1, a2) / (b1, b2) = the
                           //   axis-2p neighbours of a / b; -1 absent
     int nbr2_ok;          // the streaming build filled nbr2 for the lattices now in HBM
+    // compact form of nbr for the blur passes of the streaming engine (sorted build only): with the vertices in row-major order the
+    // neighbours of consecutive vertices are (nearly) consecutive, so 16-bit offsets from a base per block of kNbrcBlock vertices
+    // say the same as the 32-bit ids in half the bytes (a blur pass moves 20 instead of 24 bytes per vertex)
+    unsigned short *nbrc; // [F][D1][Epad][2] or null: {n1, n2} - base of the vertex's block, 0xffff = absent
+    int *nbrc_base;       // [F][D1][Epad / kNbrcBlock + 1][2]: smallest n1 / n2 of the block
+    int *nbrc_bad;        // pinned host word: raised by the build when a block's neighbours span more than 16 bits
+    int nbrc_ok;          // nbrc describes the lattices now in HBM
     int *rowptr;          // [F][Epad+1]       CSR: vertex -> range of splat contributions
     int *csr_pt;          // [F][Epad]         contributing point, ascending within a row
     float *csr_w;         // [F][Epad]         its barycentric weight

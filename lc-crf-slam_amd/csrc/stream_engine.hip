@@ -29,27 +29,25 @@ constexpr int kSmallFBlock = 64;          // lanes per workgroup of the iteratio
 
 // XCD-aware grids.  The chip's eight XCDs have private 4 MB L2s and workgroup L of a launch runs on XCD L % 8 (observed
 // dispatch order; used for speed only, never for correctness).  With the frame in blockIdx.y every XCD touches every frame's
-// lattice values.  Instead:
-//   8 frames or more (G = 1)   workgroup L = 8 (g nb + x) + r handles block x of frame 8 g + r: ONE XCD owns a frame, and that
-//                              frame's value array (4.7 MB at C5) is what its L2 sees in the blur gathers;
-//   fewer (G = 8 / F' XCDs per frame, F' = F rounded up to a power of two)   frame f owns the XCDs [f G, (f + 1) G) and XCD c
-//                              of them handles the CONTIGUOUS blocks [c nb, (c + 1) nb) of the frame -- a contiguous chunk of the
-//                              frame's Z-ordered vertex range (blur), row range (splat) or point range (slice): the neighbours a
-//                              blur gather wants are mostly the centre lines of nearby blocks, i.e. lines the same L2 is
-//                              fetching anyway (BASELINE config 5 as written is ONE frame: with the plain grid consecutive
-//                              blocks went round-robin over the XCDs and every L2 saw the gathers of the whole array).
+// lattice values.  Instead the launch's work -- F frames of nb blocks each, frame after frame -- is cut into EIGHT CONTIGUOUS
+// parts of `per` blocks, one per XCD: workgroup L = 8 q + x handles block x per + q of that line.
+//   F a multiple of 8      one XCD owns whole frames, and those frames' value arrays (4.7 MB each at C5) are what its L2 sees in
+//                          the blur gathers;
+//   F < 8                  an XCD handles a contiguous chunk of a frame's row-major vertex range (blur), row range (splat) or point
+//                          range (slice): the neighbours a blur gather wants are mostly the centre lines of nearby blocks, i.e.
+//                          lines the same L2 is fetching anyway (BASELINE config 5 as written is ONE frame: with the plain grid
+//                          consecutive blocks went round-robin over the XCDs and every L2 saw the gathers of the whole array);
+//   anything else          (3, 6, 12 frames ...) the same cut: every XCD gets F / 8 of a frame's worth -- frames pinned to
+//                          XCDs whole, or to power-of-two groups of them, left a quarter of the chip idle at 3, 6 or 12 frames.
 // `nb` = 0 selects the plain (x, frame) grid (empty launches only).
-struct XcdMap { int nb, G; };
+struct XcdMap { int nb, per; };
 struct FrameBlock { int f, bx; };
 __device__ __forceinline__ FrameBlock frame_block(XcdMap m)
 {
     if (m.nb == 0) return FrameBlock{(int)blockIdx.y, (int)blockIdx.x};
     const int L = blockIdx.x, xcd = L & 7, q = L >> 3;
-    if (m.G == 1) {
-        const int g = q / m.nb;
-        return FrameBlock{g * 8 + xcd, q - g * m.nb};
-    }
-    return FrameBlock{xcd / m.G, (xcd % m.G) * m.nb + q};  // (a block index beyond the frame's work fails the kernel's own range check)
+    const int idx = xcd * m.per + q, f = idx / m.nb;
+    return FrameBlock{f, idx - f * m.nb};                 // (the last XCD's tail lies beyond frame F - 1: the kernels' own range check)
 }
 // lanes per workgroup of the iteration kernels: 256; with one or two frames in flight a pass is a chain of latencies and smaller
 // workgroups drain sooner (scripts/ubench/phasecost.hip: 256 -> 64 lanes 6.8 -> 6.4 us per pass of one C5 frame; in the engine,
@@ -64,17 +62,11 @@ inline dim3 grid_xcd(long work, int F, XcdMap *m, int block = 256)
 {
     const long n = (work + block - 1) / block;
     if (n < 1) { *m = XcdMap{0, 1}; return dim3(1u, (unsigned)F); }
-    if (F >= 8) {
-        *m = XcdMap{(int)n, 1};
-        return dim3((unsigned)(8L * ((F + 7) / 8) * n));
-    }
     static const bool no_chunk = getenv("LCCRF_NO_XCD_CHUNK") != nullptr;   // A/B switch (same results): plain (x, frame) grid below 8 frames
-    if (no_chunk) { *m = XcdMap{0, 1}; return dim3((unsigned)n, (unsigned)F); }
-    int Fp = 1;
-    while (Fp < F) Fp <<= 1;
-    const int G = 8 / Fp;
-    *m = XcdMap{(int)((n + G - 1) / G), G};
-    return dim3((unsigned)(8L * m->nb));
+    if (no_chunk && F < 8) { *m = XcdMap{0, 1}; return dim3((unsigned)n, (unsigned)F); }
+    const long per = (n * F + 7) / 8;
+    *m = XcdMap{(int)n, (int)per};
+    return dim3((unsigned)(8L * per));
 }
 
 inline dim3 grid_for(long work, int F)
@@ -890,6 +882,52 @@ __global__ void __launch_bounds__(kBlock) k_neighbors(KernelDev kd, int F, XcdMa
     nbp[2 * b] = v;                      // its n1
 }
 
+// The compact neighbour table of the sorted build (KernelDev::nbrc): per block of kNbrcBlock = 64 vertices (one wavefront) and axis
+// the smallest n1 and the smallest n2, and per vertex the two 16-bit offsets from them.  Ids follow the codes, so n1 / n2 grow with v
+// and a block's neighbours span about a block; should a span not fit 16 bits the pinned word is raised and the blur keeps to the
+// 32-bit table.  The host does not know V yet (a grid over the CAPACITY was 0.16 ms of empty workgroups at C5 x 8): kNbrcGrid
+// workgroups per (frame, axis) walk the blocks below V, four per wavefront and round with their loads issued together (one block
+// per round and a workgroup-wide minimum through LDS: 156 us per 4 C5 frames).
+constexpr int kNbrcGrid = 64;
+__device__ __forceinline__ int wave_min(int x)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) x = min(x, __shfl_xor(x, m, 64));
+    return x;
+}
+__global__ void __launch_bounds__(kBlock) k_nbr_compact(KernelDev kd, int limit)          // limit: 0xffff (the instrumented library's test hook lowers it)
+{
+    static_assert(kNbrcBlock == 64, "one wavefront per base");
+    constexpr int U = 4;
+    const int f = blockIdx.z, j = blockIdx.y;
+    const int V = kd.V[f];
+    const size_t fj = (size_t)f * kd.D1 + j;
+    const int2 *tab = reinterpret_cast<const int2 *>(kd.nbr) + fj * kd.Epad;
+    unsigned *out = reinterpret_cast<unsigned *>(kd.nbrc) + fj * kd.Epad;
+    int2 *base = reinterpret_cast<int2 *>(kd.nbrc_base) + fj * (kd.Epad / kNbrcBlock + 1);
+    const int lane = threadIdx.x & 63, wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6), nwaves = kNbrcGrid * (kBlock / 64);
+    for (int b0 = wave * U; b0 * kNbrcBlock < V; b0 += nwaves * U) {
+        int2 n[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int v = (b0 + u) * kNbrcBlock + lane;
+            n[u] = v < V ? tab[v] : make_int2(-1, -1);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int b = b0 + u, v = b * kNbrcBlock + lane;
+            if (b * kNbrcBlock >= V) break;
+            const int m0 = wave_min(n[u].x < 0 ? INT_MAX : n[u].x), m1 = wave_min(n[u].y < 0 ? INT_MAX : n[u].y);
+            const int lo0 = m0 == INT_MAX ? 0 : m0, lo1 = m1 == INT_MAX ? 0 : m1;
+            if (lane == 0) base[b] = make_int2(lo0, lo1);
+            if (v >= V) continue;
+            const int o0 = n[u].x < 0 ? 0xffff : n[u].x - lo0, o1 = n[u].y < 0 ? 0xffff : n[u].y - lo1;
+            if ((n[u].x >= 0 && o0 >= limit) || (n[u].y >= 0 && o1 >= limit)) *kd.nbrc_bad = 1;
+            out[v] = (unsigned)(o0 & 0xffff) | ((unsigned)(o1 & 0xffff) << 16);
+        }
+    }
+}
+
 // nbr16 = (n1 + 1) | (n2 + 1) << 16 per (axis, vertex) for frames whose ids fit 16 bits (the fused engine's table)
 __global__ void __launch_bounds__(kBlock) k_neighbors16(KernelDev kd)
 {
@@ -1201,6 +1239,41 @@ __global__ void __launch_bounds__(kBlock) k_blur2(KernelDev kd, const float *__r
     }
 }
 
+// The same pass off the COMPACT neighbour table of the sorted build (KernelDev::nbrc): 4 instead of 8 table bytes per vertex, the
+// ids rebuilt as base-of-the-block + 16-bit offset (0xffff = absent -> -1).  Same neighbours, same operations, same bits.
+template <bool NT>
+__global__ void __launch_bounds__(kBlock) k_blur2c(KernelDev kd, const float *__restrict__ src,
+                                                   float *__restrict__ dst, int j, int F, XcdMap nb)
+{
+    const FrameBlock fb = frame_block(nb);
+    const int f = fb.f;
+    if (f >= F) return;
+    const int V = kd.V[f];
+    const int v = 2 * (fb.bx * (int)blockDim.x + threadIdx.x);
+    if (v >= V) return;
+    const float2 *o = reinterpret_cast<const float2 *>(src + (size_t)f * kd.vstride + kd.vbase);   // o[-1] = absent
+    float2 *d = reinterpret_cast<float2 *>(dst + (size_t)f * kd.vstride + kd.vbase);
+    const size_t fj = (size_t)f * kd.D1 + j;
+    const int2 base = reinterpret_cast<const int2 *>(kd.nbrc_base)[fj * (kd.Epad / kNbrcBlock + 1) + v / kNbrcBlock];
+    const unsigned *tp = reinterpret_cast<const unsigned *>(kd.nbrc) + fj * kd.Epad + v;            // (v even: 8-byte aligned)
+    if (v + 1 < V) {
+        typedef unsigned lccrf_v2u __attribute__((ext_vector_type(2)));
+        const lccrf_v2u t = NT ? __builtin_nontemporal_load(reinterpret_cast<const lccrf_v2u *>(tp)) : *reinterpret_cast<const lccrf_v2u *>(tp);
+        const unsigned a0 = t.x & 0xffffu, b0 = t.x >> 16, a1 = t.y & 0xffffu, b1 = t.y >> 16;
+        const int n0 = a0 == 0xffffu ? -1 : base.x + (int)a0, m0 = b0 == 0xffffu ? -1 : base.y + (int)b0;
+        const int n1 = a1 == 0xffffu ? -1 : base.x + (int)a1, m1 = b1 == 0xffffu ? -1 : base.y + (int)b1;
+        const float4 c = *reinterpret_cast<const float4 *>(o + v);
+        const float2 x0 = o[n0], y0 = o[m0], x1 = o[n1], y1 = o[m1];
+        *reinterpret_cast<float4 *>(d + v) = make_float4(c.x + 0.5f * (x0.x + y0.x), c.y + 0.5f * (x0.y + y0.y),
+                                                         c.z + 0.5f * (x1.x + y1.x), c.w + 0.5f * (x1.y + y1.y));
+    } else {
+        const unsigned t = *tp, a0 = t & 0xffffu, b0 = t >> 16;
+        const int n0 = a0 == 0xffffu ? -1 : base.x + (int)a0, m0 = b0 == 0xffffu ? -1 : base.y + (int)b0;
+        const float2 c = o[v], x = o[n0], y = o[m0];
+        d[v] = make_float2(c.x + 0.5f * (x.x + y.x), c.y + 0.5f * (x.y + y.y));
+    }
+}
+
 // TWO passes (axes j, j + 1) in one launch, no extra tables -- for one or two frames in flight, where a pass is a chain of
 // latencies (launch ~2.5 us, table load, gather: ~7 us per pass of one C5 frame against ~0.5 us of streaming) and every launch
 // saved counts: out[v] = t[v] + 0.5 (t[a] + t[b]) with {a, b} = the axis-(j+1) neighbours of v and
@@ -1267,12 +1340,20 @@ inline bool pair_fuse(int F, int maxV)
     return F <= kPairFuseMaxFrames || (long)F * maxV <= kPairFuseMaxVertices;
 }
 
+// (the table non-temporally: C5 with 5 / 6 / 7 frames in flight 23.7 -> 26.1 / 26.9 -> 25.7 / 27.0 -> 24.8 us per frame and iteration)
+constexpr int kBlurNtMinFrames = 6;
 inline void launch_blur2(const KernelDev &kd, const float *src, float *dst, int j, int F, int maxV, hipStream_t s)
 {
     XcdMap nb;
     const int blk = iter_block(F);
     const dim3 g = grid_xcd((maxV + 1) / 2, F, &nb, blk);
-    if (F >= 8) k_blur2<true><<<g, blk, 0, s>>>(kd, src, dst, j, F, nb);
+    static const bool no_compact = getenv("LCCRF_NO_COMPACT_NBR") != nullptr;      // A/B switch: same results either way
+    static const char *env_nt = getenv("LCCRF_BLUR_NT");                            // A/B: 0 plain loads, 1 non-temporal
+    const bool nt = env_nt ? atoi(env_nt) != 0 : F >= kBlurNtMinFrames;
+    if (kd.nbrc && kd.nbrc_ok && !no_compact) {
+        if (nt) k_blur2c<true><<<g, blk, 0, s>>>(kd, src, dst, j, F, nb);
+        else k_blur2c<false><<<g, blk, 0, s>>>(kd, src, dst, j, F, nb);
+    } else if (nt) k_blur2<true><<<g, blk, 0, s>>>(kd, src, dst, j, F, nb);
     else k_blur2<false><<<g, blk, 0, s>>>(kd, src, dst, j, F, nb);
 }
 
@@ -1431,6 +1512,13 @@ void build_kernel_d(const KernelDev &kd, const CrfDev &c, hipStream_t s, const S
         XcdMap nb;
         const dim3 g = grid_xcd((long)kd.Epad, F, &nb);
         k_eneighbors<D><<<g, kBlock, 0, s>>>(kd, F, nb, ss);
+        if (kd.nbrc && F >= kNbrcMinFrames && F <= kNbrcMaxFrames) {
+            int limit = 0xffff;
+#if LCCRF_INSTRUMENT
+            if (const char *e = getenv("LCCRF_NBRC_SPAN")) limit = std::min(std::max(atoi(e), 1), 0xffff);   // test hook: spans the table "cannot" hold
+#endif
+            k_nbr_compact<<<dim3(kNbrcGrid, D1, F), kBlock, 0, s>>>(kd, limit);
+        }
     } else {
         (void)hipMemsetAsync(kd.slot, 0xff, (size_t)F * kd.cap * sizeof(int), s);
         k_points<D, false><<<grid_for(kd.maxNpad, F), kBlock, 0, s>>>(kd, c.n_points, nullptr);

@@ -10,12 +10,15 @@ BIT-IDENTICAL Q and normalisation, and identical lattice numbering.
 """
 import importlib
 import os
+import subprocess
+import sys
 
 import numpy as np
 import pytest
 
 import crf_cases as cc
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pkg = importlib.import_module("lc-crf-slam_amd")
 pytestmark = pytest.mark.gpu
 
@@ -589,13 +592,14 @@ def test_streaming_engine_xcd_aware_grid_with_many_frames(po, wl):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("F", [1, 2, 3, 4, 5, 7])
+@pytest.mark.parametrize("F", [1, 2, 3, 4, 5, 6, 7, 9, 12, 13])
 def test_streaming_engine_xcd_chunked_grid_below_eight_frames(po, wl, F):
-    """Fewer than 8 frames in flight (round 4): every frame owns 8 / F' XCDs and each of them a contiguous chunk of the frame's
-    vertex / row / point range (F' = F rounded up to a power of two: with 3, 5, 7 frames some XCDs stay idle).  Ragged frames, an
-    empty one, on engine 1 against the oracle -- and the plain grid (LCCRF_NO_XCD_CHUNK is read once per process, so the A/B
-    itself is `FRAMES=1 scripts/gpu_c5_env_ab.sh LCCRF_NO_XCD_CHUNK=1 ""`; here the results must simply be the oracle's)."""
-    sizes = [700, 333, 0, 699, 5, 512, 257][:F]
+    """Any number of frames in flight (round 4): the launch's blocks -- frame after frame -- are cut into eight contiguous parts,
+    one per XCD, so with fewer than 8 frames an XCD holds a contiguous chunk of a frame's vertex / row / point range and with 3, 6,
+    12, 13 frames a part spans a frame boundary.  Ragged frames, an empty one, on engine 1 against the oracle -- and the plain grid
+    (LCCRF_NO_XCD_CHUNK is read once per process, so the A/B itself is `FRAMES=1 scripts/gpu_c5_env_ab.sh LCCRF_NO_XCD_CHUNK=1 ""`;
+    here the results must simply be the oracle's)."""
+    sizes = [700, 333, 0, 699, 5, 512, 257, 700, 1, 650, 0, 300, 699][:F]
     maxN = 700
     pbs = [wl.slam_problem(n, seed=640 + i) for i, n in enumerate(sizes)]
     feats = [np.zeros((F, maxN, 2), np.float32) for _ in range(2)]
@@ -771,6 +775,50 @@ def test_sorted_build_falls_back_to_the_hash_when_codes_overflow(po, wl, d, spre
     b.inference(2, True)
     assert cc.same_bits(b.probability(), Q)
     b.close(); o.close()
+
+
+@pytest.mark.gpu
+def test_compact_neighbour_table_is_abandoned_when_a_span_does_not_fit(po, wl):
+    """With up to 5 large frames in flight the blur passes read the sorted build's COMPACT neighbour table: 16-bit offsets from a base
+    per 64 vertices.  Ids follow the row-major codes, so a block's neighbours span about a block -- but nothing guarantees it: the
+    build checks every offset and raises a pinned flag, and the engine then reads the 32-bit table.  LCCRF_NBRC_SPAN (INSTRUMENTED
+    library only, child process) lowers the width the check allows to 3 bits, which real lattices exceed at once: same bits as the
+    oracle through the fallback, and through the compact table without the hook."""
+    instr = os.path.join(ROOT, "lc-crf-slam_amd", "liblccrf_hip_instr.so")
+    if not os.path.exists(instr):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "lc-crf-slam_amd"), "-j4", "INSTRUMENT=1"], check=True, stdout=subprocess.DEVNULL)
+    code = r"""
+import importlib, sys, numpy as np
+sys.path.insert(0, %r)
+pkg = importlib.import_module("lc-crf-slam_amd"); wl = importlib.import_module("lc-crf-slam_amd.workloads")
+N, F, d = 9000, 3, 5
+pb = wl.generic_problem(N, [d], 2, seed=31)
+b = pkg.BatchCRF(F, N, 2, [d], [float(pb["kernels"][0][1])])
+b.set_inputs_host([N, N - 700, N], [np.repeat(pb["kernels"][0][0][None], F, 0)], unary=np.repeat(pb["unary"][None], F, 0))
+b.build(); b.inference(3, True)
+np.save(sys.argv[1], np.concatenate([b.probability().ravel(), b.map().astype(np.float32).ravel()]))
+""" % ROOT
+    N, F, d = 9000, 3, 5
+    pb = wl.generic_problem(N, [d], 2, seed=31)
+    want = []
+    for n in (N, N - 700):
+        q = dict(pb, N=n, unary=pb["unary"][:n], kernels=[(pb["kernels"][0][0][:n], pb["kernels"][0][1])])
+        o = cc.setup(po.OracleCRF, q)
+        o.inference_native(3, True)
+        want.append((o.probability().copy(), o.map().copy()))
+        o.close()
+    for env, said in (({"LCCRF_NBRC_SPAN": "8"}, True), ({}, False)):
+        path = os.path.join(ROOT, "gpurun_out", "nbrc_span.npy")
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        r = subprocess.run([sys.executable, "-c", code, path], check=True, env=dict(os.environ, LCCRF_LIB=instr, **env), timeout=300,
+                           stderr=subprocess.PIPE)
+        assert (b"compact neighbour table abandoned" in r.stderr) == said, r.stderr[-400:]
+        res = np.load(path)
+        Q, M = res[:F * N * 2].reshape(F, N, 2), res[F * N * 2:].reshape(F, N)
+        for f, n in enumerate((N, N - 700, N)):
+            wq, wm = want[0] if n == N else want[1]
+            assert cc.same_bits(Q[f, :n], wq) and np.array_equal(M[f, :n], wm.astype(np.float32)), (env, f)
+    assert b"LCCRF_NBRC_SPAN" not in open(os.path.join(ROOT, "lc-crf-slam_amd", "liblccrf_hip.so"), "rb").read()
 
 
 @pytest.mark.gpu
