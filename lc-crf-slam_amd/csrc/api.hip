@@ -191,7 +191,7 @@ struct Engine {
     int opt_vertex_order = 0;          // LCCRF_OPT_VERTEX_ORDER: 0 automatic (= on), 1 on, 2 off -- locality mode's sorted build
     bool vorder_on = false;            // ... as decided by the last build of every kernel
     bool vorder_broken = false;        // a frame's code space overflowed (*sort.vbad): this engine keeps to the hash build
-    int *nbrc_bad = nullptr;           // pinned: the sorted build could not put a neighbour table into 16-bit offsets (KernelDev::nbrc_bad)
+    int *tbl_bad = nullptr;            // pinned [2]: what the sorted build found wrong with its tables (KernelDev::tbl_bad)
     unsigned *dual_area = nullptr;     // hand-off area of the two-workgroup form of the frame kernel (batches of up to kDualMaxFrames frames)
     unsigned dual_epoch = 0;
     // object API: the frame kernel's last act is a store of `done_epoch` into this pinned word, behind its results; the host
@@ -374,17 +374,20 @@ struct Engine {
         // one frame in flight, large frames (the object API's handles are sized for SLAM frames, which run on the one-workgroup engines):
         // the blur passes go two per launch and read a two-hop neighbour table
         if (Fcap == 1 && L == 2 && allow_perm && (rc = mem.alloc(&k.nbr2, (size_t)(k.D1 / 2) * E * 8))) return rc;
+        if (L == 2 && allow_perm && maxN >= kPermMinPoints) {
+            if (!tbl_bad) {
+                if ((rc = mem.alloc_pinned(&tbl_bad, 2))) return rc;
+                tbl_bad[0] = tbl_bad[1] = 0;
+            }
+            k.tbl_bad = tbl_bad;
+            if ((rc = mem.alloc(&k.fastn, Fz * E))) return rc;
+        }
         // large frames, a few in flight: the sorted build also leaves the neighbour table in its compact form (16-bit offsets), for
         // the batches of kNbrcMinFrames..kNbrcMaxFrames frames this engine may see
-        if (L == 2 && allow_perm && maxN >= kPermMinPoints && Fcap >= kNbrcMinFrames) {
+        if (k.tbl_bad && Fcap >= kNbrcMinFrames) {
             const size_t Fc = (size_t)std::min(Fcap, kNbrcMaxFrames);
-            if (!nbrc_bad) {
-                if ((rc = mem.alloc_pinned(&nbrc_bad, 1))) return rc;
-                *nbrc_bad = 0;
-            }
             if ((rc = mem.alloc(&k.nbrc, Fc * k.D1 * E * 2))) return rc;
             if ((rc = mem.alloc(&k.nbrc_base, Fc * k.D1 * (E / kNbrcBlock + 1) * 2))) return rc;
-            k.nbrc_bad = nbrc_bad;
         }
         if ((rc = mem.alloc(&k.rowptr, Fz * (E + 1)))) return rc;
         if ((rc = mem.alloc(&k.csr_pt, Fz * E))) return rc;
@@ -517,12 +520,14 @@ struct Engine {
             const int NA = activeN > 0 ? activeN : maxN;
             if (!no_small && k + 1 < k0 + n && build_small_supported(&kdevs[k], 2, NA)) m = 2;
             if (!no_small && build_small_supported(&kdevs[k], m, NA)) {
-                for (int u = 0; u < m; ++u) kernels[k + u].dev.nbr2_ok = kernels[k + u].dev.nbrc_ok = 0;
+                for (int u = 0; u < m; ++u) kernels[k + u].dev.nbr2_ok = kernels[k + u].dev.nbrc_ok = kernels[k + u].dev.fast0_ok = 0;
                 launch_build_small(&kdevs[k], m, NA, crf, stream);   // writes V / rowmax to the pinned mirrors itself
             } else {
                 m = 1;
                 kernels[k].dev.nbr2_ok = kernels[k].dev.nbr2 != nullptr;      // (the streaming build fills the two-hop table when there is one)
                 kernels[k].dev.nbrc_ok = kernels[k].dev.nbrc != nullptr && kernels[k].dev.vorder && F >= kNbrcMinFrames && F <= kNbrcMaxFrames;   // (... and the sorted build the compact one)
+                kernels[k].dev.fast0_ok = kernels[k].dev.tbl_bad != nullptr && kernels[k].dev.vorder;
+                kernels[k].dev.nbr2_first = kernels[k].dev.fast0_ok;              // (what build_kernel_d derives from the same two fields)
                 launch_build_kernel(kdevs[k], crf, kernels[k].maxV, stream, perm_on ? &sort : nullptr);
                 launch_norm(kdevs[k], crf, kernels[k].maxV, stream);
                 HIP_TRY(hipMemcpyAsync(V_host + (size_t)k * Fcap, kernels[k].dev.V, sizeof(int) * F, hipMemcpyDeviceToHost, stream));
@@ -565,12 +570,21 @@ struct Engine {
             if (rcb) return rcb;
             HIP_TRY(hipStreamSynchronize(stream));
         }
-        if (nbrc_bad && *nbrc_bad) {                       // a block's neighbours span more than 16 bits: the blur reads the 32-bit table
-            *nbrc_bad = 0;
-            for (auto &ks : kernels) ks.dev.nbrc_ok = 0;
 #if LCCRF_INSTRUMENT
-            fprintf(stderr, "lccrf: compact neighbour table abandoned (a block's neighbours span more than its offsets hold)\n");
+        if (tbl_bad && getenv("LCCRF_FAST0_BREAK")) tbl_bad[1] = 1;      // test hook: as if the build had found an axis-0 neighbour elsewhere
 #endif
+        if (tbl_bad && (tbl_bad[0] || tbl_bad[1])) {
+            // [0] a block's neighbours span more than 16 bits: the blur reads the 32-bit table; [1] an axis-0 neighbour that is not the
+            // next / previous id (cannot happen with exact codes -- checked all the same): the first blur pass keeps its own launch
+            for (auto &ks : kernels) {
+                if (tbl_bad[0]) ks.dev.nbrc_ok = 0;
+                if (tbl_bad[1]) ks.dev.fast0_ok = 0;
+            }
+#if LCCRF_INSTRUMENT
+            if (tbl_bad[0]) fprintf(stderr, "lccrf: compact neighbour table abandoned (a block's neighbours span more than its offsets hold)\n");
+            if (tbl_bad[1]) fprintf(stderr, "lccrf: first blur pass keeps its own launch (an axis-0 neighbour is not an adjacent id)\n");
+#endif
+            tbl_bad[0] = tbl_bad[1] = 0;
         }
         for (size_t k = 0; k < kernels.size(); ++k) {
             int m = 0, r = 0;

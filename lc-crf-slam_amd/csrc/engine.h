@@ -56,14 +56,19 @@ struct KernelDev {
                           //   launch per TWO blur passes, stream_engine.hip: k_blur2x2t): {v1, v2, a, b, a1, a2, b1, b2} with
                           //   (v1, v2) = axis-2p neighbours of v, (a, b) = its axis-(2p+1) neighbours, (a1, a2) / (b1, b2) = the
                           //   axis-2p neighbours of a / b; -1 absent
-    int nbr2_ok;          // the streaming build filled nbr2 for the lattices now in HBM
+    int nbr2_ok;          // the streaming build filled nbr2 for the lattices now in HBM ...
+    int nbr2_first;       // ... for the pass pairs (first + 2p, first + 2p + 1): first = 1 when the splat takes pass 0 along (fast0_ok)
     // compact form of nbr for the blur passes of the streaming engine (sorted build only): with the vertices in row-major order the
     // neighbours of consecutive vertices are (nearly) consecutive, so 16-bit offsets from a base per block of kNbrcBlock vertices
     // say the same as the 32-bit ids in half the bytes (a blur pass moves 20 instead of 24 bytes per vertex)
     unsigned short *nbrc; // [F][D1][Epad][2] or null: {n1, n2} - base of the vertex's block, 0xffff = absent
     int *nbrc_base;       // [F][D1][Epad / kNbrcBlock + 1][2]: smallest n1 / n2 of the block
-    int *nbrc_bad;        // pinned host word: raised by the build when a block's neighbours span more than 16 bits
+    int *tbl_bad;         // two pinned host words raised by the sorted build: [0] a block's neighbours span more than 16 bits (nbrc is
+                          //   unusable), [1] an axis-0 neighbour is not the next / previous id (fast0_ok must not be relied on)
     int nbrc_ok;          // nbrc describes the lattices now in HBM
+    int fast0_ok;         // sorted build: axis 0 is the fastest coordinate of the row-major code, so a vertex's axis-0 neighbours are
+                          //   v - 1 and v + 1 or absent, and the first blur pass can ride in the splat (k_splat2<true>) ...
+    uint8_t *fastn;       // [F][Epad] or null: ... which reads this instead of the table: 1 = vertex v + 1 is v's axis-0 neighbour
     int *rowptr;          // [F][Epad+1]       CSR: vertex -> range of splat contributions
     int *csr_pt;          // [F][Epad]         contributing point, ascending within a row
     float *csr_w;         // [F][Epad]         its barycentric weight

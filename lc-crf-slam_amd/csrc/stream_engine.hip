@@ -806,6 +806,7 @@ __global__ void __launch_bounds__(kBlock) k_eneighbors(KernelDev kd, int F, XcdM
     unsigned long long first[D1];
 #pragma unroll
     for (int j = 0; j < D1; ++j) first[j] = vkey[min(v0[j], V - 1)];
+    bool next0 = false;
 #pragma unroll
     for (int j = 0; j < D1; ++j) {
         if (!ok[j] || v0[j] >= v1[j]) continue;
@@ -813,10 +814,15 @@ __global__ void __launch_bounds__(kBlock) k_eneighbors(KernelDev kd, int F, XcdM
         for (int u = v0[j] + 1; found < 0 && u < v1[j]; ++u)
             if (vkey[u] == target[j]) found = u;
         if (found < 0) continue;
+        if (j == 0) {                    // axis 0 is the code's fastest coordinate: code + 1 is the next id
+            next0 = true;
+            if (found != v + 1 && kd.tbl_bad) kd.tbl_bad[1] = 1;
+        }
         int *nbp = kd.nbr + ((size_t)f * D1 + j) * kd.Epad * 2;
         nbp[2 * v + 1] = found;          // my n2
         nbp[2 * found] = v;              // its n1
     }
+    if (kd.fastn) kd.fastn[(size_t)f * kd.Epad + v] = next0 ? 1 : 0;
 }
 
 // offset[e] = dense id of e's vertex; the first entry of each vertex registers as its
@@ -922,7 +928,7 @@ __global__ void __launch_bounds__(kBlock) k_nbr_compact(KernelDev kd, int limit)
             if (lane == 0) base[b] = make_int2(lo0, lo1);
             if (v >= V) continue;
             const int o0 = n[u].x < 0 ? 0xffff : n[u].x - lo0, o1 = n[u].y < 0 ? 0xffff : n[u].y - lo1;
-            if ((n[u].x >= 0 && o0 >= limit) || (n[u].y >= 0 && o1 >= limit)) *kd.nbrc_bad = 1;
+            if ((n[u].x >= 0 && o0 >= limit) || (n[u].y >= 0 && o1 >= limit)) kd.tbl_bad[0] = 1;
             out[v] = (unsigned)(o0 & 0xffff) | ((unsigned)(o1 & 0xffff) << 16);
         }
     }
@@ -940,16 +946,16 @@ __global__ void __launch_bounds__(kBlock) k_neighbors16(KernelDev kd)
     kd.nbr16[((size_t)f * kd.D1 + j) * kd.Epad + v] = (unsigned)(r.x + 1) | ((unsigned)(r.y + 1) << 16);
 }
 
-// two-hop table of the pass pair (2p, 2p + 1) for single-frame engines (KernelDev::nbr2): everything k_blur2x2 looks up on its way,
-// looked up once at build time, so that a launch of two passes is a table read and ONE level of gathers
-__global__ void __launch_bounds__(kBlock) k_neighbors_2hop(KernelDev kd, int npairs)
+// two-hop table of the pass pair (first + 2p, first + 2p + 1) for single-frame engines (KernelDev::nbr2): everything k_blur2x2 looks
+// up on its way, looked up once at build time, so that a launch of two passes is a table read and ONE level of gathers
+__global__ void __launch_bounds__(kBlock) k_neighbors_2hop(KernelDev kd, int first, int npairs)
 {
     const int f = blockIdx.y;
     const int V = kd.V[f];
     const int idx = blockIdx.x * kBlock + threadIdx.x;
     if (idx >= V * npairs) return;
     const int p = idx / V, v = idx - p * V;
-    const int2 *nj = reinterpret_cast<const int2 *>(kd.nbr) + ((size_t)f * kd.D1 + 2 * p) * kd.Epad;
+    const int2 *nj = reinterpret_cast<const int2 *>(kd.nbr) + ((size_t)f * kd.D1 + first + 2 * p) * kd.Epad;
     const int2 *nj1 = nj + kd.Epad;
     const int2 ab = nj1[v], nv = nj[v];
     const int2 na = ab.x >= 0 ? nj[ab.x] : make_int2(-1, -1), nb = ab.y >= 0 ? nj[ab.y] : make_int2(-1, -1);
@@ -1177,24 +1183,49 @@ __global__ void __launch_bounds__(kBlock) k_slice_norm(KernelDev kd, CrfDev c, c
 
 // ---- two-label specialisations (the SLAM configuration, L = 2): one thread per vertex / point,
 // both labels in a float2.  Same operations per label as the generic kernels above.
+// BLUR0 (sorted build, KernelDev::fast0_ok): the FIRST blur pass rides along.  Axis 0 is the fastest coordinate of the row-major
+// vertex code, so a vertex's axis-0 neighbours are v - 1 and v + 1 (or absent): the workgroup's row sums go to LDS -- every thread
+// sums one row, the first and the last only for their neighbours' sake (blockDim - 2 results per workgroup) -- and
+// t[v] = s[v] + 0.5 (s[n1] + s[n2]) is formed from there: the operations of k_blur2 on the stored sums, in the same order, hence the
+// same bits, without the pass's launch, its table-to-gather round trip and its 16 bytes per vertex of reads and writes.
+template <bool BLUR0>
 __global__ void __launch_bounds__(kBlock) k_splat2(KernelDev kd, const float2 *__restrict__ in, int in_stride, int F, XcdMap nb)
 {
+    __shared__ float2 tile[BLUR0 ? kBlock : 1];
+    __shared__ uint8_t next[BLUR0 ? kBlock : 1];
     const FrameBlock fb = frame_block(nb);
     const int f = fb.f;
     if (f >= F) return;
-    const int v = fb.bx * (int)blockDim.x + threadIdx.x;
-    if (v >= kd.V[f]) return;
+    const int V = kd.V[f];
+    const int v0 = BLUR0 ? fb.bx * ((int)blockDim.x - 2) - 1 : fb.bx * (int)blockDim.x;      // the vertex of thread 0
+    const int v = v0 + threadIdx.x;
+    if (v0 + (BLUR0 ? 1 : 0) >= V) return;                // (the whole workgroup)
     const size_t fe = (size_t)f * kd.Epad, f1 = (size_t)f * (kd.Epad + 1);
     const float2 *x = in + (size_t)f * in_stride;
     float a0 = 0.0f, a1 = 0.0f;
-    const int s = kd.rowptr[f1 + v], t = kd.rowptr[f1 + v + 1];
-    for (int p = s; p < t; ++p) {
-        const float w = kd.csr_w[fe + p];
-        const float2 q = x[kd.csr_pt[fe + p]];
-        a0 += w * q.x;
-        a1 += w * q.y;
+    uint8_t nx = 0;
+    if (v >= 0 && v < V) {
+        const int s = kd.rowptr[f1 + v], t = kd.rowptr[f1 + v + 1];
+        if (BLUR0) nx = kd.fastn[fe + v];
+        for (int p = s; p < t; ++p) {
+            const float w = kd.csr_w[fe + p];
+            const float2 q = x[kd.csr_pt[fe + p]];
+            a0 += w * q.x;
+            a1 += w * q.y;
+        }
     }
-    reinterpret_cast<float2 *>(kd.val0 + (size_t)f * kd.vstride + kd.vbase)[v] = make_float2(a0, a1);
+    float2 *out = reinterpret_cast<float2 *>(kd.val0 + (size_t)f * kd.vstride + kd.vbase);
+    if (!BLUR0) {
+        if (v < V) out[v] = make_float2(a0, a1);
+        return;
+    }
+    tile[threadIdx.x] = make_float2(a0, a1);
+    next[threadIdx.x] = nx;
+    __syncthreads();
+    if (threadIdx.x == 0 || threadIdx.x == blockDim.x - 1 || v >= V) return;
+    const float2 zero = make_float2(0.0f, 0.0f);                                                   // (what the absent vertex's slot holds)
+    const float2 p = next[threadIdx.x - 1] ? tile[threadIdx.x - 1] : zero, q = nx ? tile[threadIdx.x + 1] : zero;    // n1 = v - 1, n2 = v + 1
+    out[v] = make_float2(a0 + 0.5f * (p.x + q.x), a1 + 0.5f * (p.y + q.y));
 }
 
 typedef int lccrf_v4i __attribute__((ext_vector_type(4)));
@@ -1536,7 +1567,11 @@ void build_kernel_d(const KernelDev &kd, const CrfDev &c, hipStream_t s, const S
         k_neighbors<D><<<g, kBlock, 0, s>>>(kd, F, nb);
     }
     if (kd.Epad < 65535) k_neighbors16<<<grid_for((long)kd.Epad * D1, F), kBlock, 0, s>>>(kd);
-    if (kd.nbr2) k_neighbors_2hop<<<grid_for((long)kd.Epad * (D1 / 2), F), kBlock, 0, s>>>(kd, D1 / 2);
+    if (kd.nbr2) {
+        const int first = (vsort && kd.vorder && kd.tbl_bad) ? 1 : 0;     // the sorted build's splat takes pass 0 along (KernelDev::nbr2_first)
+        const int npairs = (D1 - first) / 2;
+        if (npairs > 0) k_neighbors_2hop<<<grid_for((long)kd.Epad * npairs, F), kBlock, 0, s>>>(kd, first, npairs);
+    }
     if (!(vsort && kd.vorder)) {
         // CSR (the sorted build's runs are the rows already)
         (void)hipMemsetAsync(kd.flag, 0, (size_t)F * (kd.Epad + 1) * sizeof(int), s);
@@ -1623,20 +1658,27 @@ void launch_step_stream(const CrfDev &c, const KernelDev *kds, const int *maxV, 
             const KernelDev &kd = kds[k];
             XcdMap nb;
             const int blk = iter_block(c.F);
-            dim3 g = grid_xcd(maxV[k], c.F, &nb, blk);
-            k_splat2<<<g, blk, 0, s>>>(kd, reinterpret_cast<const float2 *>(c.Q), c.maxN, c.F, nb);
+            const bool pairs = pair_fuse(c.F, maxV[k]);
+            // sorted build, one pass per launch: the first pass (axis 0 = the code's fastest coordinate) rides in the splat
+            static const bool no_sb = getenv("LCCRF_NO_SPLAT_BLUR") != nullptr;               // A/B switch: same results either way
+            const bool blur0 = kd.vorder && kd.fast0_ok && !no_sb;
+            const int j0 = blur0 ? 1 : 0;
+            dim3 g = blur0 ? grid_xcd(((long)maxV[k] + blk - 3) / (blk - 2) * blk, c.F, &nb, blk) : grid_xcd(maxV[k], c.F, &nb, blk);
+            if (blur0) k_splat2<true><<<g, blk, 0, s>>>(kd, reinterpret_cast<const float2 *>(c.Q), c.maxN, c.F, nb);
+            else k_splat2<false><<<g, blk, 0, s>>>(kd, reinterpret_cast<const float2 *>(c.Q), c.maxN, c.F, nb);
             const float *src = kd.val0;
             float *dst = kd.val1;
-            const bool pairs = pair_fuse(c.F, maxV[k]);
             // the pass left over by the pairs rides in the slice; with a few frames in flight (one pass per launch) the last pass does
             static const char *sf = getenv("LCCRF_SLICE_BLUR_MAX");                          // (A/B: frames-in-flight threshold)
-            const bool blur_in_slice = kd.D1 <= 9 && (pairs ? (kd.D1 & 1) && kd.D1 >= 3 : c.F <= (sf ? atoi(sf) : kSliceBlurMaxFrames));
+            const bool blur_in_slice = kd.D1 <= 9 && (pairs ? ((kd.D1 - j0) & 1) && kd.D1 >= 3 : c.F <= (sf ? atoi(sf) : kSliceBlurMaxFrames));
             const int n_own = blur_in_slice ? kd.D1 - 1 : kd.D1;                           // blur passes with a launch of their own
-            for (int j = 0; j < n_own;) {
+            for (int j = j0; j < n_own;) {
                 if (pairs && j + 1 < n_own) {             // one frame in flight: two passes per launch
                     const dim3 gp = grid_xcd(maxV[k], c.F, &nb, blk);
                     static const bool no_tbl = getenv("LCCRF_NO_2HOP_TABLE") != nullptr;      // A/B switch: same results either way
-                    if (kd.nbr2 && kd.nbr2_ok && !no_tbl) k_blur2x2t<<<gp, blk, 0, s>>>(kd, src, dst, j / 2, kd.D1 / 2, c.F, nb);
+                    const int jt = j - kd.nbr2_first;     // the table holds the pairs (first, first + 1), (first + 2, first + 3) ...
+                    if (kd.nbr2 && kd.nbr2_ok && !no_tbl && jt >= 0 && !(jt & 1))
+                        k_blur2x2t<<<gp, blk, 0, s>>>(kd, src, dst, jt / 2, (kd.D1 - kd.nbr2_first) / 2, c.F, nb);
                     else k_blur2x2<<<gp, blk, 0, s>>>(kd, src, dst, j, c.F, nb);
                     j += 2;
                 } else {

@@ -1,4 +1,4 @@
 #!/bin/bash
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
-FRAMES=8 bash scripts/gpu_c5_env_ab.sh "" "LCCRF_BLUR_UNROLL=2" "LCCRF_BLUR_UNROLL=4"
-FRAMES=16 bash scripts/gpu_c5_env_ab.sh "" "LCCRF_BLUR_UNROLL=2" "LCCRF_BLUR_UNROLL=4"
+timeout 400 python scripts/stress_locality.py 200 2>&1 | tail -3
+bash scripts/gpu_cycle.sh

@@ -778,12 +778,14 @@ def test_sorted_build_falls_back_to_the_hash_when_codes_overflow(po, wl, d, spre
 
 
 @pytest.mark.gpu
-def test_compact_neighbour_table_is_abandoned_when_a_span_does_not_fit(po, wl):
-    """With up to 5 large frames in flight the blur passes read the sorted build's COMPACT neighbour table: 16-bit offsets from a base
-    per 64 vertices.  Ids follow the row-major codes, so a block's neighbours span about a block -- but nothing guarantees it: the
-    build checks every offset and raises a pinned flag, and the engine then reads the 32-bit table.  LCCRF_NBRC_SPAN (INSTRUMENTED
-    library only, child process) lowers the width the check allows to 3 bits, which real lattices exceed at once: same bits as the
-    oracle through the fallback, and through the compact table without the hook."""
+def test_sorted_build_tables_are_checked_and_abandoned_when_they_do_not_hold(po, wl):
+    """Two short cuts of the sorted build rest on the ids following the row-major codes, and the build CHECKS both instead of trusting
+    the argument.  (1) With 3-5 large frames in flight the blur passes read a COMPACT neighbour table: 16-bit offsets from a base per
+    64 vertices -- a block's neighbours span about a block, but nothing guarantees it: every offset is checked, a pinned flag is
+    raised and the engine then reads the 32-bit table.  LCCRF_NBRC_SPAN (INSTRUMENTED library only, child process) lowers the width
+    the check allows to 3 bits, which real lattices exceed at once.  (2) The first blur pass rides in the splat because a vertex's
+    axis-0 neighbours are the adjacent ids; the neighbour search verifies that for every vertex, and LCCRF_FAST0_BREAK (same library)
+    raises its flag: the pass gets its own launch back.  Same bits as the oracle through both fallbacks and without them."""
     instr = os.path.join(ROOT, "lc-crf-slam_amd", "liblccrf_hip_instr.so")
     if not os.path.exists(instr):
         subprocess.run(["make", "-C", os.path.join(ROOT, "lc-crf-slam_amd"), "-j4", "INSTRUMENT=1"], check=True, stdout=subprocess.DEVNULL)
@@ -807,18 +809,20 @@ np.save(sys.argv[1], np.concatenate([b.probability().ravel(), b.map().astype(np.
         o.inference_native(3, True)
         want.append((o.probability().copy(), o.map().copy()))
         o.close()
-    for env, said in (({"LCCRF_NBRC_SPAN": "8"}, True), ({}, False)):
+    for env, said in (({"LCCRF_NBRC_SPAN": "8"}, b"compact neighbour table abandoned"), ({"LCCRF_FAST0_BREAK": "1"}, b"first blur pass keeps its own launch"),
+                      ({}, None)):
         path = os.path.join(ROOT, "gpurun_out", "nbrc_span.npy")
         os.makedirs(os.path.dirname(path), exist_ok=True)
         r = subprocess.run([sys.executable, "-c", code, path], check=True, env=dict(os.environ, LCCRF_LIB=instr, **env), timeout=300,
                            stderr=subprocess.PIPE)
-        assert (b"compact neighbour table abandoned" in r.stderr) == said, r.stderr[-400:]
+        assert (said in r.stderr) if said else (b"lccrf:" not in r.stderr), r.stderr[-400:]
         res = np.load(path)
         Q, M = res[:F * N * 2].reshape(F, N, 2), res[F * N * 2:].reshape(F, N)
         for f, n in enumerate((N, N - 700, N)):
             wq, wm = want[0] if n == N else want[1]
             assert cc.same_bits(Q[f, :n], wq) and np.array_equal(M[f, :n], wm.astype(np.float32)), (env, f)
-    assert b"LCCRF_NBRC_SPAN" not in open(os.path.join(ROOT, "lc-crf-slam_amd", "liblccrf_hip.so"), "rb").read()
+    rel = open(os.path.join(ROOT, "lc-crf-slam_amd", "liblccrf_hip.so"), "rb").read()
+    assert b"LCCRF_NBRC_SPAN" not in rel and b"LCCRF_FAST0_BREAK" not in rel
 
 
 @pytest.mark.gpu
