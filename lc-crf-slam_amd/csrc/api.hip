@@ -191,6 +191,7 @@ struct Engine {
     int opt_vertex_order = 0;          // LCCRF_OPT_VERTEX_ORDER: 0 automatic (= on), 1 on, 2 off -- locality mode's sorted build
     bool vorder_on = false;            // ... as decided by the last build of every kernel
     bool vorder_broken = false;        // a frame's code space overflowed (*sort.vbad): this engine keeps to the hash build
+    int *ndist_host = nullptr;         // pinned [K][kNdistAxes]: the sorted build's largest neighbour distances (KernelDev::ndist)
     int *tbl_bad = nullptr;            // pinned [2]: what the sorted build found wrong with its tables (KernelDev::tbl_bad)
     unsigned *dual_area = nullptr;     // hand-off area of the two-workgroup form of the frame kernel (batches of up to kDualMaxFrames frames)
     unsigned dual_epoch = 0;
@@ -381,6 +382,8 @@ struct Engine {
             }
             k.tbl_bad = tbl_bad;
             if ((rc = mem.alloc(&k.fastn, Fz * E))) return rc;
+            if ((rc = mem.alloc(&k.ndist, (size_t)kNdistAxes))) return rc;
+            if (!ndist_host && (rc = mem.alloc_pinned(&ndist_host, (size_t)LCCRF_MAX_KERNELS * kNdistAxes))) return rc;
         }
         // large frames, a few in flight: the sorted build also leaves the neighbour table in its compact form (16-bit offsets), for
         // the batches of kNbrcMinFrames..kNbrcMaxFrames frames this engine may see
@@ -532,6 +535,8 @@ struct Engine {
                 launch_norm(kdevs[k], crf, kernels[k].maxV, stream);
                 HIP_TRY(hipMemcpyAsync(V_host + (size_t)k * Fcap, kernels[k].dev.V, sizeof(int) * F, hipMemcpyDeviceToHost, stream));
                 HIP_TRY(hipMemcpyAsync(row_host + (size_t)k * Fcap, kernels[k].dev.rowmax, sizeof(int) * F, hipMemcpyDeviceToHost, stream));
+                if (kernels[k].dev.fast0_ok)
+                    HIP_TRY(hipMemcpyAsync(ndist_host + (size_t)k * kNdistAxes, kernels[k].dev.ndist, sizeof(int) * kNdistAxes, hipMemcpyDeviceToHost, stream));
             }
             k += m;
         }
@@ -587,6 +592,27 @@ struct Engine {
             tbl_bad[0] = tbl_bad[1] = 0;
         }
         for (size_t k = 0; k < kernels.size(); ++k) {
+            // how many blur passes ride in the splat (sorted build): pass 0 always (adjacent ids); passes 1 and 2 when the largest id
+            // distances of their neighbours fit the halo of a window of up to 1024 vertices that keeps >= 3/4 of its lanes productive
+            KernelDev &kd = kernels[k].dev;
+            kd.splat_passes = kd.fast0_ok ? 1 : 0;
+            kd.splat_halo = 1;
+            kd.splat_block = 0;
+            static const char *env_sp = getenv("LCCRF_SPLAT_PASSES");               // A/B switch (same results): at most this many
+            const int cap = env_sp ? atoi(env_sp) : 3;
+            if (kd.fast0_ok && cap >= 2) {
+                const int *nd = ndist_host + k * kNdistAxes;
+                int halo = 1;
+                for (int j = 1; j < std::min(kd.D1, std::min(cap, 3)); ++j) {
+                    if (nd[j] < 1 || halo + nd[j] > 1024 / 8) break;
+                    halo += nd[j];
+                    kd.splat_passes = j + 1;
+                    kd.splat_halo = halo;
+                }
+                // single frames pair the passes behind the splat off a two-hop table built for the pairs (1,2), (3,4) ...: 1 or 3 passes
+                if (kd.splat_passes == 2 && kd.nbr2 && kd.D1 > 3) { kd.splat_passes = 1; kd.splat_halo = 1; }
+                if (kd.splat_passes >= 2) kd.splat_block = kd.splat_halo * 8 <= 256 ? 256 : kd.splat_halo * 8 <= 512 ? 512 : 1024;
+            }
             int m = 0, r = 0;
             for (int f = 0; f < F; ++f) {
                 m = std::max(m, V_host[k * Fcap + f]);

@@ -17,6 +17,7 @@ namespace lccrf {
 constexpr int kMaxD = LCCRF_MAX_DIMS;
 constexpr int kEmpty = -1;
 
+constexpr int kNdistAxes = 4;
 constexpr int kNbrcBlock = 64;      // vertices per base of the compact neighbour table (KernelDev::nbrc): one wavefront
 constexpr int kNbrcMinFrames = 3;   // ... which is built and read with 3 to 5 frames in flight (one frame: the passes go two per launch off the
 constexpr int kNbrcMaxFrames = 5;   //   two-hop table; two frames: +-0) (C5, per frame and iteration: 3 / 4 / 5 frames
@@ -69,6 +70,13 @@ struct KernelDev {
     int fast0_ok;         // sorted build: axis 0 is the fastest coordinate of the row-major code, so a vertex's axis-0 neighbours are
                           //   v - 1 and v + 1 or absent, and the first blur pass can ride in the splat (k_splat2<true>) ...
     uint8_t *fastn;       // [F][Epad] or null: ... which reads this instead of the table: 1 = vertex v + 1 is v's axis-0 neighbour
+    // ... and the next axes' neighbours are near ids too (C5: axis 1 within ~10, axis 2 within ~100 ids; rows and planes of the sparse
+    // 6-D lattice hold a few vertices each): the sorted build measures the largest id distance per axis, and when the distances of
+    // axes 1 (and 2) fit a workgroup's halo those passes ride in the splat as well, on an overlapped window in LDS (k_splat2w)
+    int *ndist;           // [kNdistAxes] or null: largest |neighbour id - id| along axes 0 .. kNdistAxes-1 over all frames (device)
+    int splat_passes;     // blur passes the splat takes along for the lattices now in HBM: 0 (none), 1 (k_splat2<true>), 2 or 3 (k_splat2w)
+    int splat_halo;       // ... the halo that takes on each side of a window (1 + distance of axis 1 [+ distance of axis 2])
+    int splat_block;      // ... and the window = lanes per workgroup (256 / 512 / 1024)
     int *rowptr;          // [F][Epad+1]       CSR: vertex -> range of splat contributions
     int *csr_pt;          // [F][Epad]         contributing point, ascending within a row
     float *csr_w;         // [F][Epad]         its barycentric weight

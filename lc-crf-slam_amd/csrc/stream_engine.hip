@@ -807,6 +807,7 @@ __global__ void __launch_bounds__(kBlock) k_eneighbors(KernelDev kd, int F, XcdM
 #pragma unroll
     for (int j = 0; j < D1; ++j) first[j] = vkey[min(v0[j], V - 1)];
     bool next0 = false;
+    int dist[kNdistAxes] = {};           // |neighbour id - id| along the first axes (the splat's window, KernelDev::ndist)
 #pragma unroll
     for (int j = 0; j < D1; ++j) {
         if (!ok[j] || v0[j] >= v1[j]) continue;
@@ -818,11 +819,22 @@ __global__ void __launch_bounds__(kBlock) k_eneighbors(KernelDev kd, int F, XcdM
             next0 = true;
             if (found != v + 1 && kd.tbl_bad) kd.tbl_bad[1] = 1;
         }
+        if (j < kNdistAxes) dist[j] = abs(found - v);
         int *nbp = kd.nbr + ((size_t)f * D1 + j) * kd.Epad * 2;
         nbp[2 * v + 1] = found;          // my n2
         nbp[2 * found] = v;              // its n1
     }
     if (kd.fastn) kd.fastn[(size_t)f * kd.Epad + v] = next0 ? 1 : 0;
+    if (kd.ndist) {
+#pragma unroll
+        for (int j = 1; j < (D1 < kNdistAxes ? D1 : kNdistAxes); ++j) {
+            int m = dist[j];
+#pragma unroll
+            for (int w = 32; w >= 1; w >>= 1) m = max(m, __shfl_xor(m, w, 64));
+            // (a look first: the maximum settles after a few wavefronts, and 70 000 atomics on one address cost 2 ms)
+            if ((threadIdx.x & 63) == 0 && m > __builtin_nontemporal_load(&kd.ndist[j])) atomicMax(&kd.ndist[j], m);
+        }
+    }
 }
 
 // offset[e] = dense id of e's vertex; the first entry of each vertex registers as its
@@ -1183,6 +1195,14 @@ __global__ void __launch_bounds__(kBlock) k_slice_norm(KernelDev kd, CrfDev c, c
 
 // ---- two-label specialisations (the SLAM configuration, L = 2): one thread per vertex / point,
 // both labels in a float2.  Same operations per label as the generic kernels above.
+// (by value: `ok ? lds[i] : zero` selects between two ADDRESSES and parks the zero in scratch memory)
+__device__ __forceinline__ float2 lds_or_zero(bool ok, const float2 *p)
+{
+    float2 r = make_float2(0.0f, 0.0f);                   // what the absent vertex's slot holds
+    if (ok) r = *p;
+    return r;
+}
+
 // BLUR0 (sorted build, KernelDev::fast0_ok): the FIRST blur pass rides along.  Axis 0 is the fastest coordinate of the row-major
 // vertex code, so a vertex's axis-0 neighbours are v - 1 and v + 1 (or absent): the workgroup's row sums go to LDS -- every thread
 // sums one row, the first and the last only for their neighbours' sake (blockDim - 2 results per workgroup) -- and
@@ -1223,9 +1243,76 @@ __global__ void __launch_bounds__(kBlock) k_splat2(KernelDev kd, const float2 *_
     next[threadIdx.x] = nx;
     __syncthreads();
     if (threadIdx.x == 0 || threadIdx.x == blockDim.x - 1 || v >= V) return;
-    const float2 zero = make_float2(0.0f, 0.0f);                                                   // (what the absent vertex's slot holds)
-    const float2 p = next[threadIdx.x - 1] ? tile[threadIdx.x - 1] : zero, q = nx ? tile[threadIdx.x + 1] : zero;    // n1 = v - 1, n2 = v + 1
+    const float2 p = lds_or_zero(next[threadIdx.x - 1], &tile[threadIdx.x - 1]), q = lds_or_zero(nx, &tile[threadIdx.x + 1]);   // n1 = v - 1, n2 = v + 1
     out[v] = make_float2(a0 + 0.5f * (p.x + q.x), a1 + 0.5f * (p.y + q.y));
+}
+
+// ... and the passes along axes 1 (and 2) too, when the sorted build found their neighbours within a few ids (KernelDev::ndist): an
+// OVERLAPPED window.  A workgroup sums the rows of B consecutive vertices into LDS and runs the passes 0 .. P-1 there; a neighbour
+// outside the window reads as zero, which spoils its neighbours' values pass by pass -- by at most `halo` = 1 + dist_1 (+ dist_2)
+// positions from either end, so the inner B - 2 halo results are exactly what P launches of k_blur2 would have stored (the same
+// operations on the same values in the same order) and only those are written.  One launch, one table read per extra pass.
+template <int B>
+__global__ void __launch_bounds__(B) k_splat2w(KernelDev kd, const float2 *__restrict__ in, int in_stride, int F, XcdMap nb, int P, int halo)
+{
+    __shared__ float2 buf[2][B];
+    __shared__ uint8_t next[B];
+    const FrameBlock fb = frame_block(nb);
+    const int f = fb.f;
+    if (f >= F) return;
+    const int V = kd.V[f];
+    const int v0 = fb.bx * (B - 2 * halo) - halo;         // the vertex of thread 0
+    const int v = v0 + (int)threadIdx.x;
+    if (v0 + halo >= V) return;                           // (the whole workgroup)
+    const bool live = v >= 0 && v < V;
+    const size_t fe = (size_t)f * kd.Epad, f1 = (size_t)f * (kd.Epad + 1);
+    const float2 *x = in + (size_t)f * in_stride;
+    const int2 *tab = reinterpret_cast<const int2 *>(kd.nbr) + (size_t)f * kd.D1 * kd.Epad;
+    int2 n1 = make_int2(-1, -1), n2 = make_int2(-1, -1);                                   // axes 1, 2
+    if (live) n1 = tab[kd.Epad + v];
+    if (live && P > 2) n2 = tab[2 * (size_t)kd.Epad + v];
+    float a0 = 0.0f, a1 = 0.0f;
+    uint8_t nx = 0;
+    if (live) {
+        const int s = kd.rowptr[f1 + v], t = kd.rowptr[f1 + v + 1];
+        nx = kd.fastn[fe + v];
+        for (int p = s; p < t; ++p) {
+            const float w = kd.csr_w[fe + p];
+            const float2 q = x[kd.csr_pt[fe + p]];
+            a0 += w * q.x;
+            a1 += w * q.y;
+        }
+    }
+    const int tid = threadIdx.x;
+    buf[0][tid] = make_float2(a0, a1);
+    next[tid] = nx;
+    __syncthreads();
+    {
+        const float2 p = lds_or_zero(tid > 0 && next[tid > 0 ? tid - 1 : 0], &buf[0][tid > 0 ? tid - 1 : 0]);         // n1 = v - 1
+        const float2 q = lds_or_zero(nx && tid + 1 < B, &buf[0][tid + 1 < B ? tid + 1 : tid]);                         // n2 = v + 1
+        a0 = a0 + 0.5f * (p.x + q.x);
+        a1 = a1 + 0.5f * (p.y + q.y);
+    }
+    buf[1][tid] = make_float2(a0, a1);                    // pass 1 (P >= 2)
+    __syncthreads();
+    {
+        const unsigned i1 = (unsigned)(n1.x - v0), i2 = (unsigned)(n1.y - v0);
+        const float2 p = lds_or_zero(n1.x >= 0 && i1 < (unsigned)B, &buf[1][i1 < (unsigned)B ? i1 : 0]);
+        const float2 q = lds_or_zero(n1.y >= 0 && i2 < (unsigned)B, &buf[1][i2 < (unsigned)B ? i2 : 0]);
+        a0 = a0 + 0.5f * (p.x + q.x);
+        a1 = a1 + 0.5f * (p.y + q.y);
+    }
+    if (P > 2) {                                          // pass 2 (buf[0] was last read before the barrier above)
+        buf[0][tid] = make_float2(a0, a1);
+        __syncthreads();
+        const unsigned i1 = (unsigned)(n2.x - v0), i2 = (unsigned)(n2.y - v0);
+        const float2 p = lds_or_zero(n2.x >= 0 && i1 < (unsigned)B, &buf[0][i1 < (unsigned)B ? i1 : 0]);
+        const float2 q = lds_or_zero(n2.y >= 0 && i2 < (unsigned)B, &buf[0][i2 < (unsigned)B ? i2 : 0]);
+        a0 = a0 + 0.5f * (p.x + q.x);
+        a1 = a1 + 0.5f * (p.y + q.y);
+    }
+    if (tid < halo || tid >= B - halo || v >= V) return;
+    reinterpret_cast<float2 *>(kd.val0 + (size_t)f * kd.vstride + kd.vbase)[v] = make_float2(a0, a1);
 }
 
 typedef int lccrf_v4i __attribute__((ext_vector_type(4)));
@@ -1542,6 +1629,7 @@ void build_kernel_d(const KernelDev &kd, const CrfDev &c, hipStream_t s, const S
         k_ebucket_vertices<<<grid_for(nbk, F), kBlock, 0, s>>>(kd, ss);
         XcdMap nb;
         const dim3 g = grid_xcd((long)kd.Epad, F, &nb);
+        if (kd.ndist) (void)hipMemsetAsync(kd.ndist, 0, kNdistAxes * sizeof(int), s);
         k_eneighbors<D><<<g, kBlock, 0, s>>>(kd, F, nb, ss);
         if (kd.nbrc && F >= kNbrcMinFrames && F <= kNbrcMaxFrames) {
             int limit = 0xffff;
@@ -1661,11 +1749,21 @@ void launch_step_stream(const CrfDev &c, const KernelDev *kds, const int *maxV, 
             const bool pairs = pair_fuse(c.F, maxV[k]);
             // sorted build, one pass per launch: the first pass (axis 0 = the code's fastest coordinate) rides in the splat
             static const bool no_sb = getenv("LCCRF_NO_SPLAT_BLUR") != nullptr;               // A/B switch: same results either way
-            const bool blur0 = kd.vorder && kd.fast0_ok && !no_sb;
-            const int j0 = blur0 ? 1 : 0;
-            dim3 g = blur0 ? grid_xcd(((long)maxV[k] + blk - 3) / (blk - 2) * blk, c.F, &nb, blk) : grid_xcd(maxV[k], c.F, &nb, blk);
-            if (blur0) k_splat2<true><<<g, blk, 0, s>>>(kd, reinterpret_cast<const float2 *>(c.Q), c.maxN, c.F, nb);
-            else k_splat2<false><<<g, blk, 0, s>>>(kd, reinterpret_cast<const float2 *>(c.Q), c.maxN, c.F, nb);
+            const int j0 = (kd.vorder && kd.fast0_ok && !no_sb) ? std::max(kd.splat_passes, 1) : 0;   // passes the splat takes along
+            if (j0 >= 2) {
+                const int B = kd.splat_block, core = B - 2 * kd.splat_halo;
+                const dim3 g = grid_xcd(((long)maxV[k] + core - 1) / core * B, c.F, &nb, B);
+                const float2 *q2 = reinterpret_cast<const float2 *>(c.Q);
+                if (B == 256) k_splat2w<256><<<g, B, 0, s>>>(kd, q2, c.maxN, c.F, nb, j0, kd.splat_halo);
+                else if (B == 512) k_splat2w<512><<<g, B, 0, s>>>(kd, q2, c.maxN, c.F, nb, j0, kd.splat_halo);
+                else k_splat2w<1024><<<g, B, 0, s>>>(kd, q2, c.maxN, c.F, nb, j0, kd.splat_halo);
+            } else if (j0 == 1) {
+                const dim3 g = grid_xcd(((long)maxV[k] + blk - 3) / (blk - 2) * blk, c.F, &nb, blk);
+                k_splat2<true><<<g, blk, 0, s>>>(kd, reinterpret_cast<const float2 *>(c.Q), c.maxN, c.F, nb);
+            } else {
+                const dim3 g = grid_xcd(maxV[k], c.F, &nb, blk);
+                k_splat2<false><<<g, blk, 0, s>>>(kd, reinterpret_cast<const float2 *>(c.Q), c.maxN, c.F, nb);
+            }
             const float *src = kd.val0;
             float *dst = kd.val1;
             // the pass left over by the pairs rides in the slice; with a few frames in flight (one pass per launch) the last pass does
@@ -1690,7 +1788,7 @@ void launch_step_stream(const CrfDev &c, const KernelDev *kds, const int *maxV, 
                 dst = const_cast<float *>(t);
             }
             const int first = k == 0, last = k == c.K - 1;
-            g = grid_xcd(c.maxN, c.F, &nb, blk);
+            const dim3 g = grid_xcd(c.maxN, c.F, &nb, blk);
 #define LCCRF_SLICE_CASE(D)                                                                       \
     case D:                                                                                      \
         if (blur_in_slice) k_slice2<D, true><<<g, blk, 0, s>>>(kd, c, src, first, last, relax, nb); \
