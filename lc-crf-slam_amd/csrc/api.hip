@@ -383,6 +383,7 @@ struct Engine {
             k.tbl_bad = tbl_bad;
             if ((rc = mem.alloc(&k.fastn, Fz * E))) return rc;
             if ((rc = mem.alloc(&k.ndist, (size_t)kNdistAxes))) return rc;
+            if ((rc = mem.alloc(&k.nearoff, Fz * 2 * E * 2))) return rc;
             if (!ndist_host && (rc = mem.alloc_pinned(&ndist_host, (size_t)LCCRF_MAX_KERNELS * kNdistAxes))) return rc;
         }
         // large frames, a few in flight: the sorted build also leaves the neighbour table in its compact form (16-bit offsets), for
@@ -604,7 +605,7 @@ struct Engine {
                 const int *nd = ndist_host + k * kNdistAxes;
                 int halo = 1;
                 for (int j = 1; j < std::min(kd.D1, std::min(cap, 3)); ++j) {
-                    if (nd[j] < 1 || halo + nd[j] > 1024 / 8) break;
+                    if (nd[j] < 1 || nd[j] > 127 || halo + nd[j] > 1024 / 8) break;
                     halo += nd[j];
                     kd.splat_passes = j + 1;
                     kd.splat_halo = halo;

@@ -73,10 +73,12 @@ struct KernelDev {
     // ... and the next axes' neighbours are near ids too (C5: axis 1 within ~10, axis 2 within ~100 ids; rows and planes of the sparse
     // 6-D lattice hold a few vertices each): the sorted build measures the largest id distance per axis, and when the distances of
     // axes 1 (and 2) fit a workgroup's halo those passes ride in the splat as well, on an overlapped window in LDS (k_splat2w)
+    int8_t *nearoff;      // [F][2][Epad][2] or null: axes 1 and 2, {n1 - v, n2 - v} as signed bytes, 0 = absent (valid when ndist <= 127:
+                          //   the window passes read 2 instead of 8 table bytes per vertex)
     int *ndist;           // [kNdistAxes] or null: largest |neighbour id - id| along axes 0 .. kNdistAxes-1 over all frames (device)
     int splat_passes;     // blur passes the splat takes along for the lattices now in HBM: 0 (none), 1 (k_splat2<true>), 2 or 3 (k_splat2w)
     int splat_halo;       // ... the halo that takes on each side of a window (1 + distance of axis 1 [+ distance of axis 2])
-    int splat_block;      // ... and the window = lanes per workgroup (256 / 512 / 1024)
+    int splat_block;      // ... and the window (256 / 512 / 1024 vertices: 256 lanes x 1 / 2 / 4)
     int *rowptr;          // [F][Epad+1]       CSR: vertex -> range of splat contributions
     int *csr_pt;          // [F][Epad]         contributing point, ascending within a row
     float *csr_w;         // [F][Epad]         its barycentric weight

@@ -820,6 +820,12 @@ __global__ void __launch_bounds__(kBlock) k_eneighbors(KernelDev kd, int F, XcdM
             if (found != v + 1 && kd.tbl_bad) kd.tbl_bad[1] = 1;
         }
         if (j < kNdistAxes) dist[j] = abs(found - v);
+        if ((j == 1 || j == 2) && kd.nearoff) {          // the window passes' table: signed byte offsets (unused unless all of them fit)
+            const int o = found - v;
+            int8_t *no = kd.nearoff + ((size_t)f * 2 + (j - 1)) * kd.Epad * 2;
+            no[2 * (size_t)v + 1] = (int8_t)(o <= 127 ? o : 0);           // my n2
+            no[2 * (size_t)found] = (int8_t)(o <= 127 ? -o : 0);          // its n1
+        }
         int *nbp = kd.nbr + ((size_t)f * D1 + j) * kd.Epad * 2;
         nbp[2 * v + 1] = found;          // my n2
         nbp[2 * found] = v;              // its n1
@@ -1252,67 +1258,95 @@ __global__ void __launch_bounds__(kBlock) k_splat2(KernelDev kd, const float2 *_
 // outside the window reads as zero, which spoils its neighbours' values pass by pass -- by at most `halo` = 1 + dist_1 (+ dist_2)
 // positions from either end, so the inner B - 2 halo results are exactly what P launches of k_blur2 would have stored (the same
 // operations on the same values in the same order) and only those are written.  One launch, one table read per extra pass.
-template <int B>
-__global__ void __launch_bounds__(B) k_splat2w(KernelDev kd, const float2 *__restrict__ in, int in_stride, int F, XcdMap nb, int P, int halo)
+template <int LANES, int U>
+__global__ void __launch_bounds__(LANES) k_splat2w(KernelDev kd, const float2 *__restrict__ in, int in_stride, int F, XcdMap nb, int P, int halo)
 {
+    constexpr int B = LANES * U;                          // the window: U vertices per lane, at stride LANES (coalesced)
     __shared__ float2 buf[2][B];
     __shared__ uint8_t next[B];
     const FrameBlock fb = frame_block(nb);
     const int f = fb.f;
     if (f >= F) return;
     const int V = kd.V[f];
-    const int v0 = fb.bx * (B - 2 * halo) - halo;         // the vertex of thread 0
-    const int v = v0 + (int)threadIdx.x;
+    const int v0 = fb.bx * (B - 2 * halo) - halo;         // the window's first vertex
     if (v0 + halo >= V) return;                           // (the whole workgroup)
-    const bool live = v >= 0 && v < V;
     const size_t fe = (size_t)f * kd.Epad, f1 = (size_t)f * (kd.Epad + 1);
     const float2 *x = in + (size_t)f * in_stride;
-    const int2 *tab = reinterpret_cast<const int2 *>(kd.nbr) + (size_t)f * kd.D1 * kd.Epad;
-    int2 n1 = make_int2(-1, -1), n2 = make_int2(-1, -1);                                   // axes 1, 2
-    if (live) n1 = tab[kd.Epad + v];
-    if (live && P > 2) n2 = tab[2 * (size_t)kd.Epad + v];
-    float a0 = 0.0f, a1 = 0.0f;
-    uint8_t nx = 0;
-    if (live) {
-        const int s = kd.rowptr[f1 + v], t = kd.rowptr[f1 + v + 1];
-        nx = kd.fastn[fe + v];
-        for (int p = s; p < t; ++p) {
-            const float w = kd.csr_w[fe + p];
-            const float2 q = x[kd.csr_pt[fe + p]];
-            a0 += w * q.x;
-            a1 += w * q.y;
+    const char2 *off1 = reinterpret_cast<const char2 *>(kd.nearoff) + (size_t)f * 2 * kd.Epad, *off2 = off1 + kd.Epad;   // axes 1, 2
+    const int tid = threadIdx.x;
+    float a0[U], a1[U];
+    char2 o1[U], o2[U];
+    uint8_t nx[U];
+    int s[U], t[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int v = v0 + tid + u * LANES;
+        const bool live = v >= 0 && v < V;
+        s[u] = t[u] = 0;
+        nx[u] = 0;
+        o1[u] = o2[u] = make_char2(0, 0);
+        if (live) {
+            s[u] = kd.rowptr[f1 + v];
+            t[u] = kd.rowptr[f1 + v + 1];
+            nx[u] = kd.fastn[fe + v];
+            o1[u] = off1[v];
+            if (P > 2) o2[u] = off2[v];
         }
     }
-    const int tid = threadIdx.x;
-    buf[0][tid] = make_float2(a0, a1);
-    next[tid] = nx;
-    __syncthreads();
-    {
-        const float2 p = lds_or_zero(tid > 0 && next[tid > 0 ? tid - 1 : 0], &buf[0][tid > 0 ? tid - 1 : 0]);         // n1 = v - 1
-        const float2 q = lds_or_zero(nx && tid + 1 < B, &buf[0][tid + 1 < B ? tid + 1 : tid]);                         // n2 = v + 1
-        a0 = a0 + 0.5f * (p.x + q.x);
-        a1 = a1 + 0.5f * (p.y + q.y);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        float b0 = 0.0f, b1 = 0.0f;
+        for (int p = s[u]; p < t[u]; ++p) {
+            const float w = kd.csr_w[fe + p];
+            const float2 q = x[kd.csr_pt[fe + p]];
+            b0 += w * q.x;
+            b1 += w * q.y;
+        }
+        a0[u] = b0;
+        a1[u] = b1;
+        buf[0][tid + u * LANES] = make_float2(b0, b1);
+        next[tid + u * LANES] = nx[u];
     }
-    buf[1][tid] = make_float2(a0, a1);                    // pass 1 (P >= 2)
     __syncthreads();
-    {
-        const unsigned i1 = (unsigned)(n1.x - v0), i2 = (unsigned)(n1.y - v0);
-        const float2 p = lds_or_zero(n1.x >= 0 && i1 < (unsigned)B, &buf[1][i1 < (unsigned)B ? i1 : 0]);
-        const float2 q = lds_or_zero(n1.y >= 0 && i2 < (unsigned)B, &buf[1][i2 < (unsigned)B ? i2 : 0]);
-        a0 = a0 + 0.5f * (p.x + q.x);
-        a1 = a1 + 0.5f * (p.y + q.y);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {                         // pass 0: n1 = v - 1, n2 = v + 1
+        const int i = tid + u * LANES;
+        const float2 p = lds_or_zero(i > 0 && next[i > 0 ? i - 1 : 0], &buf[0][i > 0 ? i - 1 : 0]);
+        const float2 q = lds_or_zero(nx[u] && i + 1 < B, &buf[0][i + 1 < B ? i + 1 : i]);
+        a0[u] = a0[u] + 0.5f * (p.x + q.x);
+        a1[u] = a1[u] + 0.5f * (p.y + q.y);
+        buf[1][i] = make_float2(a0[u], a1[u]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < U; ++u) {                         // pass 1 (P >= 2)
+        const int i = tid + u * LANES;
+        const unsigned i1 = (unsigned)(i + o1[u].x), i2 = (unsigned)(i + o1[u].y);
+        const float2 p = lds_or_zero(o1[u].x != 0 && i1 < (unsigned)B, &buf[1][i1 < (unsigned)B ? i1 : 0]);
+        const float2 q = lds_or_zero(o1[u].y != 0 && i2 < (unsigned)B, &buf[1][i2 < (unsigned)B ? i2 : 0]);
+        a0[u] = a0[u] + 0.5f * (p.x + q.x);
+        a1[u] = a1[u] + 0.5f * (p.y + q.y);
     }
     if (P > 2) {                                          // pass 2 (buf[0] was last read before the barrier above)
-        buf[0][tid] = make_float2(a0, a1);
+#pragma unroll
+        for (int u = 0; u < U; ++u) buf[0][tid + u * LANES] = make_float2(a0[u], a1[u]);
         __syncthreads();
-        const unsigned i1 = (unsigned)(n2.x - v0), i2 = (unsigned)(n2.y - v0);
-        const float2 p = lds_or_zero(n2.x >= 0 && i1 < (unsigned)B, &buf[0][i1 < (unsigned)B ? i1 : 0]);
-        const float2 q = lds_or_zero(n2.y >= 0 && i2 < (unsigned)B, &buf[0][i2 < (unsigned)B ? i2 : 0]);
-        a0 = a0 + 0.5f * (p.x + q.x);
-        a1 = a1 + 0.5f * (p.y + q.y);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = tid + u * LANES;
+            const unsigned i1 = (unsigned)(i + o2[u].x), i2 = (unsigned)(i + o2[u].y);
+            const float2 p = lds_or_zero(o2[u].x != 0 && i1 < (unsigned)B, &buf[0][i1 < (unsigned)B ? i1 : 0]);
+            const float2 q = lds_or_zero(o2[u].y != 0 && i2 < (unsigned)B, &buf[0][i2 < (unsigned)B ? i2 : 0]);
+            a0[u] = a0[u] + 0.5f * (p.x + q.x);
+            a1[u] = a1[u] + 0.5f * (p.y + q.y);
+        }
     }
-    if (tid < halo || tid >= B - halo || v >= V) return;
-    reinterpret_cast<float2 *>(kd.val0 + (size_t)f * kd.vstride + kd.vbase)[v] = make_float2(a0, a1);
+    float2 *out = reinterpret_cast<float2 *>(kd.val0 + (size_t)f * kd.vstride + kd.vbase);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int i = tid + u * LANES, v = v0 + i;
+        if (i >= halo && i < B - halo && v < V) out[v] = make_float2(a0[u], a1[u]);
+    }
 }
 
 typedef int lccrf_v4i __attribute__((ext_vector_type(4)));
@@ -1630,6 +1664,7 @@ void build_kernel_d(const KernelDev &kd, const CrfDev &c, hipStream_t s, const S
         XcdMap nb;
         const dim3 g = grid_xcd((long)kd.Epad, F, &nb);
         if (kd.ndist) (void)hipMemsetAsync(kd.ndist, 0, kNdistAxes * sizeof(int), s);
+        if (kd.nearoff) (void)hipMemsetAsync(kd.nearoff, 0, (size_t)F * 2 * kd.Epad * 2, s);
         k_eneighbors<D><<<g, kBlock, 0, s>>>(kd, F, nb, ss);
         if (kd.nbrc && F >= kNbrcMinFrames && F <= kNbrcMaxFrames) {
             int limit = 0xffff;
@@ -1752,11 +1787,18 @@ void launch_step_stream(const CrfDev &c, const KernelDev *kds, const int *maxV, 
             const int j0 = (kd.vorder && kd.fast0_ok && !no_sb) ? std::max(kd.splat_passes, 1) : 0;   // passes the splat takes along
             if (j0 >= 2) {
                 const int B = kd.splat_block, core = B - 2 * kd.splat_halo;
-                const dim3 g = grid_xcd(((long)maxV[k] + core - 1) / core * B, c.F, &nb, B);
                 const float2 *q2 = reinterpret_cast<const float2 *>(c.Q);
-                if (B == 256) k_splat2w<256><<<g, B, 0, s>>>(kd, q2, c.maxN, c.F, nb, j0, kd.splat_halo);
-                else if (B == 512) k_splat2w<512><<<g, B, 0, s>>>(kd, q2, c.maxN, c.F, nb, j0, kd.splat_halo);
-                else k_splat2w<1024><<<g, B, 0, s>>>(kd, q2, c.maxN, c.F, nb, j0, kd.splat_halo);
+                // many frames in flight: 256 lanes x 1 / 2 / 4 vertices (C5 x 8, window 1024: 20.6 -> 18.9 us per frame-iteration against
+                // 1024 lanes x 1: workgroups of four wavefronts wait less at the barriers); one or two frames: a lane per vertex (a
+                // lane's four row walks in a row cost a single frame 33.3 -> 36.1)
+                const bool wide = c.F <= 2;
+                const int lanes = wide ? B : kBlock;
+                const dim3 g = grid_xcd(((long)maxV[k] + core - 1) / core * lanes, c.F, &nb, lanes);
+                if (B == 256) k_splat2w<256, 1><<<g, 256, 0, s>>>(kd, q2, c.maxN, c.F, nb, j0, kd.splat_halo);
+                else if (B == 512 && wide) k_splat2w<512, 1><<<g, 512, 0, s>>>(kd, q2, c.maxN, c.F, nb, j0, kd.splat_halo);
+                else if (B == 512) k_splat2w<256, 2><<<g, 256, 0, s>>>(kd, q2, c.maxN, c.F, nb, j0, kd.splat_halo);
+                else if (wide) k_splat2w<1024, 1><<<g, 1024, 0, s>>>(kd, q2, c.maxN, c.F, nb, j0, kd.splat_halo);
+                else k_splat2w<256, 4><<<g, 256, 0, s>>>(kd, q2, c.maxN, c.F, nb, j0, kd.splat_halo);
             } else if (j0 == 1) {
                 const dim3 g = grid_xcd(((long)maxV[k] + blk - 3) / (blk - 2) * blk, c.F, &nb, blk);
                 k_splat2<true><<<g, blk, 0, s>>>(kd, reinterpret_cast<const float2 *>(c.Q), c.maxN, c.F, nb);
