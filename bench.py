@@ -471,8 +471,11 @@ def c5_record(pkg, wl, torch, dev, steps=6, frames=8):
                "roofline_whole_iteration": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                             "frac": achieved / HBM_PEAK_GBS, "algorithmic_bytes_per_iteration": bytes_iter,
                                             "inference_ms": inf_ms,
-                                            "note": "algorithmic bytes (SURVEY 8d) x frames / HIP-event time of the 20-iteration "
-                                                    "inference (9 launches per iteration: splat, 7 blur passes, slice + softmax)"}}
+                                            "note": "algorithmic bytes (SURVEY 8d: splat, 7 blur passes of 24 B per vertex, slice + softmax) x frames / "
+                                                    "HIP-event time of the 20-iteration inference.  With the sorted build the first three passes "
+                                                    "ride in the splat's LDS window and move no bytes of their own (6 launches per iteration with "
+                                                    "many frames in flight, 4 with one): the engine moves less than the algorithmic bytes -- "
+                                                    "`traffic` (PMC, per frame and iteration) says how much"}}
         if hash_build:
             # what the sorted build of locality mode (default with 8 or more frames in flight) changes: the same frames on the hash build
             blur_ms, nv = b.time_blur_pass(0, 40)
@@ -510,18 +513,18 @@ def c5_record(pkg, wl, torch, dev, steps=6, frames=8):
             fc, lm, dq = check_distinct_frames(pbs[:min(F, len(pbs))], idx, M, Q, n_iter)
             rec["label_match_vs_cpu_reference"], rec["max_abs_dQ_vs_cpu_reference"] = lm, dq
             rec["frames_checked"], rec["tiles_identical"] = fc, tiles_identical(torch, b, dev, F, N, idx)
+            tr = iteration_traffic(tag) if F == 8 else None
+            if tr:                                      # (per frame, like the algorithmic bytes)
+                tr["traffic"] /= F
+                rec["roofline_whole_iteration"].update(tr, traffic_over_algorithmic=tr["traffic"] / bytes_iter)
             out.update(rec)
         else:
             M, Q = b.map(), b.probability()
             fc, lm, dq = check_distinct_frames(pbs[:1], idx, M, Q, n_iter)
             rec["label_match_vs_cpu_reference"], rec["max_abs_dQ_vs_cpu_reference"], rec["frames_checked"] = lm, dq, fc
-            ptag = latest_profile("stream_c5_f1")
-            if ptag:                                    # per iteration: 3 two-pass launches + the slice (with the 7th pass) + the splat
-                per_it = [pmc_traffic(ptag, k) for k in ("k_blur2x2t", "k_slice2", "k_splat2")]
-                if all(per_it):
-                    tr = 3 * per_it[0] + per_it[1] + per_it[2]
-                    rec["roofline_whole_iteration"].update({"traffic": tr, "traffic_over_algorithmic": tr / bytes_iter,
-                                                            "profile": "profiles/%s (kernel_stats.csv, pmc_summary.csv: FETCH x2 + WRITE per launch)" % ptag})
+            tr = iteration_traffic(latest_profile("stream_c5_f1"))
+            if tr:
+                rec["roofline_whole_iteration"].update(tr, traffic_over_algorithmic=tr["traffic"] / bytes_iter)
             out["single_frame"] = rec
         b.close()
         del f, lab, npt
@@ -539,6 +542,33 @@ def latest_profile(suffix):
         if m and os.path.exists(os.path.join(pdir, d, "pmc_summary.csv")) and (best is None or int(m.group(1)) > best[0]):
             best = (int(m.group(1)), d)
     return best[1] if best else None
+
+
+def iteration_traffic(tag):
+    """HBM bytes ONE mean-field iteration of the streaming engine moves, from a committed profile of this command line: per kernel of
+    the iteration (splat, blur passes, slice) the PMC bytes per launch (pmc_summary.csv) x its launches per iteration (kernel_stats.csv:
+    calls relative to the slice's, which runs once per iteration).  None unless the profile is there."""
+    import csv
+    d = os.path.join(ROOT, "profiles", tag or "")
+    if not tag or not os.path.exists(os.path.join(d, "kernel_stats.csv")) or not os.path.exists(os.path.join(d, "pmc_summary.csv")):
+        return None
+    calls = {}
+    for r in csv.DictReader(open(os.path.join(d, "kernel_stats.csv"))):
+        calls[r["Name"]] = calls.get(r["Name"], 0) + int(r["Calls"])
+    per_iter = max([c for n, c in calls.items() if "k_slice2" in n] or [0])
+    if not per_iter:
+        return None
+    total, parts = 0.0, {}
+    for r in csv.DictReader(open(os.path.join(d, "pmc_summary.csv"))):
+        short = next((k for k in ("k_splat2", "k_blur2", "k_slice2") if k in r["kernel"]), None)
+        n = calls.get(r["kernel"], 0)                   # (both files carry rocprofv3's full kernel name)
+        if short and n:
+            b = float(r["bytes_corrected"]) * n / per_iter
+            total += b
+            nm = r["kernel"][r["kernel"].index(short):].split("(")[0]
+            parts[nm] = {"launches_per_iteration": n / per_iter, "bytes": parts.get(nm, {}).get("bytes", 0.0) + b}
+    return {"traffic": total, "traffic_by_kernel": parts,
+            "profile": "profiles/%s (kernel_stats.csv, pmc_summary.csv: FETCH x2 + WRITE per launch)" % tag} if total else None
 
 
 def pmc_traffic(tag, kernel="k_fused", corrected=True):

@@ -1,4 +1,12 @@
 #!/bin/bash
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
-timeout 900 python -m pytest tests/test_hip_parity.py -x -q -m gpu 2>&1 | tail -3
-for F in 1 2 3 8; do FRAMES=$F bash scripts/gpu_c5_env_ab.sh "" "LCCRF_SPLAT_PASSES=1" | sed "s/^/F=$F /"; done
+mkdir -p gpurun_out/nbrc
+for F in 8 1; do
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/nbrc -o q$F -- python3 bench.py --workload c5 --frames $F --steps 5 --warmup 2 --no-cpu-baseline --no-extras > /dev/null 2>&1
+python3 - <<PY
+import csv,glob
+for p in glob.glob("gpurun_out/nbrc/**/q${F}_kernel_stats.csv", recursive=True):
+    rows=list(csv.DictReader(open(p)))
+    for r in rows[:12]: print("%-60s calls %6s avg_us %9.2f pct %5s" % (r["Name"][:60], r["Calls"], float(r["AverageNs"])/1e3, r["Percentage"]))
+PY
+done
