@@ -823,8 +823,9 @@ __global__ void __launch_bounds__(kBlock) k_eneighbors(KernelDev kd, int F, XcdM
         if ((j == 1 || j == 2) && kd.nearoff) {          // the window passes' table: signed byte offsets (unused unless all of them fit)
             const int o = found - v;
             int8_t *no = kd.nearoff + ((size_t)f * 2 + (j - 1)) * kd.Epad * 2;
-            no[2 * (size_t)v + 1] = (int8_t)(o <= 127 ? o : 0);           // my n2
-            no[2 * (size_t)found] = (int8_t)(o <= 127 ? -o : 0);          // its n1
+            const bool fits = o >= -127 && o <= 127;     // (the main diagonal, axis d, steps DOWN the codes: o < 0)
+            no[2 * (size_t)v + 1] = (int8_t)(fits ? o : 0);               // my n2
+            no[2 * (size_t)found] = (int8_t)(fits ? -o : 0);              // its n1
         }
         int *nbp = kd.nbr + ((size_t)f * D1 + j) * kd.Epad * 2;
         nbp[2 * v + 1] = found;          // my n2
@@ -1810,7 +1811,7 @@ void launch_step_stream(const CrfDev &c, const KernelDev *kds, const int *maxV, 
             float *dst = kd.val1;
             // the pass left over by the pairs rides in the slice; with a few frames in flight (one pass per launch) the last pass does
             static const char *sf = getenv("LCCRF_SLICE_BLUR_MAX");                          // (A/B: frames-in-flight threshold)
-            const bool blur_in_slice = kd.D1 <= 9 && (pairs ? ((kd.D1 - j0) & 1) && kd.D1 >= 3 : c.F <= (sf ? atoi(sf) : kSliceBlurMaxFrames));
+            const bool blur_in_slice = kd.D1 <= 9 && j0 < kd.D1 && (pairs ? ((kd.D1 - j0) & 1) && kd.D1 >= 3 : c.F <= (sf ? atoi(sf) : kSliceBlurMaxFrames));   // (j0 == d + 1: a 2-D lattice's three passes can all ride in the splat)
             const int n_own = blur_in_slice ? kd.D1 - 1 : kd.D1;                           // blur passes with a launch of their own
             for (int j = j0; j < n_own;) {
                 if (pairs && j + 1 < n_own) {             // one frame in flight: two passes per launch

@@ -778,6 +778,49 @@ def test_sorted_build_falls_back_to_the_hash_when_codes_overflow(po, wl, d, spre
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("env", [{"LCCRF_SPLAT_PASSES": "1"}, {"LCCRF_SPLAT_PASSES": "2"}, {"LCCRF_NO_SPLAT_BLUR": "1"}, {"LCCRF_NO_XCD_CHUNK": "1"},
+                                 {"LCCRF_NO_COMPACT_NBR": "1"}, {"LCCRF_NO_PAIR_FUSE": "1"}])
+def test_streaming_engine_switches_do_not_change_a_bit(po, wl, env):
+    """The sorted build lets the splat take the first blur passes along (axis 0: adjacent ids; axes 1 and 2: ids within the halo of an
+    LDS window), reads a compact neighbour table with 3-5 frames in flight, pairs the passes of a single frame ...: every one of
+    these is a choice of HOW, read once per process from the environment for A/B runs.  A child process per switch: one, three
+    and eight frames of a 6-D and of a (3-D, 2-D) problem in locality mode -- the same bits as this process's default path and
+    as the oracle."""
+    code = r"""
+import importlib, sys, numpy as np
+sys.path.insert(0, %r)
+pkg = importlib.import_module("lc-crf-slam_amd"); wl = importlib.import_module("lc-crf-slam_amd.workloads")
+def run():
+    out = []
+    for dims, N in (([6], 9000), ([3, 2], 8400)):
+        pb = wl.generic_problem(N, dims, 2, seed=41 + len(dims), spread=2.5)
+        for F in (1, 3, 8):
+            b = pkg.BatchCRF(F, N, 2, dims, [float(w) for _, w in pb["kernels"]])
+            b.set_inputs_host([N - 37 * f for f in range(F)], [np.repeat(f[None], F, 0) for f, _ in pb["kernels"]], unary=np.repeat(pb["unary"][None], F, 0))
+            b.build(); b.inference(3, True)
+            out += [b.probability().ravel(), b.map().astype(np.float32).ravel()]
+            b.close()
+    return np.concatenate(out)
+if __name__ == "__main__":
+    np.save(sys.argv[1], run())
+""" % ROOT
+    path = os.path.join(ROOT, "gpurun_out", "switch_%s.npy" % "_".join(env))
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    subprocess.run([sys.executable, "-c", code, path], check=True, env=dict(os.environ, **env), timeout=600)
+    got = np.load(path)
+    ns = {}
+    exec(compile(code.replace('if __name__ == "__main__":', "if False:"), "<switch>", "exec"), ns)
+    want = ns["run"]()
+    assert cc.same_bits(got, want), env
+    # ... and the default path against the oracle on the first problem's single frame
+    pb = wl.generic_problem(9000, [6], 2, seed=42, spread=2.5)
+    o = cc.setup(po.OracleCRF, pb)
+    o.inference_native(3, True)
+    assert cc.same_bits(want[:9000 * 2].reshape(9000, 2), o.probability())
+    o.close()
+
+
+@pytest.mark.gpu
 def test_sorted_build_tables_are_checked_and_abandoned_when_they_do_not_hold(po, wl):
     """Two short cuts of the sorted build rest on the ids following the row-major codes, and the build CHECKS both instead of trusting
     the argument.  (1) With 3-5 large frames in flight the blur passes read a COMPACT neighbour table: 16-bit offsets from a base per
