@@ -426,6 +426,47 @@ def slam_subrecord(pkg, wl, torch, dev, name, steps=10, warmup=3, distinct=32):
     return rec
 
 
+def c5_object_api(pkg, pb, n_iter, reps=5):
+    """BASELINE config 5 through the reference's OWN interface (include/lccrf_densecrf.hpp / DenseCRFHIP): host arrays in, labels
+    out -- constructor, setUnaryEnergyFromLabel, addPairwiseEnergy (the lattice + normalisation), inference(20), map() -- the
+    call sequence of src/Tracking.cc:1911-1923 on a 100 000-point frame, host to host; and the inference alone (a second call on
+    the resident lattices).  Handles of >= 8192 points run inference() in locality mode (sorted build, blur passes in the splat)."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pyoracle as po
+    whole, inf = [], []
+    M = None
+    for _ in range(reps + 1):
+        t0 = time.perf_counter()
+        h = pkg.DenseCRFHIP(pb["N"], pb["L"])
+        h.set_unary_from_label(pb["label"], pb["conf"])
+        for f, w in pb["kernels"]:
+            h.add_pairwise(f, w)
+        h.inference(n_iter, True)
+        M = h.map()
+        whole.append(time.perf_counter() - t0)
+        t0 = time.perf_counter()
+        h.inference(n_iter, True)
+        M2 = h.map()
+        inf.append(time.perf_counter() - t0)
+        h.close()
+    o = po.OracleCRF(pb["N"], pb["L"])
+    o.set_unary_from_label(pb["label"], pb["conf"])
+    for f, w in pb["kernels"]:
+        o.add_pairwise(f, w)
+    t0 = time.perf_counter()
+    o.inference_native(n_iter, True)
+    cpu_inf = time.perf_counter() - t0
+    match = float((M == o.map()).mean()) * float((M2 == o.map()).mean())
+    o.close()
+    w, i = float(np.median(whole[1:])), float(np.median(inf[1:]))
+    return {"frame_ms_host_to_host": w * 1e3, "inference_ms_host_to_host": i * 1e3, "us_per_iteration": i * 1e6 / n_iter,
+            "cpu_reference_inference_ms": cpu_inf * 1e3, "label_match_vs_cpu_reference": match,
+            "note": "DenseCRF object API, one 100 000-point frame, host arrays in / labels out: whole frame (constructors + lattice + "
+                    "%d iterations + map) and the inference alone on the resident lattices; the CPU figure is the reference's inference "
+                    "on one core of this box" % n_iter}
+
+
 def c5_record(pkg, wl, torch, dev, steps=6, frames=8):
     """Config C5 (100 000 points, one 6-D kernel, V ~ 5.9e5, 20 iterations): the configuration whose working set lives in
     HBM, i.e. the one where the 8 TB/s roof is the applicable one.  `frames` frames in flight (distinct buffers: ~340 MB
@@ -525,6 +566,7 @@ def c5_record(pkg, wl, torch, dev, steps=6, frames=8):
             tr = iteration_traffic(latest_profile("stream_c5_f1"))
             if tr:
                 rec["roofline_whole_iteration"].update(tr, traffic_over_algorithmic=tr["traffic"] / bytes_iter)
+            rec["object_api"] = c5_object_api(pkg, pbs[0], n_iter)
             out["single_frame"] = rec
         b.close()
         del f, lab, npt

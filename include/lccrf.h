@@ -117,7 +117,13 @@ int  lccrf_start_inference(lccrf_handle h);
 int  lccrf_step_inference(lccrf_handle h, float relax);
 /* DenseCRF3D<M>::buildMap()                     densecrf3d.h:136-151                  */
 int  lccrf_build_map(lccrf_handle h);
-/* DenseCRF::inference(n_iterations, with_map, relax)   densecrf_base.h:65-73          */
+/* DenseCRF::inference(n_iterations, with_map, relax)   densecrf_base.h:65-73
+ * Frames of >= 8192 points (far beyond a SLAM frame: BASELINE config 5) run it in the streaming engine's LOCALITY MODE -- the points
+ * in an internal order, the lattice built by sorting, the first blur passes inside the splat -- when the
+ * lattices are first needed by this call.  Results are the same bits in the caller's order.  The entry points that expose or
+ * continue from per-point lattice state (lccrf_start_inference / lccrf_step_inference, lccrf_pairwise_apply, lccrf_step_init,
+ * lccrf_get_norm / _lattice / _unary) work on the plain build: used first, the handle is built that way and stays so; used after an
+ * inference() in locality mode, the lattices are re-built once (same results, one extra build).                       */
 int  lccrf_inference(lccrf_handle h, int n_iterations, int with_map, float relax);
 
 /* DenseCRF::getMap() / getProbability()         densecrf_base.h:74-75

@@ -214,7 +214,10 @@ struct Engine {
     // with the points in an internal Z-order of their lattice cells (stream_engine.hip: launch_sort_points); Q, next and
     // the unaries of the iteration live in that order (Qp, unary_p / unary_own) and Q is un-permuted on the way out.
     static constexpr int kPermMinPoints = 8192;
-    bool allow_perm = false;           // set by lccrf_batch_create
+    bool allow_perm = false;           // set by lccrf_batch_create, and by lccrf_create for handles of >= kPermMinPoints points ...
+    bool perm_scoped = false;          // ... where it only applies to lattices that are first asked for by inference() (perm_scope): every
+    bool perm_scope = false;           //   other entry point of the object API (stepwise inference, PairwisePotential::apply, the lattice
+    bool perm_banned = false;          //   probes) works on the caller's point order -- such a handle is built, or re-built once, the plain way
     bool perm_on = false;              // the lattices now in HBM were built in locality mode
     bool unary_is_label = false;       // the unaries come from labels (re-derivable in any order) rather than from a raw array
     bool unary_p_valid = false;        // unary_p holds the raw unaries in the current internal order
@@ -451,6 +454,8 @@ struct Engine {
         unary_set = built = sizes_known = started = false;
         late_pending = false;
         unary_deferred = false;
+        perm_on = vorder_on = perm_banned = perm_scope = false;      // (the next user's lattices decide afresh)
+        unary_is_label = unary_p_valid = false;
         built_upto = 0;
         engine_pref = 0;
         engine_used = 1;
@@ -488,7 +493,7 @@ struct Engine {
         if (k0 == 0) {                                     // a build of every kernel decides the internal point order afresh
             static const bool no_perm = getenv("LCCRF_NO_PERM") != nullptr;   // A/B and cross-check switch: same results either way
             const int NAp = activeN > 0 ? activeN : maxN;
-            const bool want = allow_perm && !no_perm && n > 0 && n == (int)kernels.size() && NAp >= kPermMinPoints;
+            const bool want = allow_perm && !no_perm && !perm_banned && (!perm_scoped || perm_scope) && n > 0 && n == (int)kernels.size() && NAp >= kPermMinPoints;
             if (want || perm_on) {                         // whatever was derived in the old order is stale
                 if (unary_is_label) unary_deferred = true;
                 unary_p_valid = false;
@@ -665,6 +670,7 @@ struct Engine {
     {
         if (!unary_set) return fail(LCCRF_E_STATE, "unary energies not set");
         { int rl = resolve_late(); if (rl) return rl; }
+        { int rp = ensure_plain(); if (rp) return rp; }   // (object API after a locality-mode inference(): label-derived energies sit in that order)
         { int ru = ensure_unary(); if (ru) return ru; }
         launch_start(crf, stream);
         started = true;
@@ -676,8 +682,10 @@ struct Engine {
         if (!started) return fail(LCCRF_E_STATE, "stepInference before startInference");
         int rc = resolve_late();
         if (rc) return rc;
+        if ((rc = ensure_plain())) return rc;
         rc = learn_sizes();
         if (rc) return rc;
+        if ((rc = ensure_unary())) return rc;             // (label-derived energies follow the lattices' point order: re-derived after a re-build)
         launch_step_stream(crf, kdevs.data(), maxV.data(), relax, stream);
         return LCCRF_OK;
     }
@@ -735,7 +743,22 @@ struct Engine {
         // Object API: nothing has been built yet (add_pairwise only stages features) -> do not build, run the
         // frame in one launch.  If a probe already forced the lattices into HBM, iterate on those instead.
         if (late_ok && frame_ok() && !(built_upto == (int)kernels.size() && sizes_known)) return run_frame(n_iter, with_map, relax);
-        return inference_sized(n_iter, with_map, relax);
+        perm_scope = true;                                // (large frames: lattices built from here may use locality mode)
+        rc = inference_sized(n_iter, with_map, relax);
+        perm_scope = false;
+        return rc;
+    }
+
+    // Object API, large frames: DenseCRF::inference() runs in locality mode (internal point order, sorted build); the entry points
+    // that expose or continue from per-point lattice state in the CALLER's order -- stepInference, PairwisePotential::apply, the
+    // lattice / norm / unary probes -- get the plain build instead: built that way if they come first, re-built once if not.
+    int ensure_plain()
+    {
+        if (!perm_on || !perm_scoped) return LCCRF_OK;
+        perm_banned = true;
+        built_upto = 0;
+        sizes_known = false;
+        return flush_builds();
     }
 
     // lccrf_batch_run: per frame the PottsPotential ctors + inference(n, with_map)
@@ -1017,6 +1040,8 @@ int lccrf_create(lccrf_handle *out, int device_id, int n_points, int n_labels)
         if (!h) return fail(LCCRF_E_NOMEM, "host allocation failed");
         h->cap = capacity_for(n_points);
         rc = h->eng.init(device_id, 1, h->cap, n_labels);
+        // frames far beyond SLAM's (BASELINE config 5 through the reference's own interface): inference() in locality mode
+        h->eng.allow_perm = h->eng.perm_scoped = h->cap >= Engine::kPermMinPoints;
         if (!rc) rc = h->eng.mem.alloc_pinned(&h->stage_i16, h->cap);
         if (!rc) rc = h->eng.mem.alloc_pinned(&h->stage_f32, (size_t)h->cap * n_labels);
         if (!rc) rc = h->eng.mem.alloc_pinned(&h->stage_n, 1);
@@ -1136,6 +1161,7 @@ int lccrf_set_unary(lccrf_handle h, const float *unary)
     e.crf.unary = e.unary_own;
     e.unary_deferred = false;
     e.unary_is_label = false;
+    e.unary_p_valid = false;
     e.unary_set = true;
     return LCCRF_OK;
 }
@@ -1238,6 +1264,7 @@ int lccrf_pairwise_apply(lccrf_handle h, int kernel, float *out_values, const fl
     if ((!out_values || !in_values) && h->N) return fail(LCCRF_E_INVALID, "out_values / in_values is NULL");
     Engine &e = h->eng;
     int rc = e.resolve_late();
+    if (!rc) rc = e.ensure_plain();
     if (!rc) rc = e.learn_sizes();                        // builds the lattice if it only exists as staged features
     if (!rc) rc = e.need_io();
     if (rc) return rc;
@@ -1280,6 +1307,7 @@ int lccrf_step_init(lccrf_handle h, float *next_out)
     Engine &e = h->eng;
     if (!e.unary_set) return fail(LCCRF_E_STATE, "unary energies not set");
     int rc = e.resolve_late();
+    if (!rc) rc = e.ensure_plain();
     if (!rc) rc = e.ensure_unary();
     if (!rc) rc = e.need_io();
     if (rc) return rc;
@@ -1401,6 +1429,7 @@ int lccrf_get_unary(lccrf_handle h, float *unary_out)
     CHECK_H(h);
     if (!unary_out && h->N) return fail(LCCRF_E_INVALID, "unary_out is NULL");
     { int rl = h->eng.resolve_late(); if (rl) return rl; }
+    { int rp = h->eng.ensure_plain(); if (rp) return rp; }           // (energies derived from labels live in the lattices' point order)
     { int ru = h->eng.ensure_unary(); if (ru) return ru; }
     return copy_out_f32(h, h->eng.crf.unary, unary_out, (size_t)h->N * h->eng.L);
 }
@@ -1421,6 +1450,7 @@ int lccrf_get_norm(lccrf_handle h, int kernel, float *norm_out)
     CHECK_H(h);
     CHECK_K(h, kernel);
     if (!norm_out && h->N) return fail(LCCRF_E_INVALID, "norm_out is NULL");
+    { int rp = h->eng.ensure_plain(); if (rp) return rp; }
     { int rcf = h->eng.flush_builds(); if (rcf) return rcf; }
     HIP_TRY(hipStreamSynchronize(h->eng.stream));
     if (h->N) HIP_TRY(hipMemcpy(norm_out, h->eng.kernels[kernel].dev.norm, (size_t)h->N * sizeof(float), hipMemcpyDeviceToHost));
@@ -1432,6 +1462,7 @@ int lccrf_get_lattice(lccrf_handle h, int kernel, int32_t *offset_out, float *ba
     CHECK_H(h);
     CHECK_K(h, kernel);
     Engine &e = h->eng;
+    { int rp = e.ensure_plain(); if (rp) return rp; }
     { int rcf = e.flush_builds(); if (rcf) return rcf; }
     HIP_TRY(hipStreamSynchronize(e.stream));
     const KernelDev &k = e.kernels[kernel].dev;

@@ -778,6 +778,46 @@ def test_sorted_build_falls_back_to_the_hash_when_codes_overflow(po, wl, d, spre
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("d_list,labels", [([6], False), ([3, 2], True), ([5], True)])
+def test_object_api_large_frame_runs_inference_in_locality_mode(po, wl, d_list, labels):
+    """BASELINE config 5 through the reference's OWN interface: a DenseCRF of >= 8192 points.  `inference()` on such a handle runs in
+    locality mode (internal point order, sorted build, blur passes in the splat) -- and every other entry point of the object API
+    still answers in the caller's point order: stepInference continues from the result, PairwisePotential::apply, the norm, the
+    lattice probe (the reference's own vertex numbering) and the unary probe re-build the lattices the plain way, once; new unaries
+    and a second inference; a recycled handle starts afresh.  Everything against the oracle, bit for bit."""
+    N = 9100
+    pb = wl.generic_problem(N, d_list, 2, seed=913 + len(d_list), spread=2.8)
+    if labels:
+        rng = np.random.default_rng(5)
+        pb = dict(pb, label=rng.integers(-1, 2, N).astype(np.int16), conf=np.float32([0.7, 0.6]))
+        del pb["unary"]
+    for order in range(3):
+        h = cc.setup(pkg.DenseCRFHIP, pb)
+        o = cc.setup(po.OracleCRF, pb)
+        if order == 1:                                     # a probe first: the handle is built the plain way and stays so
+            assert np.array_equal(h.kernel(0)["offset"], o.kernel(0)["offset"])
+        h.inference(3, True, 0.9)
+        o.inference_native(3, True, 0.9)
+        assert cc.same_bits(h.probability(), o.probability()) and np.array_equal(h.map(), o.map()), order
+        if order == 2:                                     # new unaries on the same lattices, then again
+            u = np.random.default_rng(8).uniform(0.1, 2.0, (N, 2)).astype(np.float32)
+            h.set_unary(u); o.set_unary(u)
+            h.inference(2, True); o.inference_native(2, True)
+            assert cc.same_bits(h.probability(), o.probability()), order
+        h.step_inference(0.8)                              # continues from inference()'s Q -- on plain lattices from here on
+        o.step_inference(0.8)
+        assert cc.same_bits(h.probability(), o.probability()), order
+        x = np.random.default_rng(3).normal(0, 1, (N, 2)).astype(np.float32)
+        assert cc.same_bits(h.apply(0, np.zeros((N, 2), np.float32), x), o.apply(0, np.zeros((N, 2), np.float32), x))
+        kh, ko = h.kernel(0), o.kernel(0)
+        assert kh["V"] == ko["V"] and np.array_equal(kh["offset"], ko["offset"]) and cc.same_bits(kh["norm"], ko["norm"])
+        assert cc.same_bits(h.unary(), o.unary())
+        h.inference(2, True); o.inference_native(2, True)  # (banned from locality mode now: same bits all the same)
+        assert cc.same_bits(h.probability(), o.probability()) and np.array_equal(h.map(), o.map())
+        h.close(); o.close()                               # parked: the next round reuses the handle
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("env", [{"LCCRF_SPLAT_PASSES": "1"}, {"LCCRF_SPLAT_PASSES": "2"}, {"LCCRF_NO_SPLAT_BLUR": "1"}, {"LCCRF_NO_XCD_CHUNK": "1"},
                                  {"LCCRF_NO_COMPACT_NBR": "1"}, {"LCCRF_NO_PAIR_FUSE": "1"}])
 def test_streaming_engine_switches_do_not_change_a_bit(po, wl, env):
