@@ -2,7 +2,8 @@
 """Fuzz of the round-3 paths against the oracle (run on the GPU box): locality mode of the streaming engine (random sizes
 above 8192, 1-6 feature dimensions, 2-3 labels, 1-2 kernels, uniform / clustered / duplicated features, labels or raw
 unaries, ragged batches with empty frames, rebuilt twice) and the 512-lane shapes with per-frame fallback (random small
-frames, a few sparse ones).  Every frame checked: lattice sizes, Q bit for bit, labels.
+frames, a few sparse ones), and large single frames through the object API (inference() in locality mode, then a random
+walk over the other entry points).  Every frame checked: lattice sizes, Q bit for bit, labels.
     python scripts/stress_locality.py [seconds]"""
 import importlib
 import os
@@ -101,6 +102,49 @@ def large_case(rng):
     return ok
 
 
+def object_case(rng):
+    """One large frame through the OBJECT API: inference() in locality mode, then a random walk over the entry points that want the
+    caller's point order (they re-build the lattices the plain way, once), new unaries, a recycled handle -- against the oracle."""
+    K, L = int(rng.integers(1, 3)), int(rng.integers(2, 4))
+    dims = [int(rng.integers(1, 9)) for _ in range(K)]
+    n = int(rng.integers(8192, 16000))
+    kind = int(rng.integers(0, 3))
+    pb = dict(N=n, L=L, kernels=[(features(rng, n, d, kind), np.float32(rng.uniform(1, 12))) for d in dims])
+    if L == 2 and rng.random() < 0.5:
+        pb["label"], pb["conf"] = rng.integers(-1, 2, n).astype(np.int16), np.float32(0.7)
+    else:
+        pb["unary"] = rng.uniform(0.05, 3.0, (n, L)).astype(np.float32)
+    h, o = cc.setup(pkg.DenseCRFHIP, pb), cc.setup(po.OracleCRF, pb)
+    tag = "object K=%d L=%d dims=%s kind=%d n=%d" % (K, L, dims, kind, n)
+    ok = True
+    for step in range(int(rng.integers(2, 6))):
+        op = int(rng.integers(0, 6))
+        if op <= 1:
+            it, relax = int(rng.integers(1, 4)), float(rng.choice([1.0, 0.8]))
+            h.inference(it, True, relax); o.inference_native(it, True, relax)
+            ok = ok and cc.same_bits(h.probability(), o.probability()) and np.array_equal(h.map(), o.map())
+        elif op == 2:
+            h.start_inference(); o.start_inference()
+            h.step_inference(0.9); o.step_inference(0.9)
+            ok = ok and cc.same_bits(h.probability(), o.probability())
+        elif op == 3:
+            x = rng.normal(0, 1, (n, L)).astype(np.float32)
+            k = int(rng.integers(0, K))
+            ok = ok and cc.same_bits(h.apply(k, np.zeros((n, L), np.float32), x), o.apply(k, np.zeros((n, L), np.float32), x))
+        elif op == 4:
+            k = int(rng.integers(0, K))
+            kh, ko = h.kernel(k), o.kernel(k)
+            ok = ok and kh["V"] == ko["V"] and np.array_equal(kh["offset"], ko["offset"]) and cc.same_bits(kh["norm"], ko["norm"])
+        else:
+            u = rng.uniform(0.05, 3.0, (n, L)).astype(np.float32)
+            h.set_unary(u); o.set_unary(u)
+        if not ok:
+            print("MISMATCH", tag, "step", step, "op", op)
+            break
+    h.close(); o.close()
+    return ok
+
+
 def small_case(rng):
     F = int(rng.integers(256, 400))
     maxN = int(rng.integers(40, 1025))
@@ -149,7 +193,7 @@ def small_case(rng):
 def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
     rng = np.random.default_rng(int(time.time()))
-    t0, n_large, n_small = time.time(), 0, 0
+    t0, n_large, n_small, n_obj = time.time(), 0, 0, 0
     while time.time() - t0 < budget:
         if not large_case(rng):
             return 1
@@ -157,8 +201,12 @@ def main():
         if not small_case(rng):
             return 1
         n_small += 1
-    print("stress ok: %d large batches (locality mode), %d small batches (512-lane shapes + per-frame fallback) in %.0f s"
-          % (n_large, n_small, time.time() - t0))
+        if n_large % 4 == 0:
+            if not object_case(rng):
+                return 1
+            n_obj += 1
+    print("stress ok: %d large batches (locality mode), %d small batches (512-lane shapes + per-frame fallback), %d large object-API frames in %.0f s"
+          % (n_large, n_small, n_obj, time.time() - t0))
     return 0
 
 
