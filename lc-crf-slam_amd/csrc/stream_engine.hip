@@ -1792,7 +1792,8 @@ void launch_step_stream(const CrfDev &c, const KernelDev *kds, const int *maxV, 
                 // many frames in flight: 256 lanes x 1 / 2 / 4 vertices (C5 x 8, window 1024: 20.6 -> 18.9 us per frame-iteration against
                 // 1024 lanes x 1: workgroups of four wavefronts wait less at the barriers); one or two frames: a lane per vertex (a
                 // lane's four row walks in a row cost a single frame 33.3 -> 36.1)
-                const bool wide = c.F <= 2;
+                static const char *env_w = getenv("LCCRF_SPLAT_WIDE_MAX");                  // (A/B: frames-in-flight threshold)
+                const bool wide = c.F <= (env_w ? atoi(env_w) : 2);
                 const int lanes = wide ? B : kBlock;
                 const dim3 g = grid_xcd(((long)maxV[k] + core - 1) / core * lanes, c.F, &nb, lanes);
                 if (B == 256) k_splat2w<256, 1><<<g, 256, 0, s>>>(kd, q2, c.maxN, c.F, nb, j0, kd.splat_halo);
