@@ -397,6 +397,7 @@ struct Engine {
             if ((rc = mem.alloc(&k.nbrc_base, Fc * k.D1 * (E / kNbrcBlock + 1) * 2))) return rc;
         }
         if ((rc = mem.alloc(&k.rowptr, Fz * (E + 1)))) return rc;
+        if ((rc = mem.alloc(&k.longrow, Fz * (kLongRowCap + 1)))) return rc;
         if ((rc = mem.alloc(&k.csr_pt, Fz * E))) return rc;
         if ((rc = mem.alloc(&k.csr_w, Fz * E))) return rc;
         if ((rc = mem.alloc(&k.csr_pos, Fz * E))) return rc;
@@ -529,11 +530,12 @@ struct Engine {
             const int NA = activeN > 0 ? activeN : maxN;
             if (!no_small && k + 1 < k0 + n && build_small_supported(&kdevs[k], 2, NA)) m = 2;
             if (!no_small && build_small_supported(&kdevs[k], m, NA)) {
-                for (int u = 0; u < m; ++u) kernels[k + u].dev.nbr2_ok = kernels[k + u].dev.nbrc_ok = kernels[k + u].dev.fast0_ok = 0;
+                for (int u = 0; u < m; ++u) kernels[k + u].dev.nbr2_ok = kernels[k + u].dev.nbrc_ok = kernels[k + u].dev.fast0_ok = kernels[k + u].dev.longrow_ok = 0;
                 launch_build_small(&kdevs[k], m, NA, crf, stream);   // writes V / rowmax to the pinned mirrors itself
             } else {
                 m = 1;
                 kernels[k].dev.nbr2_ok = kernels[k].dev.nbr2 != nullptr;      // (the streaming build fills the two-hop table when there is one)
+                kernels[k].dev.longrow_ok = kdevs[k].longrow_ok = 1;          //   (... and lists the long rows: the normalisation below reads the list)
                 kernels[k].dev.nbrc_ok = kernels[k].dev.nbrc != nullptr && kernels[k].dev.vorder && F >= kNbrcMinFrames && F <= kNbrcMaxFrames;   // (... and the sorted build the compact one)
                 kernels[k].dev.fast0_ok = kernels[k].dev.tbl_bad != nullptr && kernels[k].dev.vorder;
                 kernels[k].dev.nbr2_first = kernels[k].dev.fast0_ok;              // (what build_kernel_d derives from the same two fields)

@@ -18,6 +18,8 @@ constexpr int kMaxD = LCCRF_MAX_DIMS;
 constexpr int kEmpty = -1;
 
 constexpr int kNdistAxes = 4;
+constexpr int kLongRowMin = 512;    // generic (L-label) splat: rows beyond this many entries go to a workgroup of their own (KernelDev::longrow)
+constexpr int kLongRowCap = 4095;   // ... as long as there are no more than this many of them per frame
 constexpr int kNbrcBlock = 64;      // vertices per base of the compact neighbour table (KernelDev::nbrc): one wavefront
 constexpr int kNbrcMinFrames = 3;   // ... which is built and read with 3 to 5 frames in flight (one frame: the passes go two per launch off the
 constexpr int kNbrcMaxFrames = 5;   //   two-hop table; two frames: +-0) (C5, per frame and iteration: 3 / 4 / 5 frames
@@ -80,6 +82,9 @@ struct KernelDev {
     int splat_halo;       // ... the halo that takes on each side of a window (1 + distance of axis 1 [+ distance of axis 2])
     int splat_block;      // ... and the window (256 / 512 / 1024 vertices: 256 lanes x 1 / 2 / 4)
     int *rowptr;          // [F][Epad+1]       CSR: vertex -> range of splat contributions
+    int *longrow;         // [F][kLongRowCap+1] [0] = number of rows longer than kLongRowMin, then their vertices (any order); a count
+                          //   beyond kLongRowCap = "not listed": every row is summed in line
+    int longrow_ok;       // the list describes the lattices now in HBM (the streaming build writes it; k_build_small does not)
     int *csr_pt;          // [F][Epad]         contributing point, ascending within a row
     float *csr_w;         // [F][Epad]         its barycentric weight
     int *csr_pos;         // [F][Epad]         entry -> its position in csr_pt/csr_w (inverse of the row ordering)

@@ -1111,6 +1111,7 @@ __global__ void __launch_bounds__(kBlock) k_csr_sort_long(KernelDev kd)
 
 // val0[v+1][l] = sum over the vertex's contributions, ascending point order.  in == nullptr
 // means the all-ones input of the normalisation pass (pairwise3d.h:23-24).
+constexpr int kSplatUnroll = 16;
 __global__ void __launch_bounds__(kBlock) k_splat(KernelDev kd, const float *__restrict__ in,
                                                   int in_stride, int L)
 {
@@ -1121,13 +1122,116 @@ __global__ void __launch_bounds__(kBlock) k_splat(KernelDev kd, const float *__r
     const int v = idx / L, l = idx - v * L;
     const size_t fe = (size_t)f * kd.Epad, f1 = (size_t)f * (kd.Epad + 1);
     const int s = kd.rowptr[f1 + v], t = kd.rowptr[f1 + v + 1];
+    if (kd.longrow_ok && t - s > kLongRowMin && kd.longrow[(size_t)f * (kLongRowCap + 1)] <= kLongRowCap) return;   // k_splat_long's
     const float *x = in ? in + (size_t)f * in_stride : nullptr;
     float acc = 0.0f;
-    for (int p = s; p < t; ++p) {
+    int p = s;
+    // long rows (a coarse kernel over many points: the reference's image demo has rows of ~900 entries): the adds must go one by one
+    // in point order, the LOADS need not -- kSplatUnroll entries' indices, weights and inputs in flight per round trip instead of one
+    // (the demo's splat 944 -> ~100 us per launch)
+    for (; p + kSplatUnroll <= t; p += kSplatUnroll) {
+        int pt[kSplatUnroll];
+        float w[kSplatUnroll], xv[kSplatUnroll];
+#pragma unroll
+        for (int i = 0; i < kSplatUnroll; ++i) { pt[i] = kd.csr_pt[fe + p + i]; w[i] = kd.csr_w[fe + p + i]; }
+#pragma unroll
+        for (int i = 0; i < kSplatUnroll; ++i) xv[i] = x ? x[(size_t)pt[i] * L + l] : 1.0f;
+#pragma unroll
+        for (int i = 0; i < kSplatUnroll; ++i) acc += w[i] * xv[i];
+    }
+    for (; p < t; ++p) {
         const float xv = x ? x[(size_t)kd.csr_pt[fe + p] * L + l] : 1.0f;
         acc += kd.csr_w[fe + p] * xv;
     }
     kd.val0[(size_t)f * kd.vstride + kd.vbase + (long)v * L + l] = acc;
+}
+
+// Rows of thousands of entries (a coarse kernel over many points -- the appearance kernel of the reference's image demo puts whole
+// uniformly coloured regions on one vertex): the adds of a row must still go one by one in point order (quirk Q6), but nothing says
+// the LOADS must.  A workgroup per listed row (KernelDev::longrow, filled by the build): all lanes form the products
+// w[p] * in[pt[p]][l] of a tile of entries in LDS, then lane l < L adds its label's column top to bottom -- the same products, the
+// same order, the same bits as the in-line walk.
+constexpr int kLongTile = 8192;          // products per tile (floats); two tiles in LDS
+__global__ void __launch_bounds__(kBlock) k_splat_long(KernelDev kd, const float *__restrict__ in, int in_stride, int L)
+{
+    __shared__ float prod[2][kLongTile];
+    const int f = blockIdx.y;
+    const int *lr = kd.longrow + (size_t)f * (kLongRowCap + 1);
+    const int n = lr[0];
+    if (n > kLongRowCap) return;
+    const size_t fe = (size_t)f * kd.Epad, f1 = (size_t)f * (kd.Epad + 1);
+    const float *x = in ? in + (size_t)f * in_stride : nullptr;
+    const int tid = threadIdx.x, ec = kLongTile / L;      // entries per tile
+    constexpr int kLoaders = kBlock - 64;                 // wavefront 0 adds, the other three load: the tile being added and the tile
+    for (int i = blockIdx.x; i < n; i += gridDim.x) {     // being loaded are different halves of `prod`, one barrier per tile
+        const int v = lr[1 + i];
+        const int s = kd.rowptr[f1 + v], t = kd.rowptr[f1 + v + 1];
+        const int ntiles = (t - s + ec - 1) / ec;
+        float acc = 0.0f;
+        for (int k = -1; k < ntiles; ++k) {
+            if (tid >= 64) {                              // load tile k + 1
+                const int p0 = s + (k + 1) * ec;
+                const int m = k + 1 < ntiles ? min(ec, t - p0) * L : 0;
+                float *dst = prod[(k + 1) & 1];
+                int idx = tid - 64;
+                for (; idx + 7 * kLoaders < m; idx += 8 * kLoaders) {        // eight products per lane and round trip
+                    int pt[8], l[8];
+                    float w[8], xv[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int e = (idx + u * kLoaders) / L;
+                        l[u] = idx + u * kLoaders - e * L;
+                        pt[u] = kd.csr_pt[fe + p0 + e];
+                        w[u] = kd.csr_w[fe + p0 + e];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) xv[u] = x ? x[(size_t)pt[u] * L + l[u]] : 1.0f;
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) dst[idx + u * kLoaders] = w[u] * xv[u];
+                }
+                for (; idx < m; idx += kLoaders) {
+                    const int e = idx / L, l = idx - e * L;
+                    const float xv = x ? x[(size_t)kd.csr_pt[fe + p0 + e] * L + l] : 1.0f;
+                    dst[idx] = kd.csr_w[fe + p0 + e] * xv;
+                }
+            } else if (k >= 0 && tid < L) {               // add tile k: label tid's column, top to bottom
+                const int p0 = s + k * ec;
+                const int m = min(ec, t - p0);
+                const float *src = prod[k & 1] + tid;
+                int e = 0;
+                for (; e + 8 <= m; e += 8) {
+                    float q[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) q[u] = src[(e + u) * L];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) acc += q[u];
+                }
+                for (; e < m; ++e) acc += src[e * L];
+            }
+            __syncthreads();
+        }
+        if (tid < L) kd.val0[(size_t)f * kd.vstride + kd.vbase + (long)v * L + tid] = acc;
+    }
+}
+
+// the list of long rows, once per build
+__global__ void __launch_bounds__(kBlock) k_long_rows(KernelDev kd)
+{
+    const int f = blockIdx.y;
+    const int v = blockIdx.x * kBlock + threadIdx.x;
+    if (v >= kd.V[f]) return;
+    const size_t f1 = (size_t)f * (kd.Epad + 1);
+    if (kd.rowptr[f1 + v + 1] - kd.rowptr[f1 + v] <= kLongRowMin) return;
+    int *lr = kd.longrow + (size_t)f * (kLongRowCap + 1);
+    const int i = atomicAdd(&lr[0], 1);
+    if (i < kLongRowCap) lr[1 + i] = v;
+}
+
+// the generic splat: rows in line, the long ones by a workgroup each
+inline void launch_splat(const KernelDev &kd, const float *in, int in_stride, int L, int F, int maxV, hipStream_t s)
+{
+    k_splat<<<grid_for((long)maxV * L, F), kBlock, 0, s>>>(kd, in, in_stride, L);
+    if (kd.longrow_ok) k_splat_long<<<dim3((unsigned)std::max(256 / std::max(F, 1), 8), (unsigned)F), kBlock, 0, s>>>(kd, in, in_stride, L);
 }
 
 // One Jacobi blur pass along axis j.  ref: :663-679.
@@ -1707,6 +1811,8 @@ void build_kernel_d(const KernelDev &kd, const CrfDev &c, hipStream_t s, const S
     }
     (void)hipMemsetAsync(kd.rowmax, 0, (size_t)F * sizeof(int), s);
     if (kd.Epad < 65535) k_row_max<<<grid_for(kd.Epad, F), kBlock, 0, s>>>(kd);   // only the one-workgroup engines ask (u16 ids)
+    (void)hipMemsetAsync(kd.longrow, 0, (size_t)F * (kLongRowCap + 1) * sizeof(int), s);
+    k_long_rows<<<grid_for(kd.Epad, F), kBlock, 0, s>>>(kd);
 }
 
 }  // namespace
@@ -1742,7 +1848,7 @@ static void filter_passes(const KernelDev &kd, int F, int maxV, int L, hipStream
 // norm = 1 / (compute(ones) + 1e-20), value width 1.  pairwise3d.h:22-27.
 void launch_norm(const KernelDev &kd, const CrfDev &c, int maxV, hipStream_t s)
 {
-    k_splat<<<grid_for(maxV, c.F), kBlock, 0, s>>>(kd, nullptr, 0, 1);
+    launch_splat(kd, nullptr, 0, 1, c.F, maxV, s);
     const float *res;
     filter_passes(kd, c.F, maxV, 1, s, &res);
     const dim3 g = grid_for(c.maxN, c.F);
@@ -1855,7 +1961,7 @@ void launch_step_stream(const CrfDev &c, const KernelDev *kds, const int *maxV, 
     }
     for (int k = 0; k < c.K; ++k) {
         const KernelDev &kd = kds[k];
-        k_splat<<<grid_for((long)maxV[k] * L, c.F), kBlock, 0, s>>>(kd, c.Q, c.maxN * L, L);
+        launch_splat(kd, c.Q, c.maxN * L, L, c.F, maxV[k], s);
         const float *res;
         filter_passes(kd, c.F, maxV[k], L, s, &res);
         k_slice<<<grid_for((long)c.maxN * L, c.F), kBlock, 0, s>>>(kd, c, res, L,
@@ -1982,7 +2088,7 @@ void launch_step_init(const CrfDev &c, float *out, hipStream_t s)
 void launch_filter(const KernelDev &kd, const CrfDev &c, int maxV, const float *in, float *out, int accumulate, hipStream_t s)
 {
     const int L = c.L;
-    k_splat<<<grid_for((long)maxV * L, c.F), kBlock, 0, s>>>(kd, in, c.maxN * L, L);
+    launch_splat(kd, in, c.maxN * L, L, c.F, maxV, s);
     const float *res;
     filter_passes(kd, c.F, maxV, L, s, &res);
     CrfDev c2 = c;

@@ -108,6 +108,17 @@ def generic_problem(N, d_list, L, seed, spread=4.0, lattice_ties=False):
     return dict(N=N, L=L, unary=unary, kernels=kernels)
 
 
+def image_features(W, H, posdev, rgb=None, featuredev=0.0):
+    """PairwisePotential's image features (pairwise_cpu.h:33-51, FromImage / examples/example_cpu.cpp:86-91): (x, y) / posdev and,
+    with an image, its channels / featuredev -- float divisions of exact small integers, so numpy gives the reference's bits."""
+    y, x = np.mgrid[0:H, 0:W].astype(np.float32)
+    cols = [x.ravel() / np.float32(posdev), y.ravel() / np.float32(posdev)]
+    if rgb is not None:
+        c = np.ascontiguousarray(rgb, np.uint8).reshape(W * H, -1).astype(np.float32)
+        cols += [c[:, i] / np.float32(featuredev) for i in range(c.shape[1])]
+    return np.ascontiguousarray(np.stack(cols, 1), np.float32)
+
+
 def map_point_scene(n_points, n_kf, seed, max_obs=12):
     """A synthetic local map for the unary builder (Tracking.cc:1803-1839): keyframes on a short arc
     looking roughly down +z, map points in front of them, each point observed by a random subset of

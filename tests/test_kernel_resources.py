@@ -73,3 +73,15 @@ def test_fused_build_does_not_spill_vector_registers():
     assert len(build) == 3                                    # d = 1, 2, 3
     for name, r in build.items():
         assert r["VGPRs Spill"] == 0 and r["VGPRs"] <= 128, (name, r)
+
+
+@pytest.mark.skipif(shutil.which(HIPCC) is None, reason="hipcc not installed")
+def test_streaming_iteration_kernels_use_no_scratch():
+    """The streaming engine's iteration kernels are small; scratch there is an accident, not a trade -- round 4 met one:
+    `ok ? lds[i] : zero` on float2 selects between two ADDRESSES and parks the zero in scratch (16 B per lane, the splat window 2 x
+    slower).  Every splat / blur / slice / softmax variant of stream_engine.hip must compile without it."""
+    use = resource_usage("stream_engine.hip")
+    it = {k: v for k, v in use.items() if re.search(r"k_(splat|blur|slice|softmax|map|nbr_compact|row_|long_rows)", k)}
+    assert len(it) >= 30
+    for name, r in it.items():
+        assert r["ScratchSize [bytes/lane]"] == 0 and r.get("VGPRs Spill", 0) == 0, (name, r)
