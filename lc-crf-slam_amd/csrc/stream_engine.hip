@@ -1705,6 +1705,39 @@ __global__ void __launch_bounds__(kBlock) k_softmax(CrfDev c, const float *__res
     exp_and_normalize_row(in + q, out + q, c.L, scale, relax);
 }
 
+// ... for 3 to 24 labels through LDS: a lane's row is L floats apart from its neighbour's, so the direct kernel's loads touch 64 lines
+// each (L = 21, 100 000 points: 68 us for 17 MB).  A wavefront moves the rows of its 64 points as ONE contiguous block -- coalesced --
+// into LDS, every lane works on its own row there (the same row function, the same order of operations), and the block goes back
+// the same way.
+constexpr int kSoftmaxMaxL = 24;            // (48 KB of LDS per workgroup)
+__global__ void __launch_bounds__(kBlock) k_softmax_lds(CrfDev c, const float *__restrict__ in, float *__restrict__ out, float scale, float relax)
+{
+    extern __shared__ float tile[];                       // [waves][2][64 * L]: input rows, output rows
+    const int f = blockIdx.y, L = c.L;
+    const int N = c.n_points[f];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int i0 = blockIdx.x * kBlock + wave * 64;       // the wavefront's first point
+    if (i0 >= N) return;
+    const int n = min(64, N - i0) * L;                    // floats of this wavefront's block
+    float *tin = tile + (size_t)wave * 2 * 64 * L, *tout = tin + 64 * L;
+    const size_t q0 = ((size_t)f * c.maxN + i0) * L;
+    for (int k = lane; k < n; k += 64) tin[k] = in[q0 + k];
+    if (relax != 1.0f)
+        for (int k = lane; k < n; k += 64) tout[k] = out[q0 + k];       // the blend reads the old out (densecrf3d.h:91-94)
+    __builtin_amdgcn_wave_barrier();
+    if (i0 + lane < N) exp_and_normalize_row(tin + lane * L, tout + lane * L, L, scale, relax);
+    __builtin_amdgcn_wave_barrier();
+    for (int k = lane; k < n; k += 64) out[q0 + k] = tout[k];
+}
+
+inline void launch_softmax(const CrfDev &c, const float *in, float *out, float scale, float relax, hipStream_t s)
+{
+    if (c.L >= 3 && c.L <= kSoftmaxMaxL)
+        k_softmax_lds<<<grid_for(c.maxN, c.F), kBlock, (size_t)(kBlock / 64) * 2 * 64 * c.L * sizeof(float), s>>>(c, in, out, scale, relax);
+    else
+        k_softmax<<<grid_for(c.maxN, c.F), kBlock, 0, s>>>(c, in, out, scale, relax);
+}
+
 // next = -unary (DenseCRF3D::stepInit, densecrf3d.h:154-158) into an arbitrary buffer
 __global__ void __launch_bounds__(kBlock) k_step_init(CrfDev c, float *__restrict__ out)
 {
@@ -1872,7 +1905,7 @@ void launch_unary_from_label_tbl(const CrfDev &c, const int16_t *label, const Un
 
 void launch_start(const CrfDev &c, hipStream_t s)   // densecrf_base.h:78-80
 {
-    k_softmax<<<grid_for(c.maxN, c.F), kBlock, 0, s>>>(c, c.unary, c.Q, -1.0f, 1.0f);
+    launch_softmax(c, c.unary, c.Q, -1.0f, 1.0f, s);
 }
 
 void launch_step_stream(const CrfDev &c, const KernelDev *kds, const int *maxV, float relax, hipStream_t s)
@@ -1880,7 +1913,7 @@ void launch_step_stream(const CrfDev &c, const KernelDev *kds, const int *maxV, 
     const int L = c.L;
     if (c.K == 0) {
         // stepInit only: next = -unary, then softmax.  Done by the softmax with scale -1.
-        k_softmax<<<grid_for(c.maxN, c.F), kBlock, 0, s>>>(c, c.unary, c.Q, -1.0f, relax);
+        launch_softmax(c, c.unary, c.Q, -1.0f, relax, s);
         return;
     }
     if (L == 2) {
@@ -1967,7 +2000,7 @@ void launch_step_stream(const CrfDev &c, const KernelDev *kds, const int *maxV, 
         k_slice<<<grid_for((long)c.maxN * L, c.F), kBlock, 0, s>>>(kd, c, res, L,
                                                                  k == 0 ? SLICE_APPLY_FIRST : SLICE_APPLY);
     }
-    k_softmax<<<grid_for(c.maxN, c.F), kBlock, 0, s>>>(c, c.next, c.Q, 1.0f, relax);
+    launch_softmax(c, c.next, c.Q, 1.0f, relax, s);
 }
 
 // Measurement support (bench.py's roofline object): `reps` launches of the streaming engine's dominant kernel --
@@ -2075,7 +2108,7 @@ void launch_map_of(const CrfDev &c, const float *prob, int16_t *map, hipStream_t
 
 void launch_exp_and_normalize(const CrfDev &c, const float *in, float *out, float scale, float relax, hipStream_t s)
 {
-    k_softmax<<<grid_for(c.maxN, c.F), kBlock, 0, s>>>(c, in, out, scale, relax);
+    launch_softmax(c, in, out, scale, relax, s);
 }
 
 void launch_step_init(const CrfDev &c, float *out, hipStream_t s)
