@@ -1112,6 +1112,7 @@ __global__ void __launch_bounds__(kBlock) k_csr_sort_long(KernelDev kd)
 // val0[v+1][l] = sum over the vertex's contributions, ascending point order.  in == nullptr
 // means the all-ones input of the normalisation pass (pairwise3d.h:23-24).
 constexpr int kSplatUnroll = 16;
+typedef float lccrf_f4u __attribute__((ext_vector_type(4), aligned(4)));     // four labels of a row, wherever L puts them
 __global__ void __launch_bounds__(kBlock) k_splat(KernelDev kd, const float *__restrict__ in,
                                                   int in_stride, int L)
 {
@@ -1144,6 +1145,49 @@ __global__ void __launch_bounds__(kBlock) k_splat(KernelDev kd, const float *__r
         acc += kd.csr_w[fe + p] * xv;
     }
     kd.val0[(size_t)f * kd.vstride + kd.vbase + (long)v * L + l] = acc;
+}
+
+// ... four labels per thread from L = 4 on: a row's indices and weights are read once per four labels, the inputs as 16-byte loads
+__global__ void __launch_bounds__(kBlock) k_splat4(KernelDev kd, const float *__restrict__ in, int in_stride, int L, int C)
+{
+    const int f = blockIdx.y;
+    const int V = kd.V[f];
+    const int idx = blockIdx.x * kBlock + threadIdx.x;
+    if (idx >= V * C) return;
+    const int v = idx / C, l = (idx - v * C) * 4, nl = min(4, L - l);
+    const size_t fe = (size_t)f * kd.Epad, f1 = (size_t)f * (kd.Epad + 1);
+    const int s = kd.rowptr[f1 + v], t = kd.rowptr[f1 + v + 1];
+    if (kd.longrow_ok && t - s > kLongRowMin && kd.longrow[(size_t)f * (kLongRowCap + 1)] <= kLongRowCap) return;   // k_splat_long's
+    const float *x = in + (size_t)f * in_stride + l;
+    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    constexpr int U = 8;
+    int p = s;
+    if (nl == 4) {
+        for (; p + U <= t; p += U) {
+            int pt[U];
+            float w[U];
+            lccrf_f4u xv[U];
+#pragma unroll
+            for (int i = 0; i < U; ++i) { pt[i] = kd.csr_pt[fe + p + i]; w[i] = kd.csr_w[fe + p + i]; }
+#pragma unroll
+            for (int i = 0; i < U; ++i) xv[i] = *reinterpret_cast<const lccrf_f4u *>(x + (size_t)pt[i] * L);
+#pragma unroll
+            for (int i = 0; i < U; ++i) { acc[0] += w[i] * xv[i].x; acc[1] += w[i] * xv[i].y; acc[2] += w[i] * xv[i].z; acc[3] += w[i] * xv[i].w; }
+        }
+        for (; p < t; ++p) {
+            const float w = kd.csr_w[fe + p];
+            const lccrf_f4u xv = *reinterpret_cast<const lccrf_f4u *>(x + (size_t)kd.csr_pt[fe + p] * L);
+            acc[0] += w * xv.x; acc[1] += w * xv.y; acc[2] += w * xv.z; acc[3] += w * xv.w;
+        }
+    } else {
+        for (; p < t; ++p) {
+            const float w = kd.csr_w[fe + p];
+            const float *xp = x + (size_t)kd.csr_pt[fe + p] * L;
+            for (int u = 0; u < nl; ++u) acc[u] += w * xp[u];
+        }
+    }
+    float *d = kd.val0 + (size_t)f * kd.vstride + kd.vbase + (long)v * L + l;
+    for (int u = 0; u < nl; ++u) d[u] = acc[u];
 }
 
 // Rows of thousands of entries (a coarse kernel over many points -- the appearance kernel of the reference's image demo puts whole
@@ -1230,7 +1274,11 @@ __global__ void __launch_bounds__(kBlock) k_long_rows(KernelDev kd)
 // the generic splat: rows in line, the long ones by a workgroup each
 inline void launch_splat(const KernelDev &kd, const float *in, int in_stride, int L, int F, int maxV, hipStream_t s)
 {
-    k_splat<<<grid_for((long)maxV * L, F), kBlock, 0, s>>>(kd, in, in_stride, L);
+    // four labels per thread where the rows are short (a fine lattice: about one entry per vertex at d = 5 or 6); a coarse kernel's
+    // rows of tens to hundreds of entries want every (vertex, label) walk in flight on its own (the image demo: 344 vs 554 us)
+    const bool short_rows = (long)kd.maxN * kd.D1 <= 4L * std::max(maxV, 1);
+    if (L >= 4 && in && short_rows) k_splat4<<<grid_for((long)maxV * ((L + 3) / 4), F), kBlock, 0, s>>>(kd, in, in_stride, L, (L + 3) / 4);
+    else k_splat<<<grid_for((long)maxV * L, F), kBlock, 0, s>>>(kd, in, in_stride, L);
     if (kd.longrow_ok) k_splat_long<<<dim3((unsigned)std::max(256 / std::max(F, 1), 8), (unsigned)F), kBlock, 0, s>>>(kd, in, in_stride, L);
 }
 
@@ -1251,6 +1299,34 @@ __global__ void __launch_bounds__(kBlock) k_blur(KernelDev kd, const float *__re
     dst[fv + kd.vbase + (long)v * L + l] = o[(long)v * L + l] + 0.5f * (a + c);
 }
 
+// ... four labels per thread from L = 4 on (16-byte accesses on 4-byte alignment: a vertex's row starts wherever L puts it): the
+// pass at L = 21 is bound by instructions per byte, not by bytes (55 us per 558 000 vertices against 18 at the streaming rate).
+__global__ void __launch_bounds__(kBlock) k_blur4(KernelDev kd, const float *__restrict__ src, float *__restrict__ dst, int j, int L, int C)
+{
+    const int f = blockIdx.y;
+    const int V = kd.V[f];
+    const int idx = blockIdx.x * kBlock + threadIdx.x;
+    if (idx >= V * C) return;
+    const int v = idx / C, l = (idx - v * C) * 4;         // C = ceil(L / 4) chunks per vertex
+    const size_t fv = (size_t)f * kd.vstride;
+    const int2 nb = reinterpret_cast<const int2 *>(kd.nbr)[((size_t)f * kd.D1 + j) * kd.Epad + v];
+    const float *o = src + fv + kd.vbase;                 // o[v*L+l], v = -1 is the all-zero "absent" vertex
+    float *d = dst + fv + kd.vbase + (long)v * L + l;
+    const float *pa = o + (long)nb.x * L + l, *pc = o + (long)nb.y * L + l, *po = o + (long)v * L + l;
+    if (l + 4 <= L) {
+        const lccrf_f4u a = *reinterpret_cast<const lccrf_f4u *>(pa), c = *reinterpret_cast<const lccrf_f4u *>(pc),
+                        m = *reinterpret_cast<const lccrf_f4u *>(po);
+        lccrf_f4u r;
+        r.x = m.x + 0.5f * (a.x + c.x);
+        r.y = m.y + 0.5f * (a.y + c.y);
+        r.z = m.z + 0.5f * (a.z + c.z);
+        r.w = m.w + 0.5f * (a.w + c.w);
+        *reinterpret_cast<lccrf_f4u *>(d) = r;
+    } else {
+        for (int u = 0; u < L - l; ++u) d[u] = po[u] + 0.5f * (pa[u] + pc[u]);
+    }
+}
+
 enum SliceMode { SLICE_NORM = 0, SLICE_APPLY_FIRST = 1, SLICE_APPLY = 2, SLICE_PLAIN = 3 };
 
 // slice (+ what the caller does with it).  ref: :684-694, pairwise3d.h:25-27,73-78,
@@ -1266,11 +1342,18 @@ __global__ void __launch_bounds__(kBlock) k_slice(KernelDev kd, CrfDev c, const 
     const size_t fe = (size_t)f * kd.Epad;
     const float *vf = val + (size_t)f * kd.vstride + kd.vbase;
     float t = 0.0f;
-    for (int j = 0; j < kd.D1; ++j) {
-        const int o = kd.offset[fe + (size_t)i * kd.D1 + j];
-        const float wgt = kd.bary[fe + (size_t)i * kd.D1 + j] * kd.alpha;
-        t += wgt * vf[(long)o * L + l];
-    }
+    // (every corner's id and weight, then every gather, before the first use: one round trip per level instead of one per corner)
+    int o[kMaxD + 1];
+    float wgt[kMaxD + 1], x[kMaxD + 1];
+#pragma unroll
+    for (int j = 0; j <= kMaxD; ++j)
+        if (j < kd.D1) { o[j] = kd.offset[fe + (size_t)i * kd.D1 + j]; wgt[j] = kd.bary[fe + (size_t)i * kd.D1 + j] * kd.alpha; }
+#pragma unroll
+    for (int j = 0; j <= kMaxD; ++j)
+        if (j < kd.D1) x[j] = vf[(long)o[j] * L + l];
+#pragma unroll
+    for (int j = 0; j <= kMaxD; ++j)
+        if (j < kd.D1) t += wgt[j] * x[j];
     if (mode == SLICE_NORM) {
         kd.norm[(size_t)f * kd.maxN + i] = 1.0f / (t + 1e-20f);
     } else if (mode == SLICE_PLAIN) {                      // the bare filter: out = compute(in), permutohedral_cpu.h:634-699
@@ -1870,7 +1953,8 @@ static void filter_passes(const KernelDev &kd, int F, int maxV, int L, hipStream
     const float *src = kd.val0;
     float *dst = kd.val1;
     for (int j = 0; j < kd.D1; ++j) {
-        k_blur<<<grid_for((long)maxV * L, F), kBlock, 0, s>>>(kd, src, dst, j, L);
+        if (L >= 4) k_blur4<<<grid_for((long)maxV * ((L + 3) / 4), F), kBlock, 0, s>>>(kd, src, dst, j, L, (L + 3) / 4);
+        else k_blur<<<grid_for((long)maxV * L, F), kBlock, 0, s>>>(kd, src, dst, j, L);
         const float *t = src;
         src = dst;
         dst = const_cast<float *>(t);
