@@ -936,13 +936,17 @@ struct Engine {
 
 }  // namespace
 
+// object API: up to this many points a handle's inputs (count, labels, features) are read by the kernels straight from pinned host
+// memory -- the one-launch frame kernel's range (frame_supported: 4 x 1024 points), where an upload command costs more than the reads
+constexpr int kObjectPinnedMaxPoints = 4096;
+
 struct lccrf_crf {
     Engine eng;
     int N = 0;                      // points of the CRF this handle currently represents
     int cap = 0;                    // capacity it was allocated for (eng.maxN)
     int16_t *stage_i16 = nullptr;   // pinned [cap]
     float *stage_f32 = nullptr;     // pinned [cap*L]
-    int *stage_n = nullptr;         // pinned [1]
+    int *stage_n = nullptr;         // pinned [1]: the point count where the kernels of a SLAM frame read it (no upload command)
     bool label_stage_busy = false;  // a kernel that reads stage_i16 may still be pending
     int16_t *map_pin = nullptr;     // pinned [cap]: the kernels write the MAP labels straight into host memory
 };
@@ -1069,6 +1073,10 @@ int lccrf_create(lccrf_handle *out, int device_id, int n_points, int n_labels)
     // whose every DMA packet costs microseconds of stream time (a parked engine's stream is idle, nothing reads the old value)
     *h->stage_n = n_points;
     h->eng.crf.n_points = h->stage_n;
+    if (n_points > kObjectPinnedMaxPoints) {             // (large frames: every wavefront of every kernel reads the count)
+        HIP_TRY(hipMemcpyAsync(h->eng.npoints_own, h->stage_n, sizeof(int), hipMemcpyHostToDevice, h->eng.stream));
+        h->eng.crf.n_points = h->eng.npoints_own;
+    }
     h->eng.sync_views();
     *out = h;
     return LCCRF_OK;
@@ -1179,7 +1187,12 @@ int lccrf_set_unary_from_label(lccrf_handle h, const int16_t *label, const float
     // No uploads: the 2L+1 energies travel as a kernel argument and the kernel reads the labels from
     // pinned host memory (each tiny DMA command costs ~10 us of stream time; this path is latency-bound).
     if (h->N) memcpy(h->stage_i16, label, (size_t)h->N * sizeof(int16_t));
-    e.defer_unary_from_label(h->stage_i16, conf);         // launched (or folded into the frame kernel) by the first consumer
+    const int16_t *src = h->stage_i16;
+    if (h->N > kObjectPinnedMaxPoints) {                  // (large frames: many kernels, thousands of wavefronts -- see lccrf_add_pairwise)
+        HIP_TRY(hipMemcpyAsync(e.label_own, h->stage_i16, (size_t)h->N * sizeof(int16_t), hipMemcpyHostToDevice, e.stream));
+        src = e.label_own;
+    }
+    e.defer_unary_from_label(src, conf);                  // launched (or folded into the frame kernel) by the first consumer
     h->label_stage_busy = true;
     return LCCRF_OK;
 }
@@ -1196,8 +1209,15 @@ int lccrf_add_pairwise(lccrf_handle h, const float *features, int d, float w)
     KernelState &ks = e.kernels[k];
     const size_t n = (size_t)h->N * d;
     if (n) memcpy(ks.feat_stage, features, n * sizeof(float));   // caller may free `features` right away
-    // the build reads the features once, straight from this pinned buffer (no upload command)
+    // SLAM frames: the build reads the features once, straight from this pinned buffer (no upload command on a latency-bound path).
+    // Frames beyond the one-launch kernel are built by a dozen kernels of thousands of wavefronts, several of which read the
+    // features -- in locality mode as a gather: over PCIe that was 0.12-0.15 ms per kernel on the 76 800-pixel demo -- so those
+    // are uploaded once.
     ks.dev.feat = ks.feat_stage;
+    if (h->N > kObjectPinnedMaxPoints && n) {
+        HIP_TRY(hipMemcpyAsync(ks.feat_own, ks.feat_stage, n * sizeof(float), hipMemcpyHostToDevice, e.stream));
+        ks.dev.feat = ks.feat_own;
+    }
     e.sync_views();
     // The lattice is built lazily, together with any other pending kernel, by the first call that
     // needs it (inference, a step, a parity probe): one launch builds all of them side by side.
