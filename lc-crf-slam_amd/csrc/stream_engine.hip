@@ -679,8 +679,13 @@ __global__ void __launch_bounds__(kBlock) k_eorder(KernelDev kd, const int *__re
 }
 
 // One workgroup per long bucket: bitonic sort of its entries by (code, original id) in place, then out (as k_csr_sort_long).
+constexpr int kSortBitmapWords = 15872;  // 62 KB of LDS: original ids spanning up to ~508 000
 __global__ void __launch_bounds__(kBlock) k_esort_long(KernelDev kd, SortScratch ss)
 {
+    __shared__ unsigned bm[kSortBitmapWords];
+    __shared__ int chunk_base[kBlock];
+    __shared__ int s_mixed, s_min, s_max;
+    const int tid = threadIdx.x;
     const int f = blockIdx.y;
     const int nlong = kd.rowmax[f];
     int *tmp = kd.slot_of + (size_t)f * kd.Epad, *toe = kd.rep + (size_t)f * kd.Epad;
@@ -691,6 +696,49 @@ __global__ void __launch_bounds__(kBlock) k_esort_long(KernelDev kd, SortScratch
         const int b = sorted[kd.Epad + li];
         const int lo = start[b], n = start[b + 1] - lo;
         int *r = tmp + lo, *ro = toe + lo;
+        // A giant bucket is usually ONE vertex (a whole uniformly coloured region of the image demo: 50 000 entries of the same code),
+        // where the order wanted is the order of the original ids: a presence bitmap over the ids' range in LDS, prefix popcounts,
+        // done -- O(n) instead of the 136 global-memory stages of the bitonic network below (0.8 ms per such bucket).
+        if (tid == 0) { s_mixed = 0; s_min = INT_MAX; s_max = INT_MIN; }
+        __syncthreads();
+        {
+            const unsigned long long c0 = code[r[0]];
+            int mn = INT_MAX, mx = INT_MIN, mixed = 0;
+            for (int i = tid; i < n; i += kBlock) {
+                mixed |= code[r[i]] != c0;
+                mn = min(mn, ro[i]);
+                mx = max(mx, ro[i]);
+            }
+            if (mixed) s_mixed = 1;
+            atomicMin(&s_min, mn);
+            atomicMax(&s_max, mx);
+        }
+        __syncthreads();
+        const int base_id = s_min, words = (s_max - s_min) / 32 + 1;
+        if (!s_mixed && words <= kSortBitmapWords) {       // (uniform)
+            for (int w = tid; w < words; w += kBlock) bm[w] = 0u;
+            __syncthreads();
+            for (int i = tid; i < n; i += kBlock) atomicOr(&bm[(ro[i] - base_id) >> 5], 1u << ((ro[i] - base_id) & 31));
+            __syncthreads();
+            const int chunk = (words + kBlock - 1) / kBlock;                 // words per lane
+            int cnt = 0;
+            for (int w = tid * chunk; w < min((tid + 1) * chunk, words); ++w) cnt += __popc(bm[w]);
+            chunk_base[tid] = cnt;
+            __syncthreads();
+            if (tid == 0) {
+                int run = 0;
+                for (int t = 0; t < kBlock; ++t) { const int c = chunk_base[t]; chunk_base[t] = run; run += c; }
+            }
+            __syncthreads();
+            for (int i = tid; i < n; i += kBlock) {
+                const int b = ro[i] - base_id, w = b >> 5;
+                int pos = chunk_base[w / chunk] + __popc(bm[w] & ((1u << (b & 31)) - 1u));
+                for (int u = (w / chunk) * chunk; u < w; ++u) pos += __popc(bm[u]);
+                sorted[lo + pos] = r[i];
+            }
+            __syncthreads();
+            continue;
+        }
         int np2 = 1;
         while (np2 < n) np2 <<= 1;
         for (int k = 2; k <= np2; k <<= 1) {
