@@ -1836,37 +1836,45 @@ __global__ void __launch_bounds__(kBlock) k_softmax(CrfDev c, const float *__res
     exp_and_normalize_row(in + q, out + q, c.L, scale, relax);
 }
 
-// ... for 3 to 24 labels through LDS: a lane's row is L floats apart from its neighbour's, so the direct kernel's loads touch 64 lines
-// each (L = 21, 100 000 points: 68 us for 17 MB).  A wavefront moves the rows of its 64 points as ONE contiguous block -- coalesced --
-// into LDS, every lane works on its own row there (the same row function, the same order of operations), and the block goes back
-// the same way.
-constexpr int kSoftmaxMaxL = 24;            // (48 KB of LDS per workgroup)
-__global__ void __launch_bounds__(kBlock) k_softmax_lds(CrfDev c, const float *__restrict__ in, float *__restrict__ out, float scale, float relax)
+// ... for 3 to 32 labels with a LANE PER (point, label): a wavefront takes 64 / L consecutive points, whose rows are one contiguous
+// block (coalesced loads and stores, no staging); the row maximum and the row sum are formed by every lane of the row from the
+// others' values (__shfl) -- the sum in label order 0 .. L-1, one add at a time, as densecrf3d.h:80-84 forms it; each lane's
+// exponential is computed once instead of twice (the same argument gives the same bits).  The lane-per-point kernel above reads
+// rows L floats apart (64 lines per load) and runs 2 L exponentials per lane: L = 21 x 76 800 points 34 us, through LDS 26, this ~5.
+constexpr int kSoftmaxMaxL = 32;
+__global__ void __launch_bounds__(kBlock) k_softmax_rows(CrfDev c, const float *__restrict__ in, float *__restrict__ out, float scale, float relax)
 {
-    extern __shared__ float tile[];                       // [waves][2][64 * L]: input rows, output rows
     const int f = blockIdx.y, L = c.L;
     const int N = c.n_points[f];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int i0 = blockIdx.x * kBlock + wave * 64;       // the wavefront's first point
-    if (i0 >= N) return;
-    const int n = min(64, N - i0) * L;                    // floats of this wavefront's block
-    float *tin = tile + (size_t)wave * 2 * 64 * L, *tout = tin + 64 * L;
-    const size_t q0 = ((size_t)f * c.maxN + i0) * L;
-    for (int k = lane; k < n; k += 64) tin[k] = in[q0 + k];
-    if (relax != 1.0f)
-        for (int k = lane; k < n; k += 64) tout[k] = out[q0 + k];       // the blend reads the old out (densecrf3d.h:91-94)
-    __builtin_amdgcn_wave_barrier();
-    if (i0 + lane < N) exp_and_normalize_row(tin + lane * L, tout + lane * L, L, scale, relax);
-    __builtin_amdgcn_wave_barrier();
-    for (int k = lane; k < n; k += 64) out[q0 + k] = tout[k];
+    const int rpw = 64 / L;                               // rows per wavefront
+    const int lane = threadIdx.x & 63, wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    const int row = lane / L, j = lane - row * L, i = wave * rpw + row;
+    const bool live = row < rpw && i < N;
+    const size_t q = ((size_t)f * c.maxN + (live ? i : 0)) * L + (live ? j : 0);
+    const float s = live ? scale * in[q] : 0.0f;
+    const int first = row * L;                            // the row's first lane
+    float mx = __shfl(s, first, 64);
+    for (int t = 1; t < L; ++t) {
+        const float v = __shfl(s, first + t, 64);
+        if (mx < v) mx = v;
+    }
+    const float e = fast_exp(s - mx);
+    float tt = 0;
+    for (int t = 0; t < L; ++t) tt += __shfl(e, first + t, 64);
+    if (!live) return;
+    const float v = e / tt;
+    if (relax == 1) out[q] = v;
+    else out[q] = (1 - relax) * out[q] + relax * v;
 }
 
 inline void launch_softmax(const CrfDev &c, const float *in, float *out, float scale, float relax, hipStream_t s)
 {
-    if (c.L >= 3 && c.L <= kSoftmaxMaxL)
-        k_softmax_lds<<<grid_for(c.maxN, c.F), kBlock, (size_t)(kBlock / 64) * 2 * 64 * c.L * sizeof(float), s>>>(c, in, out, scale, relax);
-    else
+    if (c.L >= 3 && c.L <= kSoftmaxMaxL) {
+        const int per_block = (kBlock / 64) * (64 / c.L);   // points per workgroup
+        k_softmax_rows<<<dim3((unsigned)((c.maxN + per_block - 1) / per_block), (unsigned)c.F), kBlock, 0, s>>>(c, in, out, scale, relax);
+    } else {
         k_softmax<<<grid_for(c.maxN, c.F), kBlock, 0, s>>>(c, in, out, scale, relax);
+    }
 }
 
 // next = -unary (DenseCRF3D::stepInit, densecrf3d.h:154-158) into an arbitrary buffer
