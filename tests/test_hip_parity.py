@@ -778,6 +778,25 @@ def test_sorted_build_falls_back_to_the_hash_when_codes_overflow(po, wl, d, spre
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("N", [4096, 4097, 6000])
+@pytest.mark.parametrize("labels", [False, True])
+def test_object_api_inputs_beyond_the_frame_kernel_are_uploaded(po, wl, N, labels):
+    """Up to 4096 points a handle's kernels read the point count, the labels and the features straight from pinned host memory (the
+    one-launch kernel's range); beyond, they are uploaded once (a dozen kernels of thousands of wavefronts would each cross PCIe).
+    Either side of the line, with labels and with raw unaries, twice on a recycled handle with other inputs: the oracle's bits."""
+    for seed in (5, 6):
+        pb = wl.generic_problem(N, [2, 3], 2, seed=seed, spread=2.0)
+        if labels:
+            pb = dict(pb, label=np.random.default_rng(seed).integers(-1, 2, N).astype(np.int16), conf=np.float32([0.8, 0.6]))
+            del pb["unary"]
+        h, o = cc.setup(pkg.DenseCRFHIP, pb), cc.setup(po.OracleCRF, pb)
+        h.inference(3, True); o.inference_native(3, True)
+        assert cc.same_bits(h.probability(), o.probability()) and np.array_equal(h.map(), o.map()), (N, seed)
+        assert cc.same_bits(h.unary(), o.unary())
+        h.close(); o.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("d_list,labels", [([6], False), ([3, 2], True), ([5], True)])
 def test_object_api_large_frame_runs_inference_in_locality_mode(po, wl, d_list, labels):
     """BASELINE config 5 through the reference's OWN interface: a DenseCRF of >= 8192 points.  `inference()` on such a handle runs in
