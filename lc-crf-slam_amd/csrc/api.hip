@@ -138,6 +138,7 @@ struct Engine {
     int16_t *label_own = nullptr;
     int *V_host = nullptr;             // pinned [K][Fcap]
     int *row_host = nullptr;           // pinned [K][Fcap]
+    int *long_host = nullptr;          // pinned [K][Fcap]: rows beyond kLongRowMin entries per frame (KernelDev::longcnt)
     std::vector<KernelState> kernels;
     std::vector<KernelState> spare;    // allocated lattices of earlier uses of this (recycled) engine
     std::vector<KernelDev> kdevs;      // contiguous copy handed to the launchers
@@ -288,6 +289,7 @@ struct Engine {
         if ((rc = mem.alloc(&label_own, (size_t)Fcap * maxN))) return rc;
         if ((rc = mem.alloc_pinned(&V_host, (size_t)LCCRF_MAX_KERNELS * Fcap))) return rc;
         if ((rc = mem.alloc_pinned(&row_host, (size_t)LCCRF_MAX_KERNELS * Fcap))) return rc;
+        if ((rc = mem.alloc_pinned(&long_host, (size_t)LCCRF_MAX_KERNELS * Fcap))) return rc;
         if ((rc = mem.alloc_pinned(&late_status, 1))) return rc;
         *late_status = 0;
         if ((rc = mem.alloc_pinned(&done_word, 1))) return rc;
@@ -397,7 +399,8 @@ struct Engine {
             if ((rc = mem.alloc(&k.nbrc_base, Fc * k.D1 * (E / kNbrcBlock + 1) * 2))) return rc;
         }
         if ((rc = mem.alloc(&k.rowptr, Fz * (E + 1)))) return rc;
-        if ((rc = mem.alloc(&k.longrow, Fz * (kLongRowCap + 1)))) return rc;
+        if ((rc = mem.alloc(&k.longrow, Fz * kLongRowCap))) return rc;
+        if ((rc = mem.alloc(&k.longcnt, Fz))) return rc;
         if ((rc = mem.alloc(&k.csr_pt, Fz * E))) return rc;
         if ((rc = mem.alloc(&k.csr_w, Fz * E))) return rc;
         if ((rc = mem.alloc(&k.csr_pos, Fz * E))) return rc;
@@ -543,6 +546,7 @@ struct Engine {
                 launch_norm(kdevs[k], crf, kernels[k].maxV, stream);
                 HIP_TRY(hipMemcpyAsync(V_host + (size_t)k * Fcap, kernels[k].dev.V, sizeof(int) * F, hipMemcpyDeviceToHost, stream));
                 HIP_TRY(hipMemcpyAsync(row_host + (size_t)k * Fcap, kernels[k].dev.rowmax, sizeof(int) * F, hipMemcpyDeviceToHost, stream));
+                HIP_TRY(hipMemcpyAsync(long_host + (size_t)k * Fcap, kernels[k].dev.longcnt, sizeof(int) * F, hipMemcpyDeviceToHost, stream));
                 if (kernels[k].dev.fast0_ok)
                     HIP_TRY(hipMemcpyAsync(ndist_host + (size_t)k * kNdistAxes, kernels[k].dev.ndist, sizeof(int) * kNdistAxes, hipMemcpyDeviceToHost, stream));
             }
@@ -621,11 +625,16 @@ struct Engine {
                 if (kd.splat_passes == 2 && kd.nbr2 && kd.D1 > 3) { kd.splat_passes = 1; kd.splat_halo = 1; }
                 if (kd.splat_passes >= 2) kd.splat_block = kd.splat_halo * 8 <= 256 ? 256 : kd.splat_halo * 8 <= 512 ? 512 : 1024;
             }
-            int m = 0, r = 0;
+            int m = 0, r = 0, nlong = 0;
             for (int f = 0; f < F; ++f) {
                 m = std::max(m, V_host[k * Fcap + f]);
                 r = std::max(r, row_host[k * Fcap + f]);
+                if (kd.longrow_ok) nlong = std::max(nlong, long_host[k * Fcap + f]);
             }
+            // a coarse kernel over many points (listed rows, or more than ~4 entries per row on average): the row-walking splat with
+            // its loads up front + a workgroup per listed row, no blur pass in the splat
+            const int NAr = activeN > 0 ? activeN : maxN;
+            kd.long_mode = kd.longrow_ok && (nlong > 0 || (long)NAr * kd.D1 > 4L * std::max(m, 1));
             kernels[k].maxV = m;
             kernels[k].maxRow = r;
         }

@@ -82,9 +82,11 @@ struct KernelDev {
     int splat_halo;       // ... the halo that takes on each side of a window (1 + distance of axis 1 [+ distance of axis 2])
     int splat_block;      // ... and the window (256 / 512 / 1024 vertices: 256 lanes x 1 / 2 / 4)
     int *rowptr;          // [F][Epad+1]       CSR: vertex -> range of splat contributions
-    int *longrow;         // [F][kLongRowCap+1] [0] = number of rows longer than kLongRowMin, then their vertices (any order); a count
-                          //   beyond kLongRowCap = "not listed": every row is summed in line
+    int *longcnt;         // [F]               number of rows longer than kLongRowMin; beyond kLongRowCap = "not listed": every row in line
+    int *longrow;         // [F][kLongRowCap]  ... and their vertices (any order)
     int longrow_ok;       // the list describes the lattices now in HBM (the streaming build writes it; k_build_small does not)
+    int long_mode;        // two-label splat: this kernel has listed rows or rows of more than ~4 entries on average (a coarse kernel over many
+                          //   points): k_splat2l + k_splat_long instead of the fused splat (set by the host once the sizes are known)
     int *csr_pt;          // [F][Epad]         contributing point, ascending within a row
     float *csr_w;         // [F][Epad]         its barycentric weight
     int *csr_pos;         // [F][Epad]         entry -> its position in csr_pt/csr_w (inverse of the row ordering)

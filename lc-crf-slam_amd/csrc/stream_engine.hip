@@ -1171,7 +1171,7 @@ __global__ void __launch_bounds__(kBlock) k_splat(KernelDev kd, const float *__r
     const int v = idx / L, l = idx - v * L;
     const size_t fe = (size_t)f * kd.Epad, f1 = (size_t)f * (kd.Epad + 1);
     const int s = kd.rowptr[f1 + v], t = kd.rowptr[f1 + v + 1];
-    if (kd.longrow_ok && t - s > kLongRowMin && kd.longrow[(size_t)f * (kLongRowCap + 1)] <= kLongRowCap) return;   // k_splat_long's
+    if (kd.longrow_ok && t - s > kLongRowMin && kd.longcnt[f] <= kLongRowCap) return;   // k_splat_long's
     const float *x = in ? in + (size_t)f * in_stride : nullptr;
     float acc = 0.0f;
     int p = s;
@@ -1205,7 +1205,7 @@ __global__ void __launch_bounds__(kBlock) k_splat4(KernelDev kd, const float *__
     const int v = idx / C, l = (idx - v * C) * 4, nl = min(4, L - l);
     const size_t fe = (size_t)f * kd.Epad, f1 = (size_t)f * (kd.Epad + 1);
     const int s = kd.rowptr[f1 + v], t = kd.rowptr[f1 + v + 1];
-    if (kd.longrow_ok && t - s > kLongRowMin && kd.longrow[(size_t)f * (kLongRowCap + 1)] <= kLongRowCap) return;   // k_splat_long's
+    if (kd.longrow_ok && t - s > kLongRowMin && kd.longcnt[f] <= kLongRowCap) return;   // k_splat_long's
     const float *x = in + (size_t)f * in_stride + l;
     float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     constexpr int U = 8;
@@ -1248,15 +1248,15 @@ __global__ void __launch_bounds__(kBlock) k_splat_long(KernelDev kd, const float
 {
     __shared__ float prod[2][kLongTile];
     const int f = blockIdx.y;
-    const int *lr = kd.longrow + (size_t)f * (kLongRowCap + 1);
-    const int n = lr[0];
+    const int *lr = kd.longrow + (size_t)f * kLongRowCap;
+    const int n = kd.longcnt[f];
     if (n > kLongRowCap) return;
     const size_t fe = (size_t)f * kd.Epad, f1 = (size_t)f * (kd.Epad + 1);
     const float *x = in ? in + (size_t)f * in_stride : nullptr;
     const int tid = threadIdx.x, ec = kLongTile / L;      // entries per tile
     constexpr int kLoaders = kBlock - 64;                 // wavefront 0 adds, the other three load: the tile being added and the tile
     for (int i = blockIdx.x; i < n; i += gridDim.x) {     // being loaded are different halves of `prod`, one barrier per tile
-        const int v = lr[1 + i];
+        const int v = lr[i];
         const int s = kd.rowptr[f1 + v], t = kd.rowptr[f1 + v + 1];
         const int ntiles = (t - s + ec - 1) / ec;
         float acc = 0.0f;
@@ -1314,9 +1314,8 @@ __global__ void __launch_bounds__(kBlock) k_long_rows(KernelDev kd)
     if (v >= kd.V[f]) return;
     const size_t f1 = (size_t)f * (kd.Epad + 1);
     if (kd.rowptr[f1 + v + 1] - kd.rowptr[f1 + v] <= kLongRowMin) return;
-    int *lr = kd.longrow + (size_t)f * (kLongRowCap + 1);
-    const int i = atomicAdd(&lr[0], 1);
-    if (i < kLongRowCap) lr[1 + i] = v;
+    const int i = atomicAdd(&kd.longcnt[f], 1);
+    if (i < kLongRowCap) kd.longrow[(size_t)f * kLongRowCap + i] = v;
 }
 
 // the generic splat: rows in line, the long ones by a workgroup each
@@ -1443,6 +1442,42 @@ __device__ __forceinline__ float2 lds_or_zero(bool ok, const float2 *p)
     float2 r = make_float2(0.0f, 0.0f);                   // what the absent vertex's slot holds
     if (ok) r = *p;
     return r;
+}
+
+// The two-label splat of a COARSE kernel over many points (KernelDev::long_mode: a 2-D smoothness kernel on 100 000 points has 2000
+// vertices and rows of 150 entries on average): eight entries' loads per round trip, the adds in order; the listed rows are left to
+// k_splat_long (L = 2: the same value layout).  8 frames of C5 never come here (1.2 entries per row).
+__global__ void __launch_bounds__(kBlock) k_splat2l(KernelDev kd, const float2 *__restrict__ in, int in_stride, int F, XcdMap nb)
+{
+    const FrameBlock fb = frame_block(nb);
+    const int f = fb.f;
+    if (f >= F) return;
+    const int v = fb.bx * (int)blockDim.x + threadIdx.x;
+    if (v >= kd.V[f]) return;
+    const size_t fe = (size_t)f * kd.Epad, f1 = (size_t)f * (kd.Epad + 1);
+    const int s = kd.rowptr[f1 + v], t = kd.rowptr[f1 + v + 1];
+    if (kd.longrow_ok && t - s > kLongRowMin && kd.longcnt[f] <= kLongRowCap) return;   // k_splat_long's
+    const float2 *x = in + (size_t)f * in_stride;
+    float a0 = 0.0f, a1 = 0.0f;
+    int p = s;
+    for (; p + 8 <= t; p += 8) {
+        int pt[8];
+        float w[8];
+        float2 q[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { pt[i] = kd.csr_pt[fe + p + i]; w[i] = kd.csr_w[fe + p + i]; }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) q[i] = x[pt[i]];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { a0 += w[i] * q[i].x; a1 += w[i] * q[i].y; }
+    }
+    for (; p < t; ++p) {
+        const float w = kd.csr_w[fe + p];
+        const float2 q = x[kd.csr_pt[fe + p]];
+        a0 += w * q.x;
+        a1 += w * q.y;
+    }
+    reinterpret_cast<float2 *>(kd.val0 + (size_t)f * kd.vstride + kd.vbase)[v] = make_float2(a0, a1);
 }
 
 // BLUR0 (sorted build, KernelDev::fast0_ok): the FIRST blur pass rides along.  Axis 0 is the fastest coordinate of the row-major
@@ -1983,7 +2018,7 @@ void build_kernel_d(const KernelDev &kd, const CrfDev &c, hipStream_t s, const S
     }
     (void)hipMemsetAsync(kd.rowmax, 0, (size_t)F * sizeof(int), s);
     if (kd.Epad < 65535) k_row_max<<<grid_for(kd.Epad, F), kBlock, 0, s>>>(kd);   // only the one-workgroup engines ask (u16 ids)
-    (void)hipMemsetAsync(kd.longrow, 0, (size_t)F * (kLongRowCap + 1) * sizeof(int), s);
+    (void)hipMemsetAsync(kd.longcnt, 0, (size_t)F * sizeof(int), s);
     k_long_rows<<<grid_for(kd.Epad, F), kBlock, 0, s>>>(kd);
 }
 
@@ -2064,7 +2099,7 @@ void launch_step_stream(const CrfDev &c, const KernelDev *kds, const int *maxV, 
             const bool pairs = pair_fuse(c.F, maxV[k]);
             // sorted build, one pass per launch: the first pass (axis 0 = the code's fastest coordinate) rides in the splat
             static const bool no_sb = getenv("LCCRF_NO_SPLAT_BLUR") != nullptr;               // A/B switch: same results either way
-            const int j0 = (kd.vorder && kd.fast0_ok && !no_sb) ? std::max(kd.splat_passes, 1) : 0;   // passes the splat takes along
+            const int j0 = (kd.vorder && kd.fast0_ok && !no_sb && !kd.long_mode) ? std::max(kd.splat_passes, 1) : 0;   // passes the splat takes along
             if (j0 >= 2) {
                 const int B = kd.splat_block, core = B - 2 * kd.splat_halo;
                 const float2 *q2 = reinterpret_cast<const float2 *>(c.Q);
@@ -2083,6 +2118,10 @@ void launch_step_stream(const CrfDev &c, const KernelDev *kds, const int *maxV, 
             } else if (j0 == 1) {
                 const dim3 g = grid_xcd(((long)maxV[k] + blk - 3) / (blk - 2) * blk, c.F, &nb, blk);
                 k_splat2<true><<<g, blk, 0, s>>>(kd, reinterpret_cast<const float2 *>(c.Q), c.maxN, c.F, nb);
+            } else if (kd.long_mode) {                    // a coarse kernel: long rows
+                const dim3 g = grid_xcd(maxV[k], c.F, &nb, kBlock);
+                k_splat2l<<<g, kBlock, 0, s>>>(kd, reinterpret_cast<const float2 *>(c.Q), c.maxN, c.F, nb);
+                if (kd.longrow_ok) k_splat_long<<<dim3((unsigned)std::max(256 / std::max(c.F, 1), 8), (unsigned)c.F), kBlock, 0, s>>>(kd, c.Q, c.maxN * 2, 2);
             } else {
                 const dim3 g = grid_xcd(maxV[k], c.F, &nb, blk);
                 k_splat2<false><<<g, blk, 0, s>>>(kd, reinterpret_cast<const float2 *>(c.Q), c.maxN, c.F, nb);
