@@ -635,6 +635,7 @@ struct Engine {
             // its loads up front + a workgroup per listed row, no blur pass in the splat
             const int NAr = activeN > 0 ? activeN : maxN;
             kd.long_mode = kd.longrow_ok && (nlong > 0 || (long)NAr * kd.D1 > 4L * std::max(m, 1));
+            if (kd.long_mode && (long)NAr * kd.D1 >= 16L * std::max(m, 1)) kd.long_mode = 2;       // ... a wavefront per vertex from ~16 entries per row
             kernels[k].maxV = m;
             kernels[k].maxRow = r;
         }

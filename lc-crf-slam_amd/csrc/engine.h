@@ -86,7 +86,8 @@ struct KernelDev {
     int *longrow;         // [F][kLongRowCap]  ... and their vertices (any order)
     int longrow_ok;       // the list describes the lattices now in HBM (the streaming build writes it; k_build_small does not)
     int long_mode;        // two-label splat: this kernel has listed rows or rows of more than ~4 entries on average (a coarse kernel over many
-                          //   points): k_splat2l + k_splat_long instead of the fused splat (set by the host once the sizes are known)
+                          //   points): k_splat2l (1) or k_splat2v (2: ~16 entries per row and more) + k_splat_long instead of the fused splat (set by
+                          //   the host once the sizes are known)
     int *csr_pt;          // [F][Epad]         contributing point, ascending within a row
     float *csr_w;         // [F][Epad]         its barycentric weight
     int *csr_pos;         // [F][Epad]         entry -> its position in csr_pt/csr_w (inverse of the row ordering)

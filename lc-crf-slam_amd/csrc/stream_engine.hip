@@ -715,7 +715,7 @@ __global__ void __launch_bounds__(kBlock) k_esort_long(KernelDev kd, SortScratch
         }
         __syncthreads();
         const int base_id = s_min, words = (s_max - s_min) / 32 + 1;
-        if (!s_mixed && words <= kSortBitmapWords) {       // (uniform)
+        if (!s_mixed && words <= kSortBitmapWords && n >= 1024) {       // (uniform; below ~1000 entries the network is cheaper than a walk over the span's words)
             for (int w = tid; w < words; w += kBlock) bm[w] = 0u;
             __syncthreads();
             for (int i = tid; i < n; i += kBlock) atomicOr(&bm[(ro[i] - base_id) >> 5], 1u << ((ro[i] - base_id) & 31));
@@ -1480,6 +1480,39 @@ __global__ void __launch_bounds__(kBlock) k_splat2l(KernelDev kd, const float2 *
     reinterpret_cast<float2 *>(kd.val0 + (size_t)f * kd.vstride + kd.vbase)[v] = make_float2(a0, a1);
 }
 
+// ... and with rows of tens of entries on average (long_mode 2) a WAVEFRONT per vertex: its 64 lanes load 64 entries' products in one
+// round trip (coalesced index / weight reads, one gather), then every lane adds them in order off the others' registers (a uniform
+// lane index: v_readlane) -- two interleaved chains, one per label.  2000 vertices x 150 entries: 45 -> ~6 us.
+__global__ void __launch_bounds__(kBlock) k_splat2v(KernelDev kd, const float2 *__restrict__ in, int in_stride, int F, XcdMap nb)
+{
+    const FrameBlock fb = frame_block(nb);
+    const int f = fb.f;
+    if (f >= F) return;
+    const int lane = threadIdx.x & 63;
+    const int v = fb.bx * ((int)blockDim.x / 64) + (threadIdx.x >> 6);      // (grid: one wavefront per vertex)
+    if (v >= kd.V[f]) return;
+    const size_t fe = (size_t)f * kd.Epad, f1 = (size_t)f * (kd.Epad + 1);
+    const int s = kd.rowptr[f1 + v], t = kd.rowptr[f1 + v + 1];
+    if (kd.longrow_ok && t - s > kLongRowMin && kd.longcnt[f] <= kLongRowCap) return;   // k_splat_long's
+    const float2 *x = in + (size_t)f * in_stride;
+    float a0 = 0.0f, a1 = 0.0f;
+    for (int base = s; base < t; base += 64) {
+        const int p = base + lane, m = min(64, t - base);
+        float p0 = 0.0f, p1 = 0.0f;
+        if (p < t) {
+            const float w = kd.csr_w[fe + p];
+            const float2 q = x[kd.csr_pt[fe + p]];
+            p0 = w * q.x;
+            p1 = w * q.y;
+        }
+        for (int u = 0; u < m; ++u) {
+            a0 += __shfl(p0, u, 64);
+            a1 += __shfl(p1, u, 64);
+        }
+    }
+    if (lane == 0) reinterpret_cast<float2 *>(kd.val0 + (size_t)f * kd.vstride + kd.vbase)[v] = make_float2(a0, a1);
+}
+
 // BLUR0 (sorted build, KernelDev::fast0_ok): the FIRST blur pass rides along.  Axis 0 is the fastest coordinate of the row-major
 // vertex code, so a vertex's axis-0 neighbours are v - 1 and v + 1 (or absent): the workgroup's row sums go to LDS -- every thread
 // sums one row, the first and the last only for their neighbours' sake (blockDim - 2 results per workgroup) -- and
@@ -2119,8 +2152,13 @@ void launch_step_stream(const CrfDev &c, const KernelDev *kds, const int *maxV, 
                 const dim3 g = grid_xcd(((long)maxV[k] + blk - 3) / (blk - 2) * blk, c.F, &nb, blk);
                 k_splat2<true><<<g, blk, 0, s>>>(kd, reinterpret_cast<const float2 *>(c.Q), c.maxN, c.F, nb);
             } else if (kd.long_mode) {                    // a coarse kernel: long rows
-                const dim3 g = grid_xcd(maxV[k], c.F, &nb, kBlock);
-                k_splat2l<<<g, kBlock, 0, s>>>(kd, reinterpret_cast<const float2 *>(c.Q), c.maxN, c.F, nb);
+                if (kd.long_mode == 2) {                  // (a wavefront per vertex: grid_xcd counts workgroups of kBlock / 64 vertices)
+                    const dim3 g = grid_xcd((long)maxV[k] * 64, c.F, &nb, kBlock);
+                    k_splat2v<<<g, kBlock, 0, s>>>(kd, reinterpret_cast<const float2 *>(c.Q), c.maxN, c.F, nb);
+                } else {
+                    const dim3 g = grid_xcd(maxV[k], c.F, &nb, kBlock);
+                    k_splat2l<<<g, kBlock, 0, s>>>(kd, reinterpret_cast<const float2 *>(c.Q), c.maxN, c.F, nb);
+                }
                 if (kd.longrow_ok) k_splat_long<<<dim3((unsigned)std::max(256 / std::max(c.F, 1), 8), (unsigned)c.F), kBlock, 0, s>>>(kd, c.Q, c.maxN * 2, 2);
             } else {
                 const dim3 g = grid_xcd(maxV[k], c.F, &nb, blk);
