@@ -778,6 +778,37 @@ def test_sorted_build_falls_back_to_the_hash_when_codes_overflow(po, wl, d, spre
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("L,dims,F", [(2, [2], 1), (2, [5, 2], 3), (5, [3], 1), (21, [2, 5], 2), (1 + 2, [2], 8)])
+def test_streaming_engine_long_rows_go_to_a_workgroup_each(po, wl, L, dims, F):
+    """A coarse kernel over many points, and a third of the points IDENTICAL: rows of tens of entries everywhere and a few of thousands
+    (the reference's image demo has them: uniformly coloured regions).  The adds of a row go one by one in point order (quirk Q6);
+    the loads do not: rows beyond 512 entries are listed by the build and summed by a workgroup each (k_splat_long: products of a
+    tile in LDS, one lane per label adds its column), the others by k_splat / k_splat4 with their loads up front, or -- two labels
+    -- by k_splat2l / k_splat2v; the sorted build orders a giant vertex's bucket by a bitmap over the original ids.  Ragged frames,
+    locality mode on and off (8300 / 6000 points): the oracle's bits."""
+    for N in (8300, 6000):
+        pb = wl.generic_problem(N, dims, L, seed=77 + L, spread=2.0)
+        for k, (f, w) in enumerate(pb["kernels"]):
+            f[: N // 3] = f[5]                               # one giant vertex (per remainder class) + its neighbourhood
+            f[N // 3: N // 2] = np.round(f[N // 3: N // 2])  # ... and many shared cells
+        sizes = [N - 211 * i for i in range(F)]
+        b = pkg.BatchCRF(F, N, L, dims, [float(w) for _, w in pb["kernels"]])
+        b.set_engine(1)
+        b.set_inputs_host(sizes, [np.repeat(f[None], F, 0) for f, _ in pb["kernels"]], unary=np.repeat(pb["unary"][None], F, 0))
+        b.build(); b.inference(3, True, relax=0.9)
+        Q, M = b.probability(), b.map()
+        for i in sorted(set([0, F - 1])):
+            n = sizes[i]
+            q = dict(pb, N=n, unary=pb["unary"][:n], kernels=[(f[:n], w) for f, w in pb["kernels"]])
+            o = cc.setup(po.OracleCRF, q)
+            o.inference_native(3, True, 0.9)
+            assert all(int(b.lattice_sizes(k)[i]) == o.kernel(k)["V"] for k in range(len(dims))), (N, i)
+            assert cc.same_bits(Q[i, :n], o.probability()) and np.array_equal(M[i, :n], o.map()), (N, i)
+            o.close()
+        b.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("N", [4096, 4097, 6000])
 @pytest.mark.parametrize("labels", [False, True])
 def test_object_api_inputs_beyond_the_frame_kernel_are_uploaded(po, wl, N, labels):
