@@ -1908,7 +1908,8 @@ __global__ void __launch_bounds__(kBlock) k_softmax(CrfDev c, const float *__res
 // block (coalesced loads and stores, no staging); the row maximum and the row sum are formed by every lane of the row from the
 // others' values (__shfl) -- the sum in label order 0 .. L-1, one add at a time, as densecrf3d.h:80-84 forms it; each lane's
 // exponential is computed once instead of twice (the same argument gives the same bits).  The lane-per-point kernel above reads
-// rows L floats apart (64 lines per load) and runs 2 L exponentials per lane: L = 21 x 76 800 points 34 us, through LDS 26, this ~5.
+// rows L floats apart (64 lines per load) and runs 2 L exponentials per lane: L = 21 x 76 800 points 34 us, through LDS 26, this 24
+// (L = 8: 7 us) -- 2 L lane-indexed reads per wavefront through the LDS crossbar are what is left.
 constexpr int kSoftmaxMaxL = 32;
 __global__ void __launch_bounds__(kBlock) k_softmax_rows(CrfDev c, const float *__restrict__ in, float *__restrict__ out, float scale, float relax)
 {
@@ -1921,14 +1922,26 @@ __global__ void __launch_bounds__(kBlock) k_softmax_rows(CrfDev c, const float *
     const size_t q = ((size_t)f * c.maxN + (live ? i : 0)) * L + (live ? j : 0);
     const float s = live ? scale * in[q] : 0.0f;
     const int first = row * L;                            // the row's first lane
+    // (the others' values eight at a time: a lane-indexed read is an LDS-crossbar round trip of ~100 cycles)
     float mx = __shfl(s, first, 64);
-    for (int t = 1; t < L; ++t) {
-        const float v = __shfl(s, first + t, 64);
-        if (mx < v) mx = v;
+    for (int t0 = 1; t0 < L; t0 += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = __shfl(s, first + min(t0 + u, L - 1), 64);
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (t0 + u < L && mx < v[u]) mx = v[u];
     }
-    const float e = fast_exp(s - mx);
+    const float e = fast_exp_nonpos(s - mx);              // (value - row maximum <= 0: the branch-free form, same bits)
     float tt = 0;
-    for (int t = 0; t < L; ++t) tt += __shfl(e, first + t, 64);
+    for (int t0 = 0; t0 < L; t0 += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = __shfl(e, first + min(t0 + u, L - 1), 64);
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (t0 + u < L) tt += v[u];
+    }
     if (!live) return;
     const float v = e / tt;
     if (relax == 1) out[q] = v;
