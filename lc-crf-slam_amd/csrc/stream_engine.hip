@@ -1246,14 +1246,16 @@ __global__ void __launch_bounds__(kBlock) k_splat4(KernelDev kd, const float *__
 constexpr int kLongTile = 8192;          // products per tile (floats); two tiles in LDS
 __global__ void __launch_bounds__(kBlock) k_splat_long(KernelDev kd, const float *__restrict__ in, int in_stride, int L)
 {
-    __shared__ float prod[2][kLongTile];
+    __shared__ __attribute__((aligned(16))) float prod[2][kLongTile];
     const int f = blockIdx.y;
     const int *lr = kd.longrow + (size_t)f * kLongRowCap;
     const int n = kd.longcnt[f];
     if (n > kLongRowCap) return;
     const size_t fe = (size_t)f * kd.Epad, f1 = (size_t)f * (kd.Epad + 1);
     const float *x = in ? in + (size_t)f * in_stride : nullptr;
-    const int tid = threadIdx.x, ec = kLongTile / L;      // entries per tile
+    // a tile holds ec entries of every label, label-major: prod[l * ecp + e] (ecp = ec + 4, a multiple of 4: the adder reads its
+    // label's column four entries per 16-byte LDS load; the loaders' stores land ecp words apart -- a few ways of bank conflict)
+    const int tid = threadIdx.x, ec = (kLongTile / L - 4) & ~3, ecp = ec + 4;
     constexpr int kLoaders = kBlock - 64;                 // wavefront 0 adds, the other three load: the tile being added and the tile
     for (int i = blockIdx.x; i < n; i += gridDim.x) {     // being loaded are different halves of `prod`, one barrier per tile
         const int v = lr[i];
@@ -1267,38 +1269,36 @@ __global__ void __launch_bounds__(kBlock) k_splat_long(KernelDev kd, const float
                 float *dst = prod[(k + 1) & 1];
                 int idx = tid - 64;
                 for (; idx + 7 * kLoaders < m; idx += 8 * kLoaders) {        // eight products per lane and round trip
-                    int pt[8], l[8];
+                    int pt[8], l[8], e[8];
                     float w[8], xv[8];
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
-                        const int e = (idx + u * kLoaders) / L;
-                        l[u] = idx + u * kLoaders - e * L;
-                        pt[u] = kd.csr_pt[fe + p0 + e];
-                        w[u] = kd.csr_w[fe + p0 + e];
+                        e[u] = (idx + u * kLoaders) / L;
+                        l[u] = idx + u * kLoaders - e[u] * L;
+                        pt[u] = kd.csr_pt[fe + p0 + e[u]];
+                        w[u] = kd.csr_w[fe + p0 + e[u]];
                     }
 #pragma unroll
                     for (int u = 0; u < 8; ++u) xv[u] = x ? x[(size_t)pt[u] * L + l[u]] : 1.0f;
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) dst[idx + u * kLoaders] = w[u] * xv[u];
+                    for (int u = 0; u < 8; ++u) dst[l[u] * ecp + e[u]] = w[u] * xv[u];
                 }
                 for (; idx < m; idx += kLoaders) {
                     const int e = idx / L, l = idx - e * L;
                     const float xv = x ? x[(size_t)kd.csr_pt[fe + p0 + e] * L + l] : 1.0f;
-                    dst[idx] = kd.csr_w[fe + p0 + e] * xv;
+                    dst[l * ecp + e] = kd.csr_w[fe + p0 + e] * xv;
                 }
             } else if (k >= 0 && tid < L) {               // add tile k: label tid's column, top to bottom
                 const int p0 = s + k * ec;
                 const int m = min(ec, t - p0);
-                const float *src = prod[k & 1] + tid;
+                const float *src = prod[k & 1] + tid * ecp;
                 int e = 0;
                 for (; e + 8 <= m; e += 8) {
-                    float q[8];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) q[u] = src[(e + u) * L];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) acc += q[u];
+                    const float4 q0 = *reinterpret_cast<const float4 *>(src + e), q1 = *reinterpret_cast<const float4 *>(src + e + 4);
+                    acc += q0.x; acc += q0.y; acc += q0.z; acc += q0.w;
+                    acc += q1.x; acc += q1.y; acc += q1.z; acc += q1.w;
                 }
-                for (; e < m; ++e) acc += src[e * L];
+                for (; e < m; ++e) acc += src[e];
             }
             __syncthreads();
         }
