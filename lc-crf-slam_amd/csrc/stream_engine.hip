@@ -1597,10 +1597,27 @@ __global__ void __launch_bounds__(LANES) k_splat2w(KernelDev kd, const float2 *_
             if (P > 2) o2[u] = off2[v];
         }
     }
+    // the first entry of each of the lane's U rows together (rows hold 1.2 entries on average: most are done after this), then
+    // whatever is left of each row in order
+    int pt0[U];
+    float w0[U];
+    float2 q0[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const bool any = s[u] < t[u];
+        pt0[u] = any ? kd.csr_pt[fe + s[u]] : 0;
+        w0[u] = any ? kd.csr_w[fe + s[u]] : 0.0f;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) q0[u] = x[pt0[u]];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         float b0 = 0.0f, b1 = 0.0f;
-        for (int p = s[u]; p < t[u]; ++p) {
+        if (s[u] < t[u]) {
+            b0 += w0[u] * q0[u].x;
+            b1 += w0[u] * q0[u].y;
+        }
+        for (int p = s[u] + 1; p < t[u]; ++p) {
             const float w = kd.csr_w[fe + p];
             const float2 q = x[kd.csr_pt[fe + p]];
             b0 += w * q.x;
