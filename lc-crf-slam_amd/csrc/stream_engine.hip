@@ -845,8 +845,12 @@ __global__ void __launch_bounds__(kBlock) k_eneighbors(KernelDev kd, int F, XcdM
     target[D] = code - sum;                               // - 1 along every coordinate
     ok[D] = code >= sum;
     int v0[D1], v1[D1];
+    // axis 0 needs no bucket: it is the code's fastest coordinate and the ids follow the codes, so code + 1 -- if it exists -- is the
+    // next id (one coalesced read of the neighbouring lane's key instead of a bucket pair and a key)
+    v0[0] = v + 1;
+    v1[0] = min(v + 2, V);
 #pragma unroll
-    for (int j = 0; j < D1; ++j) {
+    for (int j = 1; j < D1; ++j) {
         const int b = ok[j] ? vsort_bucket(ss, f, target[j]) : 0;
         v0[j] = bvert[b];
         v1[j] = bvert[b + 1];
