@@ -1221,8 +1221,8 @@ int lccrf_add_pairwise(lccrf_handle h, const float *features, int d, float w)
     if (n) memcpy(ks.feat_stage, features, n * sizeof(float));   // caller may free `features` right away
     // SLAM frames: the build reads the features once, straight from this pinned buffer (no upload command on a latency-bound path).
     // Frames beyond the one-launch kernel are built by a dozen kernels of thousands of wavefronts, several of which read the
-    // features -- in locality mode as a gather: over PCIe that was 0.12-0.15 ms per kernel on the 76 800-pixel demo -- so those
-    // are uploaded once.
+    // features -- in locality mode as a gather -- and every one of which reads the point count: over PCIe that cost a 100 000-point
+    // frame 0.36 ms (C5 through this API: 1.61 -> 1.25 ms host to host), so those are uploaded once.
     ks.dev.feat = ks.feat_stage;
     if (h->N > kObjectPinnedMaxPoints && n) {
         HIP_TRY(hipMemcpyAsync(ks.feat_own, ks.feat_stage, n * sizeof(float), hipMemcpyHostToDevice, e.stream));
