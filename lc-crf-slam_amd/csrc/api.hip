@@ -399,8 +399,12 @@ struct Engine {
             if ((rc = mem.alloc(&k.nbrc_base, Fc * k.D1 * (E / kNbrcBlock + 1) * 2))) return rc;
         }
         if ((rc = mem.alloc(&k.rowptr, Fz * (E + 1)))) return rc;
-        if ((rc = mem.alloc(&k.longrow, Fz * kLongRowCap))) return rc;
-        if ((rc = mem.alloc(&k.longcnt, Fz))) return rc;
+        // (frames of the one-workgroup engines' range keep their rows in LDS there; on the streaming engine they are summed in line: a
+        // batch engine for 16 384 SLAM frames would carry 270 MB of lists per kernel)
+        if (maxN > kLongRowListMinPoints) {
+            if ((rc = mem.alloc(&k.longrow, Fz * kLongRowCap))) return rc;
+            if ((rc = mem.alloc(&k.longcnt, Fz))) return rc;
+        }
         if ((rc = mem.alloc(&k.csr_pt, Fz * E))) return rc;
         if ((rc = mem.alloc(&k.csr_w, Fz * E))) return rc;
         if ((rc = mem.alloc(&k.csr_pos, Fz * E))) return rc;
@@ -538,7 +542,7 @@ struct Engine {
             } else {
                 m = 1;
                 kernels[k].dev.nbr2_ok = kernels[k].dev.nbr2 != nullptr;      // (the streaming build fills the two-hop table when there is one)
-                kernels[k].dev.longrow_ok = kdevs[k].longrow_ok = 1;          //   (... and lists the long rows: the normalisation below reads the list)
+                kernels[k].dev.longrow_ok = kdevs[k].longrow_ok = kernels[k].dev.longrow != nullptr;   // (... and lists the long rows: the normalisation below reads the list)
                 kernels[k].dev.nbrc_ok = kernels[k].dev.nbrc != nullptr && kernels[k].dev.vorder && F >= kNbrcMinFrames && F <= kNbrcMaxFrames;   // (... and the sorted build the compact one)
                 kernels[k].dev.fast0_ok = kernels[k].dev.tbl_bad != nullptr && kernels[k].dev.vorder;
                 kernels[k].dev.nbr2_first = kernels[k].dev.fast0_ok;              // (what build_kernel_d derives from the same two fields)
@@ -546,7 +550,8 @@ struct Engine {
                 launch_norm(kdevs[k], crf, kernels[k].maxV, stream);
                 HIP_TRY(hipMemcpyAsync(V_host + (size_t)k * Fcap, kernels[k].dev.V, sizeof(int) * F, hipMemcpyDeviceToHost, stream));
                 HIP_TRY(hipMemcpyAsync(row_host + (size_t)k * Fcap, kernels[k].dev.rowmax, sizeof(int) * F, hipMemcpyDeviceToHost, stream));
-                HIP_TRY(hipMemcpyAsync(long_host + (size_t)k * Fcap, kernels[k].dev.longcnt, sizeof(int) * F, hipMemcpyDeviceToHost, stream));
+                if (kernels[k].dev.longrow)
+                    HIP_TRY(hipMemcpyAsync(long_host + (size_t)k * Fcap, kernels[k].dev.longcnt, sizeof(int) * F, hipMemcpyDeviceToHost, stream));
                 if (kernels[k].dev.fast0_ok)
                     HIP_TRY(hipMemcpyAsync(ndist_host + (size_t)k * kNdistAxes, kernels[k].dev.ndist, sizeof(int) * kNdistAxes, hipMemcpyDeviceToHost, stream));
             }

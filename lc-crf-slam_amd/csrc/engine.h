@@ -20,6 +20,7 @@ constexpr int kEmpty = -1;
 constexpr int kNdistAxes = 4;
 constexpr int kLongRowMin = 512;    // generic (L-label) splat: rows beyond this many entries go to a workgroup of their own (KernelDev::longrow)
 constexpr int kLongRowCap = 4095;   // ... as long as there are no more than this many of them per frame
+constexpr int kLongRowListMinPoints = 4096;   // ... in engines for frames beyond the one-workgroup kernels' range (the lists are 16 KB per frame)
 constexpr int kNbrcBlock = 64;      // vertices per base of the compact neighbour table (KernelDev::nbrc): one wavefront
 constexpr int kNbrcMinFrames = 3;   // ... which is built and read with 3 to 5 frames in flight (one frame: the passes go two per launch off the
 constexpr int kNbrcMaxFrames = 5;   //   two-hop table; two frames: +-0) (C5, per frame and iteration: 3 / 4 / 5 frames

@@ -2085,8 +2085,10 @@ void build_kernel_d(const KernelDev &kd, const CrfDev &c, hipStream_t s, const S
     }
     (void)hipMemsetAsync(kd.rowmax, 0, (size_t)F * sizeof(int), s);
     if (kd.Epad < 65535) k_row_max<<<grid_for(kd.Epad, F), kBlock, 0, s>>>(kd);   // only the one-workgroup engines ask (u16 ids)
-    (void)hipMemsetAsync(kd.longcnt, 0, (size_t)F * sizeof(int), s);
-    k_long_rows<<<grid_for(kd.Epad, F), kBlock, 0, s>>>(kd);
+    if (kd.longrow) {
+        (void)hipMemsetAsync(kd.longcnt, 0, (size_t)F * sizeof(int), s);
+        k_long_rows<<<grid_for(kd.Epad, F), kBlock, 0, s>>>(kd);
+    }
 }
 
 }  // namespace
