@@ -2173,8 +2173,8 @@ void launch_step_stream(const CrfDev &c, const KernelDev *kds, const int *maxV, 
                 const int B = kd.splat_block, core = B - 2 * kd.splat_halo;
                 const float2 *q2 = reinterpret_cast<const float2 *>(c.Q);
                 // many frames in flight: 256 lanes x 1 / 2 / 4 vertices (C5 x 8, window 1024: 20.6 -> 18.9 us per frame-iteration against
-                // 1024 lanes x 1: workgroups of four wavefronts wait less at the barriers); one or two frames: a lane per vertex (a
-                // lane's four row walks in a row cost a single frame 33.3 -> 36.1)
+                // 1024 lanes x 1: workgroups of four wavefronts wait less at the barriers); one or two frames: one or two vertices per lane
+                // (a lane's four row walks in a row cost a single frame 33.3 -> 36.1)
                 static const char *env_w = getenv("LCCRF_SPLAT_WIDE_MAX");                  // (A/B: frames-in-flight threshold)
                 const bool wide = c.F <= (env_w ? atoi(env_w) : 2);
                 const int lanes = wide ? B : kBlock;
@@ -2182,6 +2182,10 @@ void launch_step_stream(const CrfDev &c, const KernelDev *kds, const int *maxV, 
                 if (B == 256) k_splat2w<256, 1><<<g, 256, 0, s>>>(kd, q2, c.maxN, c.F, nb, j0, kd.splat_halo);
                 else if (B == 512 && wide) k_splat2w<512, 1><<<g, 512, 0, s>>>(kd, q2, c.maxN, c.F, nb, j0, kd.splat_halo);
                 else if (B == 512) k_splat2w<256, 2><<<g, 256, 0, s>>>(kd, q2, c.maxN, c.F, nb, j0, kd.splat_halo);
+                else if (c.F == 1) {                      // (one frame: 663 workgroups of 1024 lanes are 1.3 rounds of the chip's 512 slots;
+                    const dim3 g5 = grid_xcd(((long)maxV[k] + core - 1) / core * 512, c.F, &nb, 512);    //  512 lanes x 2 vertices all run at once: 33.6 -> 32.5 us)
+                    k_splat2w<512, 2><<<g5, 512, 0, s>>>(kd, q2, c.maxN, c.F, nb, j0, kd.splat_halo);
+                }
                 else if (wide) k_splat2w<1024, 1><<<g, 1024, 0, s>>>(kd, q2, c.maxN, c.F, nb, j0, kd.splat_halo);
                 else k_splat2w<256, 4><<<g, 256, 0, s>>>(kd, q2, c.maxN, c.F, nb, j0, kd.splat_halo);
             } else if (j0 == 1) {
