@@ -1509,9 +1509,9 @@ __global__ void __launch_bounds__(kBlock) k_splat2v(KernelDev kd, const float2 *
             p0 = w * q.x;
             p1 = w * q.y;
         }
-        for (int u = 0; u < m; ++u) {
-            a0 += __shfl(p0, u, 64);
-            a1 += __shfl(p1, u, 64);
+        for (int u = 0; u < m; ++u) {                     // (u is uniform: v_readlane, no trip through the LDS crossbar)
+            a0 += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p0), u));
+            a1 += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p1), u));
         }
     }
     if (lane == 0) reinterpret_cast<float2 *>(kd.val0 + (size_t)f * kd.vstride + kd.vbase)[v] = make_float2(a0, a1);
