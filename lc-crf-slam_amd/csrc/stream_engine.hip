@@ -592,7 +592,7 @@ __global__ void __launch_bounds__(kBlock) k_vsort_plan(int D, int nblocks, SortS
 // sort; blur neighbours are then found by CODE (the neighbour along axis j has code +- stride_j) among the few vertices of the
 // bucket that code falls in -- one contiguous read instead of a hash probe plus a key recomputation.  Everything downstream
 // (offset, rep, V, nbr, the CSR kernels) sees the same arrays as after the hash build, with other ids.
-constexpr int kLongBucket = 128;          // buckets beyond this are sorted by a workgroup of their own (identical or clustered features)
+constexpr int kLongBucket = 512;          // buckets beyond this are sorted by a workgroup of their own (identical or clustered features)
 constexpr int kVPh = 64;                  // ints per frame of the phantom-entry list: count, then up to 3 (d+1) <= 27 positions
 __device__ __forceinline__ void csr_emit(const KernelDev &kd, size_t fe, int pos, int e, int v);   // (with the CSR kernels below)
 
