@@ -1378,6 +1378,34 @@ __global__ void __launch_bounds__(kBlock) k_blur4(KernelDev kd, const float *__r
     }
 }
 
+// ... and ONE label (the normalisation's filter of all-ones, pairwise3d.h:22-27: seven passes per build): four vertices per thread --
+// two 16-byte table loads, one 16-byte centre load, eight 4-byte gathers, one 16-byte store instead of four times (8 + 4 + 2 x 4 + 4).
+typedef int lccrf_i4u __attribute__((ext_vector_type(4), aligned(4)));
+__global__ void __launch_bounds__(kBlock) k_blur1x4(KernelDev kd, const float *__restrict__ src, float *__restrict__ dst, int j)
+{
+    const int f = blockIdx.y;
+    const int V = kd.V[f];
+    const int v = 4 * (blockIdx.x * kBlock + threadIdx.x);
+    if (v >= V) return;
+    const size_t fv = (size_t)f * kd.vstride;
+    const float *o = src + fv + kd.vbase;                 // o[-1] = the all-zero "absent" vertex
+    float *d = dst + fv + kd.vbase;
+    const int *nbp = kd.nbr + (((size_t)f * kd.D1 + j) * kd.Epad + v) * 2;
+    if (v + 4 <= V) {
+        const lccrf_i4u n0 = *reinterpret_cast<const lccrf_i4u *>(nbp), n1 = *reinterpret_cast<const lccrf_i4u *>(nbp + 4);
+        const lccrf_f4u c = *reinterpret_cast<const lccrf_f4u *>(o + v);
+        const float a0 = o[n0.x], b0 = o[n0.y], a1 = o[n0.z], b1 = o[n0.w], a2 = o[n1.x], b2 = o[n1.y], a3 = o[n1.z], b3 = o[n1.w];
+        lccrf_f4u r;
+        r.x = c.x + 0.5f * (a0 + b0);
+        r.y = c.y + 0.5f * (a1 + b1);
+        r.z = c.z + 0.5f * (a2 + b2);
+        r.w = c.w + 0.5f * (a3 + b3);
+        *reinterpret_cast<lccrf_f4u *>(d + v) = r;
+    } else {
+        for (int u = v; u < V; ++u) d[u] = o[u] + 0.5f * (o[nbp[2 * (u - v)]] + o[nbp[2 * (u - v) + 1]]);
+    }
+}
+
 enum SliceMode { SLICE_NORM = 0, SLICE_APPLY_FIRST = 1, SLICE_APPLY = 2, SLICE_PLAIN = 3 };
 
 // slice (+ what the caller does with it).  ref: :684-694, pairwise3d.h:25-27,73-78,
@@ -2114,6 +2142,7 @@ static void filter_passes(const KernelDev &kd, int F, int maxV, int L, hipStream
     float *dst = kd.val1;
     for (int j = 0; j < kd.D1; ++j) {
         if (L >= 4) k_blur4<<<grid_for((long)maxV * ((L + 3) / 4), F), kBlock, 0, s>>>(kd, src, dst, j, L, (L + 3) / 4);
+        else if (L == 1) k_blur1x4<<<grid_for(((long)maxV + 3) / 4, F), kBlock, 0, s>>>(kd, src, dst, j);
         else k_blur<<<grid_for((long)maxV * L, F), kBlock, 0, s>>>(kd, src, dst, j, L);
         const float *t = src;
         src = dst;
