@@ -94,3 +94,28 @@ def test_adapter_base_pointers_apply_and_mixed_potentials(adapter_exe, wl, tmp_p
     write_inputs(p, wl, N, 11)
     r = subprocess.run([adapter_exe, p], capture_output=True, text=True)
     assert r.returncode == 0 and "ADAPTER OK" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_image_demo_through_the_adapter_gives_the_known_answer(tmp_path, golden):
+    """Thirdparty/DenseCRF/examples/example_cpu.cpp with the two type names changed (tests/cpp/image_demo_test.cpp): 21 classes, a 2-D
+    and a 5-D potential on 76 800 pixels through DenseCRFHIP<21> -- the labels must colour to res1_cpu.ppm byte for byte."""
+    if not os.path.exists(pkg.LIB_PATH):
+        pkg.build_library()
+    exe = str(tmp_path / "image_demo_test")
+    subprocess.run(["g++", "-std=c++14", "-O2", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "image_demo_test.cpp"),
+                    "-o", exe, pkg.LIB_PATH, "-Wl,-rpath," + os.path.dirname(pkg.LIB_PATH), "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    z = golden["example_im1"]
+    im, res, lab, colors = z["im"], z["res"], z["label"], z["colors"]
+    H, W, _ = im.shape
+    src, dst = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
+    with open(src, "wb") as f:
+        f.write(np.int32(W).tobytes() + np.int32(H).tobytes())
+        f.write(np.ascontiguousarray(im, np.uint8).tobytes())
+        f.write(np.ascontiguousarray(lab, np.int16).tobytes())
+    r = subprocess.run([exe, src, dst], capture_output=True, text=True)
+    assert r.returncode == 0 and "IMAGE DEMO OK" in r.stdout, r.stdout + r.stderr
+    m = np.fromfile(dst, np.int16)
+    col = colors[m]
+    out = np.stack([col & 255, (col >> 8) & 255, (col >> 16) & 255], -1).astype(np.uint8).reshape(H, W, 3)
+    assert np.array_equal(out, res)
