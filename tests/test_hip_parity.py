@@ -794,6 +794,7 @@ def test_streaming_engine_long_rows_go_to_a_workgroup_each(po, wl, L, dims, F):
         sizes = [N - 211 * i for i in range(F)]
         b = pkg.BatchCRF(F, N, L, dims, [float(w) for _, w in pb["kernels"]])
         b.set_engine(1)
+        b.set_option(pkg.OPT_VERTEX_ORDER, 2 if (L + F) % 2 else 0)      # (the hash build lists its long rows too)
         b.set_inputs_host(sizes, [np.repeat(f[None], F, 0) for f, _ in pb["kernels"]], unary=np.repeat(pb["unary"][None], F, 0))
         b.build(); b.inference(3, True, relax=0.9)
         Q, M = b.probability(), b.map()
