@@ -214,7 +214,13 @@ struct Engine {
     // Locality mode (batch engines, frames of >= kPermMinPoints points on the streaming engine): the lattices are built
     // with the points in an internal Z-order of their lattice cells (stream_engine.hip: launch_sort_points); Q, next and
     // the unaries of the iteration live in that order (Qp, unary_p / unary_own) and Q is un-permuted on the way out.
-    static constexpr int kPermMinPoints = 8192;
+    static constexpr int kPermMinPointsDefault = 8192;
+    static int perm_min_points()
+    {
+        static const char *e = getenv("LCCRF_PERM_MIN");                         // A/B switch (same results): locality mode from this many points
+        static const int v = e ? std::max(atoi(e), 64) : kPermMinPointsDefault;
+        return v;
+    }
     bool allow_perm = false;           // set by lccrf_batch_create, and by lccrf_create for handles of >= kPermMinPoints points ...
     bool perm_scoped = false;          // ... where it only applies to lattices that are first asked for by inference() (perm_scope): every
     bool perm_scope = false;           //   other entry point of the object API (stepwise inference, PairwisePotential::apply, the lattice
@@ -380,7 +386,7 @@ struct Engine {
         // one frame in flight, large frames (the object API's handles are sized for SLAM frames, which run on the one-workgroup engines):
         // the blur passes go two per launch and read a two-hop neighbour table
         if (Fcap == 1 && L == 2 && allow_perm && (rc = mem.alloc(&k.nbr2, (size_t)(k.D1 / 2) * E * 8))) return rc;
-        if (L == 2 && allow_perm && maxN >= kPermMinPoints) {
+        if (L == 2 && allow_perm && maxN >= perm_min_points()) {
             if (!tbl_bad) {
                 if ((rc = mem.alloc_pinned(&tbl_bad, 2))) return rc;
                 tbl_bad[0] = tbl_bad[1] = 0;
@@ -501,7 +507,7 @@ struct Engine {
         if (k0 == 0) {                                     // a build of every kernel decides the internal point order afresh
             static const bool no_perm = getenv("LCCRF_NO_PERM") != nullptr;   // A/B and cross-check switch: same results either way
             const int NAp = activeN > 0 ? activeN : maxN;
-            const bool want = allow_perm && !no_perm && !perm_banned && (!perm_scoped || perm_scope) && n > 0 && n == (int)kernels.size() && NAp >= kPermMinPoints;
+            const bool want = allow_perm && !no_perm && !perm_banned && (!perm_scoped || perm_scope) && n > 0 && n == (int)kernels.size() && NAp >= perm_min_points();
             if (want || perm_on) {                         // whatever was derived in the old order is stale
                 if (unary_is_label) unary_deferred = true;
                 unary_p_valid = false;
@@ -1062,7 +1068,7 @@ int lccrf_create(lccrf_handle *out, int device_id, int n_points, int n_labels)
         h->cap = capacity_for(n_points);
         rc = h->eng.init(device_id, 1, h->cap, n_labels);
         // frames far beyond SLAM's (BASELINE config 5 through the reference's own interface): inference() in locality mode
-        h->eng.allow_perm = h->eng.perm_scoped = h->cap >= Engine::kPermMinPoints;
+        h->eng.allow_perm = h->eng.perm_scoped = h->cap >= Engine::perm_min_points();
         if (!rc) rc = h->eng.mem.alloc_pinned(&h->stage_i16, h->cap);
         if (!rc) rc = h->eng.mem.alloc_pinned(&h->stage_f32, (size_t)h->cap * n_labels);
         if (!rc) rc = h->eng.mem.alloc_pinned(&h->stage_n, 1);
