@@ -121,6 +121,7 @@ def lib():
     L.lccrf_batch_set_engine.argtypes = [vp, C.c_int]
     L.lccrf_batch_get_engine.argtypes = [vp, C.POINTER(C.c_int)]
     L.lccrf_batch_get_fallback_frames.argtypes = [vp, C.POINTER(C.c_int)]
+    L.lccrf_batch_get_fused_shape.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.lccrf_batch_pose_set_crf_counts.argtypes = [vp, vp]
     L.lccrf_batch_last_timing.argtypes = [vp, _f32p, _f32p]
     L.lccrf_batch_time_blur_pass.argtypes = [vp, C.c_int, C.c_int, _f32p, C.POINTER(C.c_int64)]
@@ -368,6 +369,12 @@ class BatchCRF:
         e = C.c_int(0)
         _check(lib().lccrf_batch_get_engine(self.h, C.byref(e)))
         return e.value
+
+    def fused_shape(self):
+        """(lanes per frame, frames per CU) of the last fused-engine launch; (0, 0) if there was none."""
+        a, b = C.c_int(0), C.c_int(0)
+        _check(lib().lccrf_batch_get_fused_shape(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def fallback_frames(self):
         """Frames of the last run() that did not fit the one-launch kernel and were re-run on the two-kernel path."""

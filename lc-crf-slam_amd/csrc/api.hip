@@ -149,6 +149,7 @@ struct Engine {
     int sized_engine = 1;              // what learn_sizes() chose for inference on lattices that sit in HBM (1 or 2)
     int last_with_map = 0;             // did the last inference produce MAP labels?
     size_t fused_lds = 0;
+    int fused_shape = 0;               // report only: what the last fused inference launched (launch_inference_fused)
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   // build begin/end, inference begin/end
     hipEvent_t ev_order = nullptr;     // orders a caller-supplied stream against the engine's own (StreamScope)
     int *npoints_bad = nullptr;        // pinned: set by the validation kernel when a bound n_points[f] is outside [0, maxN]
@@ -822,7 +823,7 @@ struct Engine {
             if (with_map) launch_map(crf, stream);
             started = true;
         } else if (sized_engine == 2) {
-            launch_inference_fused(crf, kdevs.data(), maxV.data(), maxRow.data(), n_iter, with_map, relax, stream);
+            fused_shape = launch_inference_fused(crf, kdevs.data(), maxV.data(), maxRow.data(), n_iter, with_map, relax, stream);
             started = true;
         } else {
             if ((rc = start())) return rc;
@@ -1837,6 +1838,15 @@ int lccrf_batch_get_engine(lccrf_batch_handle b, int *engine_in_use)
         e.engine_used = e.sized_engine;
     }
     *engine_in_use = e.engine_used;
+    return LCCRF_OK;
+}
+
+int lccrf_batch_get_fused_shape(lccrf_batch_handle b, int *lanes_per_frame, int *frames_per_cu)
+{
+    CHECK_H(b);
+    if (!lanes_per_frame || !frames_per_cu) return fail(LCCRF_E_INVALID, "output pointer is NULL");
+    *lanes_per_frame = b->eng.fused_shape & 0xffff;
+    *frames_per_cu = b->eng.fused_shape >> 16;
     return LCCRF_OK;
 }
 

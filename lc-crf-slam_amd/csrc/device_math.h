@@ -226,7 +226,9 @@ __device__ __forceinline__ void exp_and_normalize_reg(const float (&in)[L], floa
 // expAndNormalize for two labels (densecrf3d.h:70-98), a = scale*in[0], b = scale*in[1].  One of
 // the two fast_exp arguments is exactly 0 (value minus row maximum) and fast_exp(0) == 1, so a
 // single exp is evaluated; the sum and the two IEEE divisions are the reference's.
-__device__ __forceinline__ float2 softmax2(float a, float b, float2 old, float relax)
+// omr = 1 - relax, formed once by the caller (the same fp32 subtraction as densecrf3d.h:94, (1 - relax): a uniform value the
+// kernels would otherwise keep in a vector register for the whole launch)
+__device__ __forceinline__ float2 softmax2(float a, float b, float2 old, float relax, float omr)
 {
     const bool lt = a < b;                            // mx = b iff a < b (densecrf3d.h:76-79)
     const float e = fast_exp_nonpos(lt ? a - b : b - a);
@@ -245,8 +247,9 @@ __device__ __forceinline__ float2 softmax2(float a, float b, float2 old, float r
     const float pm = quot(1.0f), pe = quot(e);
     const float p0 = lt ? pe : pm, p1 = lt ? pm : pe;
     if (relax == 1) return make_float2(p0, p1);
-    return make_float2((1 - relax) * old.x + relax * p0, (1 - relax) * old.y + relax * p1);
+    return make_float2(omr * old.x + relax * p0, omr * old.y + relax * p1);
 }
+__device__ __forceinline__ float2 softmax2(float a, float b, float2 old, float relax) { return softmax2(a, b, old, relax, 1 - relax); }
 
 __device__ __forceinline__ int argmax_row(const float *p, int L)   // densecrf3d.h:140-149
 {

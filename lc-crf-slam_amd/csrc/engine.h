@@ -180,8 +180,9 @@ void launch_build_small(const KernelDev *kds, int n, int max_points, const CrfDe
 // ---- fused engine (SLAM sizes; one workgroup per frame, lattice values in LDS) --------
 bool fused_supported(const CrfDev &c, const KernelDev *kds, const int *maxV, const int *maxRow,
                      size_t *lds_bytes);
-void launch_inference_fused(const CrfDev &c, const KernelDev *kds, const int *maxV, const int *maxRow,
-                            int n_iter, int with_map, float relax, hipStream_t s);
+// returns the shape it launched: lanes per workgroup (= per frame) | workgroups per CU << 16 (0: nothing launched)
+int launch_inference_fused(const CrfDev &c, const KernelDev *kds, const int *maxV, const int *maxRow,
+                           int n_iter, int with_map, float relax, hipStream_t s);
 
 // ---- frame engine (SLAM sizes; lattice build + normalisation + inference of a frame in ONE launch) ---------
 bool frame_supported(const CrfDev &c, const KernelDev *kds);

@@ -21,6 +21,7 @@
 #include "engine.h"
 #include "device_math.h"
 #include "fused_loop.h"
+#include "fused_lean.h"
 
 #include <algorithm>
 #include <cstdio>
@@ -36,7 +37,7 @@ struct FusedArgs {
     KernelDev kd[kMaxFusedK];
     FusedLayout lay;
     int n_iter, with_map;
-    float relax;
+    float relax, omr;                     // omr = 1 - relax (fp32, densecrf3d.h:94), formed on the host
     long long *timing;                    // instrumented builds: shader-clock stamps of one workgroup (LCCRF_FUSED_TIMING=<block index + 1>)
     int timing_block, timing_lane;
     int dbg;                              // instrumented builds: LCCRF_FUSED_DBG (see fused_loop.h)
@@ -168,6 +169,112 @@ __global__ void __launch_bounds__(NT, 4) k_fused(CrfDev c, FusedArgs a)
     if (kInstr && a.timing && (int)blockIdx.x == a.timing_block && tid == a.timing_lane) a.timing[63] = ins.n;
 }
 
+
+// The same inference on HALF a CU's LDS (fused_lean.h): frames of 1025 .. ~2300 keypoints, two workgroups per CU.
+//   NT = 512 (8 wavefronts, 4 per SIMD with both workgroups resident: 128 registers per lane), 3 or 4 points per lane;
+//   RELOAD: unary energies, barycentric weights and norms are re-read every iteration instead of kept in registers
+template <int NT, int PPT, int K, int CH, bool RELOAD>
+__global__ void __launch_bounds__(NT, NT == 384 ? 3 : 4) k_fused_lean(CrfDev c, FusedArgs a)
+{
+    constexpr int D1 = kD1;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int f = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int N = c.n_points[f];
+    Instr ins{a.timing, a.timing_block, a.dbg, 0, a.timing_lane};
+    FL_STAMP();
+
+    PointRegs<PPT, K> pr;
+    int V[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) V[k] = a.kd[k].V[f];
+    if (N <= 0) return;
+    const FusedLayout &lay = a.lay;
+
+    // per-point records first (the long pole of the prologue), then the lattice tables
+    unsigned pk[PPT][K][D1];              // (vertex id + 1) | place in the row << 16
+    const float *gbary[K], *gnorm[K];
+    const unsigned *gnbr[K];
+    float wk[K];
+    LeanSrc src;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const KernelDev &kd = a.kd[k];
+        gbary[k] = kd.bary + (size_t)f * kd.Epad;
+        gnorm[k] = kd.norm + (size_t)f * kd.maxN;
+        gnbr[k] = kd.nbr16 + (size_t)f * D1 * kd.Epad;
+        wk[k] = kd.w;
+        src.nbr[k] = lean_rsrc(gnbr[k], (size_t)D1 * kd.Epad * 4);
+        src.bary[k] = lean_rsrc(gbary[k], (size_t)kd.Epad * 4);
+        src.norm[k] = lean_rsrc(gnorm[k], (size_t)kd.maxN * 4);
+        src.nbr_axis_bytes[k] = kd.Epad * 4;
+    }
+    src.unary = lean_rsrc(c.unary + (size_t)f * c.maxN * 2, (size_t)c.maxN * 8);
+#pragma unroll
+    for (int s = 0; s < PPT; ++s) {
+        const int ic = min(tid + s * NT, N - 1);
+        pr.un[s] = reinterpret_cast<const float2 *>(c.unary)[(size_t)f * c.maxN + ic];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const KernelDev &kd = a.kd[k];
+            const size_t e0 = (size_t)f * kd.Epad + (size_t)ic * D1;
+#pragma unroll
+            for (int j = 0; j < D1; ++j) {
+                pk[s][k][j] = kd.pk[e0 + j];
+                if (!RELOAD) pr.bary[s][k][j] = gbary[k][(size_t)ic * D1 + j];
+            }
+            if (!RELOAD) pr.wn[s][k] = gnorm[k][ic];
+        }
+    }
+    if (!RELOAD) {
+#pragma unroll
+        for (int s = 0; s < PPT; ++s)
+#pragma unroll
+            for (int k = 0; k < K; ++k) pr.wn[s][k] = wk[k] * pr.wn[s][k];   // pairwise3d.h:77 (w_*norm_[i])
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const KernelDev &kd = a.kd[k];
+        unsigned short *row = reinterpret_cast<unsigned short *>(smem + lay.row[k]);
+        const int *gr = kd.rowptr + (size_t)f * (kd.Epad + 1);
+        for (int v = tid; v <= V[k]; v += NT) row[v] = (unsigned short)gr[v];
+        if (lay.nbr[k] >= 0) {
+            unsigned *nbr = reinterpret_cast<unsigned *>(smem + lay.nbr[k]);
+            for (int idx = tid; idx < D1 * V[k]; idx += NT) {
+                const int j = idx >= 2 * V[k] ? 2 : (idx >= V[k] ? 1 : 0);
+                nbr[idx] = gnbr[k][(size_t)j * kd.Epad + (idx - j * V[k])];
+            }
+        }
+    }
+    if (tid < 32) reinterpret_cast<float *>(smem + lay.zero)[tid] = 0.0f;   // LDS bytes [0, 128): chain_rows_sel reads them by absolute address
+    if (tid == 0) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            reinterpret_cast<float2 *>(smem + lay.val[k][0])[0] = make_float2(0.f, 0.f);
+            reinterpret_cast<float2 *>(smem + lay.val[k][1])[0] = make_float2(0.f, 0.f);
+        }
+    }
+    __syncthreads();
+    FL_PSTAMP();
+
+    ChainLane cl{0u, 0u};
+    if (CH != 0 && chain_k<CH>(lay, 0)) cl = chain_setup_lean<NT>(smem, lay, V[0], tid);
+    FL_PSTAMP();
+    start_inference<PPT, K, NT>(pr, N, tid);
+    place_products_lean<PPT, K, CH, NT>(smem, lay, N, tid, pk, pr);
+    FL_STAMP();
+
+    float alpha[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) alpha[k] = a.kd[k].alpha;
+    int t = tid;                          // (the loop makes its copy of the lane id opaque; what follows uses that copy)
+    mean_field_lean<PPT, K, CH, NT, RELOAD>(smem, lay, V, N, t, pr, cl, alpha, wk, src, a.n_iter, a.relax, a.omr, ins);
+
+    store_results<PPT, K, NT>(c, f, N, t, pr, a.with_map);
+    FL_STAMP();
+    if (kInstr && a.timing && (int)blockIdx.x == a.timing_block && t == a.timing_lane) a.timing[63] = ins.n;
+}
+
 bool make_layout(const CrfDev &c, const KernelDev *kds, const int *maxV, const int *maxRow, FusedLayout *lay, int nt = kNT,
                  size_t lds_limit = kLdsLimit)
 {
@@ -191,6 +298,53 @@ bool small_layout(const CrfDev &c, const KernelDev *kds, const int *maxV, const 
     if (!make_layout(c, kds, maxV, maxRow, &L, kNTSmall, kLdsHalf)) return false;
     *lay = L;
     return true;
+}
+
+
+// Two FULL-SIZE frames per CU (fused_lean.h)?  More than two points per lane of the 512-lane small shape, the lean plan in half the CU's LDS.
+// (measured and dropped: 384 lanes x 6 points with 168 registers per lane, with and without the re-read -- 2.1e7 iterations/s on C2
+// against 3.67e7 for one 1024-lane frame per CU: twelve wavefronts per CU do not keep the LDS pipe busy)
+int lean_shape()
+{
+    static const char *e = getenv("LCCRF_LEAN_SHAPE");                   // A/B switch: 0 = one 1024-lane frame per CU (same results)
+    static const int v = e ? atoi(e) : 2;
+    return v;
+}
+
+bool lean_layout(const CrfDev &c, const KernelDev *kds, const int *maxV, const int *maxRow, FusedLayout *lay, int *nt_out)
+{
+    const int shape = lean_shape();
+    if (shape != 2) return false;
+    const int nt = kNTSmall, max_ppt = 4;
+    const int NA = c.activeN > 0 ? c.activeN : c.maxN;
+    if (c.L != 2 || c.K < 1 || c.K > kMaxFusedK || c.F < kSmallMinFrames || NA <= 2 * kNTSmall || NA > max_ppt * nt) return false;
+    for (int k = 0; k < c.K; ++k)
+        if (kds[k].d != 2 || kds[k].Epad >= 65535) return false;
+    FusedLayout L;
+    if (!layout_lean(NA, c.K, maxV, maxRow ? maxRow[0] : 0, &L, nt, kLdsHalf)) return false;
+    *lay = L;
+    *nt_out = nt;
+    return true;
+}
+
+template <int NT, int PPT, int K, int CH, bool RELOAD>
+void launch_lean(const CrfDev &c, const FusedArgs &a, hipStream_t s)
+{
+    auto fn = k_fused_lean<NT, PPT, K, CH, RELOAD>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit);
+    fn<<<dim3(c.F), dim3(NT), a.lay.total, s>>>(c, a);
+}
+
+template <int NT, int PPT, bool RELOAD>
+void launch_lean_ppt(const CrfDev &c, const FusedArgs &a, hipStream_t s)
+{
+    if (c.K == 1) {
+        if (a.lay.chain0) launch_lean<NT, PPT, 1, 1, RELOAD>(c, a, s);
+        else launch_lean<NT, PPT, 1, 0, RELOAD>(c, a, s);
+    } else {
+        if (a.lay.chain0) launch_lean<NT, PPT, 2, 1, RELOAD>(c, a, s);
+        else launch_lean<NT, PPT, 2, 0, RELOAD>(c, a, s);
+    }
 }
 
 template <int NT, int PPT, int K, int CH>
@@ -225,18 +379,21 @@ bool fused_supported(const CrfDev &c, const KernelDev *kds, const int *maxV, con
     return ok;
 }
 
-void launch_inference_fused(const CrfDev &c, const KernelDev *kds, const int *maxV, const int *maxRow, int n_iter,
-                            int with_map, float relax, hipStream_t s)
+int launch_inference_fused(const CrfDev &c, const KernelDev *kds, const int *maxV, const int *maxRow, int n_iter,
+                           int with_map, float relax, hipStream_t s)
 {
     FusedArgs a{};
     const bool small = small_layout(c, kds, maxV, maxRow, &a.lay);
-    if (!small && !make_layout(c, kds, maxV, maxRow, &a.lay)) return;
+    int lean_nt = 0;
+    const bool lean = !small && lean_layout(c, kds, maxV, maxRow, &a.lay, &lean_nt);
+    if (!small && !lean && !make_layout(c, kds, maxV, maxRow, &a.lay)) return 0;
     static const bool no_chain = getenv("LCCRF_NO_CHAIN") != nullptr;     // debugging aid: compiler-scheduled S phase
     if (no_chain) a.lay.chain0 = 0;                                        // (the padded plane size is harmless)
     for (int k = 0; k < c.K; ++k) a.kd[k] = kds[k];
     a.n_iter = n_iter;
     a.with_map = with_map;
     a.relax = relax;
+    a.omr = 1 - relax;
     static long long *timing_buf = nullptr;
     static const bool want_timing = kInstr && getenv("LCCRF_FUSED_TIMING") != nullptr;
     if (want_timing && !timing_buf) (void)hipMalloc(&timing_buf, 64 * sizeof(long long));
@@ -250,6 +407,9 @@ void launch_inference_fused(const CrfDev &c, const KernelDev *kds, const int *ma
     if (small) {
         if (NAp <= kNTSmall) launch_fused_ppt<kNTSmall, 1>(c, a, s);
         else launch_fused_ppt<kNTSmall, 2>(c, a, s);
+    } else if (lean) {
+        if (NAp <= 3 * 512) launch_lean_ppt<512, 3, true>(c, a, s);
+        else launch_lean_ppt<512, 4, true>(c, a, s);
     } else {
         switch ((NAp + kNT - 1) / kNT) {
         case 1: launch_fused_ppt<kNT, 1>(c, a, s); break;
@@ -267,6 +427,7 @@ void launch_inference_fused(const CrfDev &c, const KernelDev *kds, const int *ma
         for (int i = 1; i < h[63] && i < 63; ++i) fprintf(stderr, " %lld", h[i] - h[i - 1]);
         fprintf(stderr, "\n");
     }
+    return small ? (kNTSmall | 2 << 16) : lean ? (lean_nt | 2 << 16) : (kNT | 1 << 16);
 }
 
 }  // namespace lccrf

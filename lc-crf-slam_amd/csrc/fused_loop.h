@@ -58,6 +58,7 @@ struct FusedLayout {                      // byte offsets into dynamic LDS
     int Ecap[kMaxFusedK];                 // floats per label plane of prod
     int prod_all;                         // 1: every kernel has its own product buffer
     int chain0;                           // 1: kernel 0 has long splat rows, S runs chain_rows on them
+    int pstart;                           // lean plan only (fused_lean.h): u16 [V_0+2] first product slot of every chain row
     int total;
 };
 
@@ -159,46 +160,49 @@ __host__ __device__ inline bool layout_core(int NA, int K, const int *V, int row
     "v_add_f32_e32 %[acc], %[acc], " #e "\n\tv_add_f32_e32 %[acc], %[acc], " #f "\n\t"               \
     "v_add_f32_e32 %[acc], %[acc], " #g "\n\tv_add_f32_e32 %[acc], %[acc], " #h "\n\t"
 
+#define LCCRF_CHAIN_ROWS_ASM                                                                                         \
+        "v_min_u32_e32 %[sel], %[ad], %[e0]\n\t"                                                                     \
+        "ds_read_b128 v[96:99], %[sel]\n\tds_read_b128 v[100:103], %[sel] offset:16\n\t"                             \
+        "v_min_u32_e32 %[sel], %[ad], %[e1]\n\t"                                                                     \
+        "ds_read_b128 v[104:107], %[sel] offset:32\n\tds_read_b128 v[108:111], %[sel] offset:48\n\t"                 \
+        "v_min_u32_e32 %[sel], %[ad], %[e2]\n\t"                                                                     \
+        "ds_read_b128 v[112:115], %[sel] offset:64\n\tds_read_b128 v[116:119], %[sel] offset:80\n\t"                 \
+        "1:\n\t"                                                                                                     \
+        "v_min_u32_e32 %[sel], %[ad], %[e3]\n\t"                                                                     \
+        "ds_read_b128 v[120:123], %[sel] offset:96\n\tds_read_b128 v[124:127], %[sel] offset:112\n\t"                \
+        "s_waitcnt lgkmcnt(6)\n\t"                                                                                   \
+        LCCRF_ASM_ADD8(v96, v97, v98, v99, v100, v101, v102, v103)                                                   \
+        "v_add_u32_e32 %[ad], 0x80, %[ad]\n\t"                                                                       \
+        "v_min_u32_e32 %[sel], %[ad], %[e0]\n\t"                                                                     \
+        "ds_read_b128 v[96:99], %[sel]\n\tds_read_b128 v[100:103], %[sel] offset:16\n\t"                             \
+        "s_waitcnt lgkmcnt(6)\n\t"                                                                                   \
+        LCCRF_ASM_ADD8(v104, v105, v106, v107, v108, v109, v110, v111)                                               \
+        "v_min_u32_e32 %[sel], %[ad], %[e1]\n\t"                                                                     \
+        "ds_read_b128 v[104:107], %[sel] offset:32\n\tds_read_b128 v[108:111], %[sel] offset:48\n\t"                 \
+        "s_waitcnt lgkmcnt(6)\n\t"                                                                                   \
+        LCCRF_ASM_ADD8(v112, v113, v114, v115, v116, v117, v118, v119)                                               \
+        "v_min_u32_e32 %[sel], %[ad], %[e2]\n\t"                                                                     \
+        "ds_read_b128 v[112:115], %[sel] offset:64\n\tds_read_b128 v[116:119], %[sel] offset:80\n\t"                 \
+        "s_waitcnt lgkmcnt(6)\n\t"                                                                                   \
+        LCCRF_ASM_ADD8(v120, v121, v122, v123, v124, v125, v126, v127)                                               \
+        "s_sub_u32 %[n], %[n], 1\n\t"                                                                                \
+        "s_cmp_lg_u32 %[n], 0\n\t"                                                                                   \
+        "s_cbranch_scc1 1b\n\t"                                                                                      \
+        "s_waitcnt lgkmcnt(0)\n\t"
+#define LCCRF_CHAIN_RING_CLOBBERS                                                                                      \
+    "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112",   \
+        "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127"
+
 __device__ __forceinline__ float chain_rows(unsigned addr, unsigned end, unsigned trips)
 {
     float acc = 0.0f;
     if (trips == 0) return acc;
     const unsigned e1 = end - 32u, e2 = end - 64u, e3 = end - 96u;      // min(addr, end - k) + k == min(addr + k, end)
     unsigned sel;
-    asm volatile(
-        "v_min_u32_e32 %[sel], %[ad], %[e0]\n\t"
-        "ds_read_b128 v[96:99], %[sel]\n\tds_read_b128 v[100:103], %[sel] offset:16\n\t"
-        "v_min_u32_e32 %[sel], %[ad], %[e1]\n\t"
-        "ds_read_b128 v[104:107], %[sel] offset:32\n\tds_read_b128 v[108:111], %[sel] offset:48\n\t"
-        "v_min_u32_e32 %[sel], %[ad], %[e2]\n\t"
-        "ds_read_b128 v[112:115], %[sel] offset:64\n\tds_read_b128 v[116:119], %[sel] offset:80\n\t"
-        "1:\n\t"
-        "v_min_u32_e32 %[sel], %[ad], %[e3]\n\t"
-        "ds_read_b128 v[120:123], %[sel] offset:96\n\tds_read_b128 v[124:127], %[sel] offset:112\n\t"
-        "s_waitcnt lgkmcnt(6)\n\t"
-        LCCRF_ASM_ADD8(v96, v97, v98, v99, v100, v101, v102, v103)
-        "v_add_u32_e32 %[ad], 0x80, %[ad]\n\t"
-        "v_min_u32_e32 %[sel], %[ad], %[e0]\n\t"
-        "ds_read_b128 v[96:99], %[sel]\n\tds_read_b128 v[100:103], %[sel] offset:16\n\t"
-        "s_waitcnt lgkmcnt(6)\n\t"
-        LCCRF_ASM_ADD8(v104, v105, v106, v107, v108, v109, v110, v111)
-        "v_min_u32_e32 %[sel], %[ad], %[e1]\n\t"
-        "ds_read_b128 v[104:107], %[sel] offset:32\n\tds_read_b128 v[108:111], %[sel] offset:48\n\t"
-        "s_waitcnt lgkmcnt(6)\n\t"
-        LCCRF_ASM_ADD8(v112, v113, v114, v115, v116, v117, v118, v119)
-        "v_min_u32_e32 %[sel], %[ad], %[e2]\n\t"
-        "ds_read_b128 v[112:115], %[sel] offset:64\n\tds_read_b128 v[116:119], %[sel] offset:80\n\t"
-        "s_waitcnt lgkmcnt(6)\n\t"
-        LCCRF_ASM_ADD8(v120, v121, v122, v123, v124, v125, v126, v127)
-        "s_sub_u32 %[n], %[n], 1\n\t"
-        "s_cmp_lg_u32 %[n], 0\n\t"
-        "s_cbranch_scc1 1b\n\t"
-        "s_waitcnt lgkmcnt(0)\n\t"
-        : [acc] "+v"(acc), [ad] "+v"(addr), [n] "+s"(trips), [sel] "=&v"(sel)
-        : [e0] "v"(end), [e1] "v"(e1), [e2] "v"(e2), [e3] "v"(e3)
-        : "scc", "memory", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107",
-          "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120",
-          "v121", "v122", "v123", "v124", "v125", "v126", "v127");
+    asm volatile(LCCRF_CHAIN_ROWS_ASM
+                 : [acc] "+v"(acc), [ad] "+v"(addr), [n] "+s"(trips), [sel] "=&v"(sel)
+                 : [e0] "v"(end), [e1] "v"(e1), [e2] "v"(e2), [e3] "v"(e3)
+                 : "scc", "memory", LCCRF_CHAIN_RING_CLOBBERS);
     return acc;
 }
 

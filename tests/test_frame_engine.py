@@ -590,3 +590,60 @@ def test_two_label_softmax_dense_sweep(po, wl, N):
     assert b.engine() == 2
     assert cc.same_bits(b.probability().reshape(total, 2), expect)
     b.close()
+
+
+@pytest.mark.parametrize("shape", ["2"])
+def test_full_size_frames_share_a_cu_and_give_the_same_bits(po, wl, shape):
+    """Round 5: frames of 1025 .. ~2300 points run TWO per CU as well when a batch has at least 256 frames -- the lean plan of
+    csrc/fused_lean.h (one shared product buffer, the large lattice's neighbour table read from HBM/L2, chain rows placed by a scan;
+    384 lanes x 6 points or 512 lanes x 4 points with the weights re-read per iteration).  Ragged sizes around every
+    points-per-lane boundary of both shapes, an empty and a tiny frame among them; every frame against the oracle, bit for bit."""
+    code = r"""
+import importlib, sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r); sys.path.insert(0, %r)
+import crf_cases as cc, pyoracle as po
+from test_frame_engine import _batch_of
+wl = importlib.import_module("lc-crf-slam_amd.workloads")
+lanes = 512 if %r == "2" else 384
+top = 2048 if lanes == 512 else 2304
+sizes = [2000, 1025, 1536, 1537, 1999, top, 1100, 1920, 1921, top - 1, 0, 700, 1152, 1153, 3, 2001]
+base = [wl.slam_problem(n, seed=5100 + i) for i, n in enumerate(sizes)]
+F = 272
+pbs = [base[f %% len(base)] for f in range(F)]
+refs = []
+for n_iter, relax in ((5, 1.0), (3, 0.5)):
+    b = _batch_of(pbs, maxN=top)
+    b.build(); b.inference(n_iter, True, relax=relax)
+    Q, M = b.probability(), b.map()
+    assert b.engine() == 2 and b.fused_shape() == (lanes, 2), (b.engine(), b.fused_shape())
+    b.close()
+    for i, pb in enumerate(base):
+        o = cc.setup(po.OracleCRF, pb)
+        o.inference_native(n_iter, True, relax)
+        for f in range(i, F, len(base)):
+            n = pb["N"]
+            assert cc.same_bits(Q[f, :n], o.probability()), (n_iter, f, n)
+            assert np.array_equal(M[f, :n], o.map()), (n_iter, f, n)
+        o.close()
+# one kernel only (the chain kernel alone, then the short-row kernel alone), and two short-row kernels
+for pick in ((0,), (1,), (1, 1)):
+    pb1 = []
+    for pb in base:
+        q = dict(pb); q["kernels"] = [pb["kernels"][k] for k in pick]; pb1.append(q)
+    pbs1 = [pb1[f %% len(pb1)] for f in range(F)]
+    b = _batch_of(pbs1, maxN=top)
+    b.build(); b.inference(4, True)
+    Q = b.probability()
+    # (two large lattices do not fit half a CU's LDS: that batch keeps the 1024-lane shape)
+    assert b.engine() == 2 and b.fused_shape() == ((lanes, 2) if len(pick) == 1 else (1024, 1)), (pick, b.engine(), b.fused_shape())
+    b.close()
+    for i, pb in enumerate(pb1):
+        o = cc.setup(po.OracleCRF, pb)
+        o.inference_native(4, True)
+        assert cc.same_bits(Q[i, :pb["N"]], o.probability()) and cc.same_bits(Q[i + 256, :pb["N"]], o.probability()), (pick, i)
+        o.close()
+print("ok")
+""" % (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle"), shape)
+    env = dict(os.environ, LCCRF_LEAN_SHAPE=shape)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout[-2000:] + r.stderr[-4000:]

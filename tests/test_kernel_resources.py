@@ -37,7 +37,7 @@ def test_fused_slam_variants_do_not_spill():
     """Every BASELINE configuration's variant -- 1000 / 2000 keypoints (1-2 points per lane) and 3000 (3 points per lane,
     config C4) -- runs without scratch memory."""
     use = resource_usage("fused_engine.hip")
-    fused = {k: v for k, v in use.items() if "k_fused" in k}
+    fused = {k: v for k, v in use.items() if "k_fusedI" in k}
     assert len(fused) == 24                                   # 1024 lanes: PPT 1..4 x K 1..2 x {short rows, chain}; 512 lanes: PPT 1..2 x ...
     for name, r in fused.items():
         nt, ppt = (int(x) for x in re.search(r"k_fusedILi(\d+)ELi(\d)E", name).groups())
@@ -46,6 +46,21 @@ def test_fused_slam_variants_do_not_spill():
         assert r["VGPRs"] + r.get("AGPRs", 0) <= 128, name
         if ppt <= 3:
             assert r["ScratchSize [bytes/lane]"] == 0 and r["VGPRs Spill"] == 0, (name, r)
+
+
+@pytest.mark.skipif(shutil.which(HIPCC) is None, reason="hipcc not installed")
+def test_two_full_size_frames_per_cu_fit_the_register_file_without_scratch():
+    """Round 5 (csrc/fused_lean.h): frames of 1025 .. 2048 keypoints as 512-lane workgroups, 3 or 4 points per lane, TWO workgroups per
+    CU -- which only works at 128 registers per lane (four wavefronts per SIMD) and only pays without scratch traffic in the loop.
+    The rings of the ordered row sums clobber v96..v127; what must survive them passes through the asm statements as operands."""
+    use = resource_usage("fused_engine.hip")
+    lean = {k: v for k, v in use.items() if "k_fused_leanI" in k}
+    assert len(lean) == 8                                     # PPT 3..4 x K 1..2 x {short rows, chain}
+    for name, r in lean.items():
+        nt, ppt = (int(x) for x in re.search(r"k_fused_leanILi(\d+)ELi(\d)E", name).groups())
+        assert nt == 512 and ppt in (3, 4)
+        assert r["VGPRs"] + r.get("AGPRs", 0) <= 128, name
+        assert r["ScratchSize [bytes/lane]"] == 0 and r["VGPRs Spill"] == 0, (name, r)
 
 
 @pytest.mark.skipif(shutil.which(HIPCC) is None, reason="hipcc not installed")
