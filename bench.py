@@ -613,6 +613,147 @@ def c5_record(pkg, wl, torch, dev, steps=6, frames=8):
     return out
 
 
+
+# ---------------------------------------------------------------------------------------------
+# SURVEY 8(d)'s end to end, host to host: feature upload + lattice build + norm + inference + label download, pipelined.
+# The reference pays its per-frame cost from host arrays to host labels (src/Tracking.cc:1919-1930); here batches of B frames go
+# through lccrf_batch_set_inputs_host_async -> lccrf_batch_run -> lccrf_batch_download_async on three handles used round-robin, so
+# that batch i+1 is staged and uploaded under batch i's kernel while batch i-1's labels travel back.
+# ---------------------------------------------------------------------------------------------
+def link_peak(torch, dev, mb=256, reps=5):
+    """Measured rate of the host link with large pinned copies, GB/s (h2d, d2h)."""
+    host = torch.empty(mb << 20, dtype=torch.uint8).pin_memory()
+    devb = torch.empty(mb << 20, dtype=torch.uint8, device=dev)
+    out = []
+    for up in (True, False):
+        best = 0.0
+        for _ in range(reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            if up:
+                devb.copy_(host, non_blocking=True)
+            else:
+                host.copy_(devb, non_blocking=True)
+            e1.record()
+            e1.synchronize()
+            best = max(best, (mb << 20) / (e0.elapsed_time(e1) * 1e-3) / 1e9)
+        out.append(best)
+    return out
+
+
+def host_to_host_record(pkg, wl, torch, dev, name="c2", batch_sizes=(256, 4096), distinct=64, target_s=1.0):
+    """end_to_end.host_to_host: frames/s from host arrays to host label bits.  The figures are those of a C++ host
+    (tools/host_pipeline.cpp, compiled here with g++ against the in-tree library: the tracker / a replay tool is a C++ program);
+    the same pipeline driven from Python through ctypes is reported beside them, and the label bits of both are compared with
+    the synchronous path's."""
+    import shutil
+    import tempfile
+    import numpy as np
+    N, n_iter, cap, _ = WORKLOADS[name]
+    pbs = [wl.slam_problem(N, 1 + i, obs_cap=cap) for i in range(distinct)]
+    dims = [2, 2]
+    weights = [float(pbs[0]["kernels"][k][1]) for k in range(2)]
+    conf = float(pbs[0]["conf"])
+    h2d, d2h = link_peak(torch, dev)
+    BC = pkg.BatchCRF
+    words = (N + 63) // 64
+    rec = {"link_peak_GBs": {"h2d": h2d, "d2h": d2h, "how": "256 MB pinned copies, best of 5, HIP events"},
+           "note": "frames/s, host arrays in -> host label bits out.  Per batch: lccrf_batch_set_inputs_host_async (features 2 x 16 KB + labels "
+                   "4 KB per frame) -> lccrf_batch_run (ONE launch per frame: both lattices, norms, %d iterations, MAP) -> "
+                   "lccrf_batch_download_async (label bits, 256 B per frame), on several handles round-robin so that batch i+1 is staged "
+                   "and uploaded under batch i's kernel.  pageable = the caller's arrays are ordinary memory (copied into the batch's pinned "
+                   "staging by a pool of 16 host threads; the caller's buffers are free on return), pinned = LCCRF_HOST_PINNED (the DMA reads "
+                   "the caller's pinned arrays), serial = one handle, the synchronous lccrf_batch_set_inputs_host + run + "
+                   "lccrf_batch_get_map_host.  pcie_bound = link_peak h2d / upload bytes per frame." % n_iter}
+    tmp = tempfile.mkdtemp(prefix="lccrf_h2h_")
+    exe = None
+    try:
+        if shutil.which("g++"):
+            exe, libdir = os.path.join(tmp, "host_pipeline"), os.path.join(ROOT, "lc-crf-slam_amd")
+            r = subprocess.run(["g++", "-std=c++14", "-O2", "-I" + os.path.join(ROOT, "include"), "-I/opt/rocm/include", "-D__HIP_PLATFORM_AMD__",
+                                os.path.join(ROOT, "tools", "host_pipeline.cpp"), "-o", exe, "-L" + libdir, "-l:liblccrf_hip.so",
+                                "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"],
+                               capture_output=True, text=True, timeout=300)
+            if r.returncode:
+                rec["cpp_build_error"], exe = r.stderr[-300:], None
+        inp = os.path.join(tmp, "frames.bin")
+        with open(inp, "wb") as f:
+            f.write(np.array([distinct, N, n_iter], np.int32).tobytes() + np.array([weights[0], weights[1], conf], np.float32).tobytes())
+            for pb in pbs:
+                f.write(np.ascontiguousarray(pb["kernels"][0][0], np.float32).tobytes())
+                f.write(np.ascontiguousarray(pb["kernels"][1][0], np.float32).tobytes())
+                f.write(np.ascontiguousarray(pb["label"], np.int16).tobytes())
+        for B in batch_sizes:
+            idx = [i % distinct for i in range(B)]
+            feats = [np.ascontiguousarray(np.stack([pbs[i]["kernels"][k][0] for i in idx])) for k in range(2)]
+            label = np.ascontiguousarray(np.stack([pbs[i]["label"] for i in idx]))
+            npts = np.full(B, N, np.int32)
+            up_bytes = sum(f.nbytes for f in feats) + label.nbytes + npts.nbytes
+            nh, copy_threads = 4, 16                         # (scripts/gpu_h2h_matrix.sh: handles x staging threads; 3-4 handles, 16 threads)
+            ref = BC(B, N, 2, dims, weights)                 # the label bits of this batch from the synchronous path
+            ref.set_inputs_host(npts, feats, label=label, conf=conf)
+            ref.run(n_iter, True)
+            m_ref = ref.map()
+            ref.close()
+            ref_bits = np.packbits((m_ref == 1).astype(np.uint8).reshape(B, -1), axis=1, bitorder="little")
+            ref_bits = np.pad(ref_bits, ((0, 0), (0, words * 8 - ref_bits.shape[1]))).view(np.uint64)
+            r = {"frames_per_batch": B, "handles": nh, "upload_bytes_per_frame": up_bytes / B, "download_bytes_per_frame": words * 8,
+                 "pcie_bound_frames_per_s": h2d * 1e9 / (up_bytes / B)}
+            if exe:
+                for mode in ("serial", "pageable", "pinned"):
+                    per = max(up_bytes / (h2d * 1e9), 1e-4) * (3 if mode == "serial" else 1.5)
+                    nb = int(min(max(target_s / per, 8), 2000))
+                    bits_out = os.path.join(tmp, "bits_%s.bin" % mode)
+                    q = subprocess.run([exe, inp, str(B), str(nb), str(nh), mode, bits_out, str(copy_threads)], capture_output=True, text=True, timeout=600)
+                    line = [l for l in q.stdout.splitlines() if l.startswith("{")]
+                    d = json.loads(line[-1]) if line else {"error": (q.stderr or q.stdout)[-300:]}
+                    if "frames_per_s" in d:
+                        got = np.fromfile(bits_out, np.uint64).reshape(B, words)
+                        d["labels_identical_to_synchronous_path"] = bool(np.array_equal(got, ref_bits))
+                        d["frac_of_link_peak"] = d["upload_GBs"] / h2d
+                        d["frac_of_pcie_bound"] = d["frames_per_s"] / r["pcie_bound_frames_per_s"]
+                    r[mode] = d
+            # the same pipeline from Python (ctypes): what bench-style callers see
+            handles = [BC(B, N, 2, dims, weights) for _ in range(nh)]
+            for h in handles:
+                h.set_option(BC.OPT_COPY_THREADS, copy_threads)
+            t_feats = [torch.from_numpy(f).pin_memory() for f in feats]
+            t_label = torch.from_numpy(label).pin_memory()
+            py = {}
+            for mode in ("pageable", "pinned"):
+                src_f = feats if mode == "pageable" else [t.numpy() for t in t_feats]
+                src_l = label if mode == "pageable" else t_label.numpy()
+
+                def pump(nb):
+                    got = None
+                    for i in range(nb + nh):
+                        h = handles[i % nh]
+                        if i >= nh:
+                            got = h.wait_download(copy=False)["bits"]
+                        if i < nb:
+                            h.set_inputs_host_async(npts, src_f, label=src_l, conf=conf, pinned=(mode == "pinned"))
+                            h.run(n_iter, True)
+                            h.download_async(BC.DOWNLOAD_LABEL_BITS)
+                    return got
+                pump(2 * nh)                                     # staging buffers allocated, kernels loaded
+                t0 = time.perf_counter()
+                pump(nh)
+                per = (time.perf_counter() - t0) / nh
+                nb = int(min(max(0.3 / max(per, 1e-6), 2 * nh), 400))
+                t0 = time.perf_counter()
+                bits = pump(nb)
+                dt = time.perf_counter() - t0
+                py[mode] = {"frames_per_s": nb * B / dt, "batches": nb, "upload_GBs": nb * up_bytes / dt / 1e9,
+                            "labels_identical_to_synchronous_path": bool(np.array_equal(bits, ref_bits))}
+            for h in handles:
+                h.close()
+            r["python_ctypes"] = py
+            rec["B%d" % B] = r
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return rec
+
+
 def latest_profile(suffix):
     """profiles/r<NN>_<suffix> of the latest round that committed one (e.g. 'fused_c2' -> 'r3_fused_c2'), or None."""
     import re
@@ -723,6 +864,7 @@ def main():
                     help="N > 1: wait for each step's label gather before the next launch instead of overlapping them")
     ap.add_argument("--distinct", type=int, default=64, help="distinct synthetic frames tiled into the batch")
     ap.add_argument("--rehearse-cpu", action="store_true", help="launcher test: gloo, no GPU, no compute, no metric")
+    ap.add_argument("--host-to-host", action="store_true", help="only the pipelined host-to-host record (end_to_end.host_to_host)")
     ap.add_argument("--lite", action="store_true",
                     help="counter-collection runs (rocprofv3 --pmc serialises every dispatch): one event-timed launch instead of "
                          "five, two one-launch batches instead of many -- the timed region itself is unchanged")
@@ -764,6 +906,9 @@ def main():
     wl = importlib.import_module("lc-crf-slam_amd.workloads")
     sh = importlib.import_module("lc-crf-slam_amd.sharding")
 
+    if args.host_to_host:
+        print(json.dumps({"host_to_host": host_to_host_record(pkg, wl, torch, dev, args.workload if args.workload != "c5" else "c2")}))
+        return
     name = args.workload
     N, n_iter, _, desc = WORKLOADS[name]
     F = args.frames or (1 if name == "c5" else DEFAULT_FRAMES)   # frames in flight per GPU: 64 full waves of workgroups on 256 CUs, ~11 GB
@@ -819,8 +964,35 @@ def main():
     barrier()
     t1 = time.perf_counter()
     dt = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
+    multi = None
     if world > 1:
+        # what every rank measured (the value uses the slowest), what the collective library itself spans, and the label
+        # gather's own cost: the same steps once more with gather-then-launch instead of the overlapped form
+        per_rank = [torch.zeros_like(dt) for _ in range(world)]
+        dist.all_gather(per_rank, dt)
+        ones = torch.ones(1, dtype=torch.int32, device=dev)
+        dist.all_reduce(ones)                           # a sum over the communicator of the timed region: N iff it spans N ranks
         dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+        other = sh.OverlappedLabelGather(bits_view, world, serial=not args.serial_gather)
+        main_gather, gather = gather, other
+        for _ in range(2):
+            step()
+        barrier()
+        t0s = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        dts = torch.tensor([time.perf_counter() - t0s], dtype=torch.float64, device=dev)
+        dist.all_reduce(dts, op=dist.ReduceOp.MAX)
+        gather = main_gather
+        ser, ovl = (float(dt.item()), float(dts.item())) if args.serial_gather else (float(dts.item()), float(dt.item()))
+        multi = {"ms_per_step_by_rank": [float(x.item()) / args.steps * 1e3 for x in per_rank],
+                 "ranks_in_collective": int(ones.item()), "backend": dist.get_backend(),
+                 "label_gather": {"serial_ms_per_step": ser / args.steps * 1e3, "overlapped_ms_per_step": ovl / args.steps * 1e3,
+                                  "exposed_ms_per_step": (ser - ovl) / args.steps * 1e3,
+                                  "bytes_per_rank": int(F * words * 8)}}
+        if multi["ranks_in_collective"] != world:
+            raise SystemExit("the collective spans %d ranks, not %d" % (multi["ranks_in_collective"], world))
     dt = float(dt.item())
 
     gather_ok = None
@@ -935,8 +1107,12 @@ def main():
             "frames_checked": frames_checked,        # distinct frames compared with the CPU checker (all of them)
             "tiles_identical": tiles_ok,             # every one of the F slots equals its source frame bit for bit (Q and labels, on the device)
         }
+        # a scaling curve needs the 1/2/4/8-GPU lines of one node side by side: this line alone never is one
+        out["scaling_measured"] = False
         if gather_ok is not None:
             out["label_gather_ok"] = gather_ok
+        if multi is not None:
+            out["multi_gpu"] = multi
         if world == 1 and not args.no_extras:
             b.close()
             del d_feats, d_label
@@ -948,6 +1124,7 @@ def main():
                 out["c5"] = c5_record(pkg, wl, torch, dev)
             if name == "c2":
                 out["image_demo"] = image_demo_record(pkg, wl)
+                out["end_to_end"]["host_to_host"] = host_to_host_record(pkg, wl, torch, dev, "c2")
             lat_pbs = pbs[:8] if name not in ("c5", "n500") else [wl.slam_problem(2000, s) for s in range(1, 9)]
             out["single_frame_latency_us"] = single_frame_latency(pkg, lat_pbs, 5)
             out["single_frame_latency_us_n500"] = single_frame_latency(pkg, [wl.slam_problem(500, s) for s in range(1, 9)], 5, reps=160)

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define LCCRF_ABI_VERSION 1
+#define LCCRF_ABI_VERSION 2   /* 2: lccrf_batch_get_fused_shape, the asynchronous host path of the batch API, lccrf_set_option's options 3-4 */
 #define LCCRF_MAX_KERNELS 8      /* pairwise terms per CRF                        */
 #define LCCRF_MAX_DIMS    8      /* feature dimensions per kernel (reference uses <= 6) */
 #define LCCRF_MAX_LABELS  64
@@ -81,11 +81,15 @@ int  lccrf_trim_cache(void);
  *       and a blur pass (permutohedral_cpu.h:663-679) touches half as many cache lines per gather (23 -> 19.5 us per pass over 8 frames of
  *       100 000 points, 0.61 -> 0.72 of the HBM peak).  2 selects round 3's build (hash table, vertices by first occurrence along a
  *       Z-order curve of the points).  Results never depend on how vertices are found or numbered.
- * lccrf_set_option applies to one handle (set it after lccrf_create: a handle taken from the cache starts from the defaults);
- * lccrf_set_default_option to every handle and batch created afterwards in this process.                                      */
+ *   LCCRF_OPT_COPY_THREADS   (batches; 1 .. 64, default 8) host threads that copy the caller's arrays into the batch's pinned
+ *       staging in lccrf_batch_set_inputs_host_async (one core copies ~10 GB/s, the PCIe link takes ~50).
+ * lccrf_set_option applies to one handle (set it after lccrf_create: a handle taken from the cache starts from the defaults) and is
+ * per handle only for LCCRF_OPT_VERTEX_ORDER and LCCRF_OPT_COPY_THREADS; lccrf_set_default_option applies LCCRF_OPT_SINGLE_WORKGROUP
+ * to every handle and batch created afterwards in this process.                                                              */
 typedef enum lccrf_option {
     LCCRF_OPT_SINGLE_WORKGROUP = 1,
-    LCCRF_OPT_VERTEX_ORDER     = 2
+    LCCRF_OPT_VERTEX_ORDER     = 2,
+    LCCRF_OPT_COPY_THREADS     = 3
 } lccrf_option;
 int  lccrf_set_option(lccrf_handle h, int option, int value);
 int  lccrf_set_default_option(int option, int value);
@@ -190,6 +194,32 @@ int  lccrf_batch_set_option(lccrf_batch_handle b, int option, int value);
 int  lccrf_batch_set_inputs_host(lccrf_batch_handle b, int n_frames, const int32_t *n_points,
                                  const float *unary, const int16_t *label, const float *conf,
                                  const float *const *features /* [n_kernels] */);
+/* Host inputs, nothing waits (round 5; the reference's per-frame cost at src/Tracking.cc:1919-1930 is host to host, so a replay
+ * that wants the GPU's rate has to keep the link busy under the kernels).  Same arrays as lccrf_batch_set_inputs_host.  They are
+ * copied into pinned staging owned by the batch before the call returns -- the caller's buffers may be reused at once -- and
+ * uploaded on the batch's copy stream; whatever is queued on the batch afterwards (lccrf_batch_run / _build / ..., on its own or a
+ * caller's stream) waits for the upload on the device, and the upload itself waits for the kernels queued before it.  With
+ * LCCRF_HOST_PINNED the caller vouches that every array is pinned (hipHostMalloc / hipHostRegister) and stays untouched until
+ * lccrf_batch_wait_inputs returns (or any later result of this batch has been seen): no staging copy, the DMA reads the caller's
+ * memory.  One batch is in flight per handle: to upload batch i+1 under batch i's kernels alternate between two or three handles
+ * (tools/replay_multi.cpp does).                                                                       */
+#define LCCRF_HOST_PINNED 1
+int  lccrf_batch_set_inputs_host_async(lccrf_batch_handle b, int n_frames, const int32_t *n_points,
+                                       const float *unary, const int16_t *label, const float *conf,
+                                       const float *const *features /* [n_kernels] */, int flags);
+int  lccrf_batch_wait_inputs(lccrf_batch_handle b);
+/* Results to the host, nothing waits: queues, behind everything queued on the batch so far, copies of the chosen results into
+ * pinned memory owned by the batch (label bits: 256 bytes per 2000-keypoint frame -- the layout of lccrf_batch_device_label_bits;
+ * int16 labels and probabilities: the layouts of lccrf_batch_get_map_host / _get_probability_host) on the batch's download
+ * stream.  lccrf_batch_wait_download waits for them -- and settles the per-frame fallback of a one-launch run first, refreshing
+ * the copies if a frame had to be re-run -- and hands out the host pointers (NULL for what was not asked for), valid until the
+ * next lccrf_batch_download_async on this handle.                                                                              */
+#define LCCRF_DOWNLOAD_LABEL_BITS  1
+#define LCCRF_DOWNLOAD_MAP         2
+#define LCCRF_DOWNLOAD_PROBABILITY 4
+int  lccrf_batch_download_async(lccrf_batch_handle b, int what);
+int  lccrf_batch_wait_download(lccrf_batch_handle b, const uint64_t **label_bits, int *words_per_frame,
+                               const int16_t **map, const float **probability);
 /* Device inputs (bound, not copied; must stay valid until the batch finished).  d_n_points must be COMPLETE when
  * this is called (it is validated and clamped into a private copy on the batch's own stream right here, unordered
  * with any other stream); an entry outside [0, max_points] raises LCCRF_E_CAPACITY at the next synchronisation point. */
@@ -242,6 +272,11 @@ int  lccrf_batch_get_engine(lccrf_batch_handle b, int *engine_in_use);
  * ~2300 points in batches of at least 256 frames, csrc/fused_lean.h).  0 / 0 if no such launch happened yet.  Same results in
  * every shape (the order of every row sum is the reference's, permutohedral_cpu.h:653-661).                                   */
 int  lccrf_batch_get_fused_shape(lccrf_batch_handle b, int *lanes_per_frame, int *frames_per_cu);
+/* Report only: how the lattices now in HBM were built (after lccrf_batch_build) -- whether the points of a frame are processed in
+ * an internal order (locality mode: frames of >= 8192 points) and whether the vertices were found by the SORTED build
+ * (LCCRF_OPT_VERTEX_ORDER) or, 0, by the hash table: also what an engine falls back to for good when a frame's vertex codes overflow
+ * 62 bits or a feature is wide enough to wrap the reference's int16 keys.  Either pointer may be NULL.                           */
+int  lccrf_batch_get_locality_mode(lccrf_batch_handle b, int *internal_point_order, int *sorted_build);
 
 /* Measurement support for bench.py: HIP-event time of the last lccrf_batch_inference()
  * on its stream, the number of launches of the dominant kernel and their summed

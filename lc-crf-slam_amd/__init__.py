@@ -108,6 +108,10 @@ def lib():
     L.lccrf_batch_destroy.restype = None
     L.lccrf_batch_set_inputs_host.argtypes = [vp, C.c_int, _i32p, _f32p, _i16p, _f32p, C.POINTER(_f32p)]
     L.lccrf_batch_bind_inputs_device.argtypes = [vp, C.c_int, vp, vp, vp, _f32p, C.POINTER(vp)]
+    L.lccrf_batch_set_inputs_host_async.argtypes = [vp, C.c_int, vp, vp, vp, _f32p, C.POINTER(vp), C.c_int]
+    L.lccrf_batch_wait_inputs.argtypes = [vp]
+    L.lccrf_batch_download_async.argtypes = [vp, C.c_int]
+    L.lccrf_batch_wait_download.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_int), C.POINTER(vp), C.POINTER(vp)]
     L.lccrf_batch_build.argtypes = [vp, vp]
     L.lccrf_batch_inference.argtypes = [vp, C.c_int, C.c_int, C.c_float, vp]
     L.lccrf_batch_run.argtypes = [vp, C.c_int, C.c_int, C.c_float, vp]
@@ -122,6 +126,7 @@ def lib():
     L.lccrf_batch_get_engine.argtypes = [vp, C.POINTER(C.c_int)]
     L.lccrf_batch_get_fallback_frames.argtypes = [vp, C.POINTER(C.c_int)]
     L.lccrf_batch_get_fused_shape.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.lccrf_batch_get_locality_mode.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.lccrf_batch_pose_set_crf_counts.argtypes = [vp, vp]
     L.lccrf_batch_last_timing.argtypes = [vp, _f32p, _f32p]
     L.lccrf_batch_time_blur_pass.argtypes = [vp, C.c_int, C.c_int, _f32p, C.POINTER(C.c_int64)]
@@ -334,6 +339,57 @@ class BatchCRF:
             _p(l, _i16p) if l is not None else None, _p(cf, _f32p) if cf is not None else None, arr))
         self.n_frames = F
 
+    HOST_PINNED = 1
+    DOWNLOAD_LABEL_BITS, DOWNLOAD_MAP, DOWNLOAD_PROBABILITY = 1, 2, 4
+    OPT_COPY_THREADS = 3
+
+    def set_inputs_host_async(self, n_points, features, unary=None, label=None, conf=None, pinned=False):
+        """lccrf_batch_set_inputs_host_async: the arrays are staged and uploaded without a host wait.  The arrays must already be
+        C-contiguous of the right dtype (nothing is converted here: a hidden copy would be timed as part of the call); with
+        pinned=True they must live in pinned memory and stay untouched until wait_inputs() or a result of this batch."""
+        npts = np.ascontiguousarray(n_points, np.int32)
+        F = npts.size
+
+        def addr(a, dtype, count):
+            assert a.dtype == dtype and a.flags["C_CONTIGUOUS"] and a.size == count, (a.dtype, a.shape, count)
+            return C.c_void_p(a.ctypes.data)
+        arr = (C.c_void_p * len(features))(*[addr(f, np.float32, F * self.maxN * d) for f, d in zip(features, self.dims)])
+        u = l = cf = None
+        if unary is not None:
+            u = addr(unary, np.float32, F * self.maxN * self.L)
+        if label is not None:
+            l = addr(label, np.int16, F * self.maxN)
+            cf = _f32(np.broadcast_to(np.asarray(conf, np.float32), (self.L,)))
+        _check(lib().lccrf_batch_set_inputs_host_async(
+            self.h, F, C.c_void_p(npts.ctypes.data), u, l, _p(cf, _f32p) if cf is not None else None, arr,
+            self.HOST_PINNED if pinned else 0))
+        self.n_frames = F
+
+    def wait_inputs(self):
+        _check(lib().lccrf_batch_wait_inputs(self.h))
+
+    def download_async(self, what=1):
+        _check(lib().lccrf_batch_download_async(self.h, int(what)))
+
+    def wait_download(self, copy=True):
+        """-> dict with the arrays that were asked for ('bits' uint64 [F][words], 'map' int16 [F][maxN], 'prob' float32 [F][maxN][L]);
+        copy=False hands out views of the batch's pinned memory (valid until the next download_async)."""
+        bits, mp, pr, words = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_int(0)
+        _check(lib().lccrf_batch_wait_download(self.h, C.byref(bits), C.byref(words), C.byref(mp), C.byref(pr)))
+        out, F = {}, self.n_frames
+
+        def view(ptr, ctype, shape, dtype):
+            n = int(np.prod(shape))
+            a = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ctype)), (max(n, 1),))[:n].reshape(shape).view(dtype)
+            return a.copy() if copy else a
+        if bits.value:
+            out["bits"] = view(bits, C.c_uint64, (F, words.value), np.uint64)
+        if mp.value:
+            out["map"] = view(mp, C.c_int16, (F, self.maxN), np.int16)
+        if pr.value:
+            out["prob"] = view(pr, C.c_float, (F, self.maxN, self.L), np.float32)
+        return out
+
     def bind_inputs_device(self, n_frames, d_n_points, d_features, d_unary=None, d_label=None, conf=None):
         """Pointers are raw device addresses (e.g. torch_tensor.data_ptr())."""
         arr = (C.c_void_p * len(d_features))(*[C.c_void_p(int(p)) for p in d_features])
@@ -375,6 +431,12 @@ class BatchCRF:
         a, b = C.c_int(0), C.c_int(0)
         _check(lib().lccrf_batch_get_fused_shape(self.h, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def locality_mode(self):
+        """(internal point order in use, sorted build in use) for the lattices now in HBM."""
+        a, b = C.c_int(0), C.c_int(0)
+        _check(lib().lccrf_batch_get_locality_mode(self.h, C.byref(a), C.byref(b)))
+        return bool(a.value), bool(b.value)
 
     def fallback_frames(self):
         """Frames of the last run() that did not fit the one-launch kernel and were re-run on the two-kernel path."""

@@ -17,6 +17,8 @@
 #include <string>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <thread>
 #include <vector>
 
 using namespace lccrf;
@@ -218,7 +220,7 @@ struct Engine {
     static constexpr int kPermMinPointsDefault = 8192;
     static int perm_min_points()
     {
-        static const char *e = getenv("LCCRF_PERM_MIN");                         // A/B switch (same results): locality mode from this many points
+        static const char *e = ab_env("LCCRF_PERM_MIN");                         // A/B switch (same results): locality mode from this many points
         static const int v = e ? std::max(atoi(e), 64) : kPermMinPointsDefault;
         return v;
     }
@@ -232,9 +234,12 @@ struct Engine {
     SortScratch sort{};
     float *Qp = nullptr, *unary_p = nullptr;   // [Fcap][maxN][L]
 
+    bool sort_scratch_complete = false;
     int ensure_sort_scratch()
     {
-        if (sort.perm) return LCCRF_OK;
+        // (complete or nothing: an allocation that fails half way -- E_NOMEM -- must not leave a later build with some of the
+        // arrays null; what a failed attempt did allocate stays with the arena until the engine goes -- ADVICE r4)
+        if (sort_scratch_complete) return LCCRF_OK;
         int bits = 8;
         while (bits < 16 && (1 << bits) < 2 * maxN) ++bits;
         sort.bits = bits;
@@ -270,6 +275,7 @@ struct Engine {
         if ((rc = mem.alloc(&sort.vtiles, Fz * ((vnbk + 4095) / 4096 + 1)))) return rc;
         if ((rc = mem.alloc(&sort.vpartial, Fz * ((maxNpad + 255) / 256 + 1) * 2 * kMaxD))) return rc;
         if ((rc = mem.alloc(&sort.vplan, Fz * (2 * kMaxD + 3)))) return rc;
+        sort_scratch_complete = true;
         return LCCRF_OK;
     }
 
@@ -506,7 +512,7 @@ struct Engine {
     {
         for (int k = k0; k < k0 + n; ++k) kernels[k].maxV = kernels[k].dev.Epad;
         if (k0 == 0) {                                     // a build of every kernel decides the internal point order afresh
-            static const bool no_perm = getenv("LCCRF_NO_PERM") != nullptr;   // A/B and cross-check switch: same results either way
+            static const bool no_perm = ab_env("LCCRF_NO_PERM") != nullptr;   // A/B and cross-check switch: same results either way
             const int NAp = activeN > 0 ? activeN : maxN;
             const bool want = allow_perm && !no_perm && !perm_banned && (!perm_scoped || perm_scope) && n > 0 && n == (int)kernels.size() && NAp >= perm_min_points();
             if (want || perm_on) {                         // whatever was derived in the old order is stale
@@ -517,7 +523,7 @@ struct Engine {
             // ... and, with the points permuted, whether the lattices are built by SORTING the entries on the row-major code of their
             // vertex (ids along the lattice's axes: the blur pass touches half as many lines) -- yes unless switched off: with the
             // points in row-major order too it wins at every number of frames in flight (notes/r4_experiments.md section 2)
-            static const char *env_vo = getenv("LCCRF_VERTEX_ORDER");               // A/B switch: 1 on, 0 off (same results)
+            static const char *env_vo = ab_env("LCCRF_VERTEX_ORDER");               // A/B switch: 1 on, 0 off (same results)
             const int vo = env_vo ? (atoi(env_vo) ? 1 : 2) : opt_vertex_order;
             vorder_on = want && !vorder_broken && vo != 2;
             sync_views();
@@ -529,7 +535,7 @@ struct Engine {
                     if (kernels[k].dev.d > kernels[src].dev.d) src = k;
                 // with the sorted build the points follow the vertices: (coarse) row-major order of their cells in the lattice's own basis
                 // instead of the Z-order curve (C5 x 8: splat 30.5 -> 27.7, slice 24.2 -> 19.5 us, build 1.93 -> 1.76 ms)
-                static const bool env_z = getenv("LCCRF_POINTS_ZORDER") != nullptr;        // A/B switch (same results)
+                static const bool env_z = ab_env("LCCRF_POINTS_ZORDER") != nullptr;        // A/B switch (same results)
                 sort.rm_points = (vorder_on && !env_z) ? 1 : 0;
                 launch_sort_points(kdevs[src], crf, sort, stream);
                 HIP_TRY(hipGetLastError());
@@ -537,13 +543,16 @@ struct Engine {
             }
         }
         sync_views();
-        const bool no_small = getenv("LCCRF_NO_FUSED_BUILD") != nullptr;   // debug / cross-check switch
+        const bool no_small = ab_env("LCCRF_NO_FUSED_BUILD") != nullptr;   // debug / cross-check switch
         int k = k0;
         while (k < k0 + n) {
             int m = 1;
             const int NA = activeN > 0 ? activeN : maxN;
-            if (!no_small && k + 1 < k0 + n && build_small_supported(&kdevs[k], 2, NA)) m = 2;
-            if (!no_small && build_small_supported(&kdevs[k], m, NA)) {
+            // (locality mode: the one-workgroup build knows nothing of the internal point order -- ADVICE r4: with the threshold lowered
+            // below its range it would have built in the caller's order under an engine that iterates in the permuted one)
+            const bool small_ok = !no_small && !perm_on;
+            if (small_ok && k + 1 < k0 + n && build_small_supported(&kdevs[k], 2, NA)) m = 2;
+            if (small_ok && build_small_supported(&kdevs[k], m, NA)) {
                 for (int u = 0; u < m; ++u) kernels[k + u].dev.nbr2_ok = kernels[k + u].dev.nbrc_ok = kernels[k + u].dev.fast0_ok = kernels[k + u].dev.longrow_ok = 0;
                 launch_build_small(&kdevs[k], m, NA, crf, stream);   // writes V / rowmax to the pinned mirrors itself
             } else {
@@ -600,7 +609,7 @@ struct Engine {
             HIP_TRY(hipStreamSynchronize(stream));
         }
 #if LCCRF_INSTRUMENT
-        if (tbl_bad && getenv("LCCRF_FAST0_BREAK")) tbl_bad[1] = 1;      // test hook: as if the build had found an axis-0 neighbour elsewhere
+        if (tbl_bad && ab_env("LCCRF_FAST0_BREAK")) tbl_bad[1] = 1;      // test hook: as if the build had found an axis-0 neighbour elsewhere
 #endif
         if (tbl_bad && (tbl_bad[0] || tbl_bad[1])) {
             // [0] a block's neighbours span more than 16 bits: the blur reads the 32-bit table; [1] an axis-0 neighbour that is not the
@@ -622,7 +631,7 @@ struct Engine {
             kd.splat_passes = kd.fast0_ok ? 1 : 0;
             kd.splat_halo = 1;
             kd.splat_block = 0;
-            static const char *env_sp = getenv("LCCRF_SPLAT_PASSES");               // A/B switch (same results): at most this many
+            static const char *env_sp = ab_env("LCCRF_SPLAT_PASSES");               // A/B switch (same results): at most this many
             const int cap = env_sp ? atoi(env_sp) : 3;
             if (kd.fast0_ok && cap >= 2) {
                 const int *nd = ndist_host + k * kNdistAxes;
@@ -717,7 +726,7 @@ struct Engine {
     // Can the whole frame (lattices + normalisation + inference) run as ONE launch (frame_engine.hip)?
     bool frame_ok() const
     {
-        static const bool no_frame = getenv("LCCRF_NO_FRAME") != nullptr;   // cross-check switch: two-kernel path, same results
+        static const bool no_frame = ab_env("LCCRF_NO_FRAME") != nullptr;   // cross-check switch: two-kernel path, same results
         return !no_frame && engine_pref == 0 && !kernels.empty() && frame_supported(crf, kdevs.data());
     }
 
@@ -738,7 +747,7 @@ struct Engine {
             dual = dual_area;
             if (++dual_epoch == 0) dual_epoch = 1;
         }
-        static const bool no_done_word = getenv("LCCRF_NO_DONE_WORD") != nullptr;   // A/B switch: wait on the stream instead
+        static const bool no_done_word = ab_env("LCCRF_NO_DONE_WORD") != nullptr;   // A/B switch: wait on the stream instead
         done_armed = late_ok && F == 1 && !no_done_word;
         if (done_armed && ++done_epoch == 0) done_epoch = 1;
         labels_armed = done_armed && with_map && L == 2 && map_host && map_host == crf.map && activeN > 0;
@@ -997,12 +1006,40 @@ constexpr int kMaxDevices = 64;
 PoseStage g_pose_stage[kMaxDevices];
 }  // namespace
 
+// The asynchronous host path of a batch (lccrf_batch_set_inputs_host_async / _download_async / _wait_download): pinned staging for
+// the inputs and the results, one stream per copy direction (the GPU has DMA engines for both), events instead of host waits.
+// One batch is in flight per handle; a caller that wants batch i+1 uploaded under batch i's kernels alternates between handles.
+struct HostPipe {
+    hipStream_t up = nullptr, down = nullptr;
+    hipEvent_t ev_up = nullptr, ev_down = nullptr, ev_q = nullptr;   // upload landed / download landed / "everything queued so far"
+    int *npoints = nullptr;                  // pinned staging, sized for the batch's capacities
+    int16_t *label = nullptr;
+    float *unary = nullptr;
+    std::vector<float *> feat;
+    uint64_t *bits = nullptr;                // pinned results
+    int16_t *map = nullptr;
+    float *prob = nullptr;
+    bool up_pending = false, down_pending = false;
+    int down_what = 0, down_frames = 0;
+    int copy_threads = 8;                    // host threads of the staging copy (LCCRF_OPT_COPY_THREADS)
+    void destroy()
+    {
+        if (up) (void)hipStreamDestroy(up);
+        if (down) (void)hipStreamDestroy(down);
+        for (hipEvent_t ev : {ev_up, ev_down, ev_q})
+            if (ev) (void)hipEventDestroy(ev);
+        up = down = nullptr;
+        ev_up = ev_down = ev_q = nullptr;
+    }
+};
+
 struct lccrf_batch {
     Engine eng;
     lccrf_batch_desc desc{};
     bool inputs_set = false, labels_bound = false;
     const int16_t *d_label = nullptr;
     const int32_t *d_pose_total = nullptr;   // lccrf_batch_pose_set_crf_counts
+    HostPipe pipe;
 };
 
 namespace {
@@ -1018,6 +1055,101 @@ int apply_option(Engine &e, int option, int value)
         return LCCRF_OK;
     default: return fail(LCCRF_E_INVALID, "unknown option %d", option);
     }
+}
+
+// caller's arrays -> pinned staging by a few host threads (one core copies ~10 GB/s, the link takes ~55): a small process-wide pool
+// of workers that sleep between batches; the calling thread takes its share of the chunks too.
+class CopyPool {
+public:
+    struct Job { char *dst; const char *src; size_t bytes; };
+    void run(const std::vector<Job> &arrays, int max_threads)
+    {
+        constexpr size_t kChunk = (size_t)512 << 10;
+        std::vector<Job> chunks;
+        size_t total = 0;
+        for (const Job &j : arrays)
+            for (size_t lo = 0; lo < j.bytes; lo += kChunk) {
+                chunks.push_back({j.dst + lo, j.src + lo, std::min(kChunk, j.bytes - lo)});
+                total += chunks.back().bytes;
+            }
+        const int want = (int)std::min<size_t>((size_t)std::max(max_threads, 1), (total + 4 * kChunk - 1) / (4 * kChunk));
+        if (want <= 1 || chunks.size() < 2) {
+            for (const Job &c : chunks) memcpy(c.dst, c.src, c.bytes);
+            return;
+        }
+        std::unique_lock<std::mutex> lk(m_);
+        while ((int)workers_.size() < want - 1) workers_.emplace_back([this] { worker(); });
+        jobs_ = &chunks;
+        next_ = 0;
+        left_ = chunks.size();
+        helpers_ = want - 1;
+        ++epoch_;
+        lk.unlock();
+        cv_.notify_all();
+        take();                                            // the caller works too
+        lk.lock();
+        done_.wait(lk, [this] { return left_ == 0 && busy_ == 0; });
+        jobs_ = nullptr;
+    }
+    ~CopyPool()
+    {
+        {
+            std::lock_guard<std::mutex> g(m_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        for (auto &t : workers_) t.join();
+    }
+
+private:
+    void take()
+    {
+        for (;;) {
+            std::unique_lock<std::mutex> lk(m_);
+            if (!jobs_ || next_ >= jobs_->size()) return;
+            const Job c = (*jobs_)[next_++];
+            lk.unlock();
+            memcpy(c.dst, c.src, c.bytes);
+            lk.lock();
+            if (--left_ == 0) done_.notify_all();
+        }
+    }
+    void worker()
+    {
+        unsigned long seen = 0;
+        for (;;) {
+            std::unique_lock<std::mutex> lk(m_);
+            cv_.wait(lk, [&] { return stop_ || (epoch_ != seen && helpers_ > 0); });
+            if (stop_) return;
+            seen = epoch_;
+            --helpers_;
+            ++busy_;
+            lk.unlock();
+            take();
+            lk.lock();
+            if (--busy_ == 0 && left_ == 0) done_.notify_all();
+        }
+    }
+    std::mutex m_;
+    std::condition_variable cv_, done_;
+    std::vector<std::thread> workers_;
+    const std::vector<Job> *jobs_ = nullptr;
+    size_t next_ = 0, left_ = 0;
+    int helpers_ = 0, busy_ = 0;
+    unsigned long epoch_ = 0;
+    bool stop_ = false;
+};
+CopyPool g_copy_pool;
+std::mutex g_copy_pool_user;                               // (one batch stages at a time; handles on other threads queue up)
+
+template <typename T>
+int pinned_plain(Arena &mem, T **out, size_t count)      // ordinary (cached, DMA-friendly) pinned memory owned by the arena
+{
+    void *p = nullptr;
+    HIP_TRY(hipHostMalloc(&p, (count ? count : 1) * sizeof(T), hipHostMallocDefault));
+    mem.pinned.push_back(p);
+    *out = static_cast<T *>(p);
+    return LCCRF_OK;
 }
 }  // namespace
 
@@ -1088,7 +1220,7 @@ int lccrf_create(lccrf_handle *out, int device_id, int n_points, int n_labels)
     h->eng.crf.map = h->map_pin;
     h->eng.map_host = h->map_pin;
     h->eng.crf.map_bits = nullptr;                       // the packed copy is the batch API's gather payload only
-    static const bool no_late = getenv("LCCRF_NO_LATE") != nullptr;   // debugging aid: always size the fused kernel on the host
+    static const bool no_late = ab_env("LCCRF_NO_LATE") != nullptr;   // debugging aid: always size the fused kernel on the host
     h->eng.late_ok = !no_late;
     h->label_stage_busy = false;    // a parked engine's stream is idle (recycle() synchronised it or saw the frame kernel's done word, its last store)
     // the kernels read the point count where the host wrote it (pinned, device-visible): no upload command on a path
@@ -1096,7 +1228,12 @@ int lccrf_create(lccrf_handle *out, int device_id, int n_points, int n_labels)
     *h->stage_n = n_points;
     h->eng.crf.n_points = h->stage_n;
     if (n_points > kObjectPinnedMaxPoints) {             // (large frames: every wavefront of every kernel reads the count)
-        HIP_TRY(hipMemcpyAsync(h->eng.npoints_own, h->stage_n, sizeof(int), hipMemcpyHostToDevice, h->eng.stream));
+        const hipError_t ec = hipMemcpyAsync(h->eng.npoints_own, h->stage_n, sizeof(int), hipMemcpyHostToDevice, h->eng.stream);
+        if (ec != hipSuccess) {                          // (the handle is neither parked nor handed out yet: do not leak it -- ADVICE r4)
+            h->eng.destroy();
+            delete h;
+            return fail(LCCRF_E_HIP, "hipMemcpyAsync(n_points): %s", hipGetErrorString(ec));
+        }
         h->eng.crf.n_points = h->eng.npoints_own;
     }
     h->eng.sync_views();
@@ -1129,6 +1266,11 @@ int lccrf_set_option(lccrf_handle h, int option, int value)
 int lccrf_batch_set_option(lccrf_batch_handle b, int option, int value)
 {
     if (!b) return fail(LCCRF_E_INVALID, "handle is NULL");
+    if (option == LCCRF_OPT_COPY_THREADS) {
+        if (value < 1 || value > 64) return fail(LCCRF_E_INVALID, "LCCRF_OPT_COPY_THREADS takes 1 .. 64");
+        b->pipe.copy_threads = value;
+        return LCCRF_OK;
+    }
     return apply_option(b->eng, option, value);
 }
 
@@ -1556,7 +1698,10 @@ void lccrf_batch_destroy(lccrf_batch_handle b)
 {
     if (!b) return;
     (void)hipSetDevice(b->eng.device);
+    if (b->pipe.up) (void)hipStreamSynchronize(b->pipe.up);
+    if (b->pipe.down) (void)hipStreamSynchronize(b->pipe.down);
     b->eng.destroy();
+    b->pipe.destroy();
     delete b;
 }
 
@@ -1613,6 +1758,181 @@ int lccrf_batch_set_inputs_host(lccrf_batch_handle b, int n_frames, const int32_
     e.sync_views();
     e.unary_set = true;
     b->inputs_set = true;
+    return LCCRF_OK;
+}
+
+static int pipe_init(lccrf_batch *b)
+{
+    HostPipe &p = b->pipe;
+    if (p.up) return LCCRF_OK;
+    Engine &e = b->eng;
+    HIP_TRY(hipStreamCreateWithFlags(&p.up, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&p.down, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&p.ev_up, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&p.ev_down, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&p.ev_q, hipEventDisableTiming));
+    (void)e;
+    return LCCRF_OK;
+}
+
+int lccrf_batch_set_inputs_host_async(lccrf_batch_handle b, int n_frames, const int32_t *n_points, const float *unary,
+                                      const int16_t *label, const float *conf, const float *const *features, int flags)
+{
+    CHECK_H(b);
+    if (!n_points) return fail(LCCRF_E_INVALID, "n_points is NULL");
+    if (b->desc.n_kernels && !features) return fail(LCCRF_E_INVALID, "features is NULL");
+    if (flags & ~LCCRF_HOST_PINNED) return fail(LCCRF_E_INVALID, "unknown flags 0x%x", flags);
+    for (int k = 0; k < b->desc.n_kernels; ++k)
+        if (!features[k]) return fail(LCCRF_E_INVALID, "features[%d] is NULL", k);
+    int rc = batch_common_inputs(b, n_frames, conf, unary != nullptr, label != nullptr);   // (settles what the previous batch on this handle left pending)
+    if (rc) return rc;
+    Engine &e = b->eng;
+    HostPipe &p = b->pipe;
+    for (int f = 0; f < n_frames; ++f)
+        if (n_points[f] < 0 || n_points[f] > e.maxN) return fail(LCCRF_E_CAPACITY, "n_points[%d]=%d not in [0,%d]", f, n_points[f], e.maxN);
+    e.activeN = 0;
+    for (int f = 0; f < n_frames; ++f) e.activeN = std::max(e.activeN, n_points[f]);
+    if ((rc = pipe_init(b))) return rc;
+    const bool direct = (flags & LCCRF_HOST_PINNED) != 0;
+    const size_t per = (size_t)e.maxN, Fz = (size_t)n_frames, Fc = (size_t)e.Fcap;
+    if (p.up_pending) {                                // the staging set is still the source of the previous upload (normally long done)
+        HIP_TRY(hipEventSynchronize(p.ev_up));
+        p.up_pending = false;
+    }
+    const int32_t *src_np = n_points;
+    const float *src_un = unary;
+    const int16_t *src_lb = label;
+    std::vector<const float *> src_ft(features, features + b->desc.n_kernels);
+    if (!direct) {                                     // copy out of the caller's buffers before returning
+        std::vector<CopyPool::Job> jobs;
+        if (!p.npoints && (rc = pinned_plain(e.mem, &p.npoints, Fc))) return rc;
+        memcpy(p.npoints, n_points, sizeof(int) * Fz);
+        src_np = p.npoints;
+        if (unary) {
+            if (!p.unary && (rc = pinned_plain(e.mem, &p.unary, Fc * per * e.L))) return rc;
+            jobs.push_back({(char *)p.unary, (const char *)unary, sizeof(float) * Fz * per * e.L});
+            src_un = p.unary;
+        } else {
+            if (!p.label && (rc = pinned_plain(e.mem, &p.label, Fc * per))) return rc;
+            jobs.push_back({(char *)p.label, (const char *)label, sizeof(int16_t) * Fz * per});
+            src_lb = p.label;
+        }
+        p.feat.resize(b->desc.n_kernels, nullptr);
+        for (int k = 0; k < b->desc.n_kernels; ++k) {
+            const int d = e.kernels[k].dev.d;
+            if (!p.feat[k] && (rc = pinned_plain(e.mem, &p.feat[k], Fc * per * d))) return rc;
+            jobs.push_back({(char *)p.feat[k], (const char *)features[k], sizeof(float) * Fz * per * d});
+            src_ft[k] = p.feat[k];
+        }
+        std::lock_guard<std::mutex> g(g_copy_pool_user);
+        g_copy_pool.run(jobs, p.copy_threads);
+    }
+    // the upload waits for everything queued on the batch's stream so far (a kernel of the previous batch may still read the
+    // device copies), and whatever is queued from here on waits for the upload
+    HIP_TRY(hipEventRecord(p.ev_q, e.stream));
+    HIP_TRY(hipStreamWaitEvent(p.up, p.ev_q, 0));
+    HIP_TRY(hipMemcpyAsync(e.npoints_own, src_np, sizeof(int) * Fz, hipMemcpyHostToDevice, p.up));
+    e.crf.n_points = e.npoints_own;
+    e.crf.unary = e.unary_own;
+    if (unary) {
+        HIP_TRY(hipMemcpyAsync(e.unary_own, src_un, sizeof(float) * Fz * per * e.L, hipMemcpyHostToDevice, p.up));
+        e.unary_deferred = false;
+        e.unary_is_label = false;
+        e.unary_p_valid = false;
+    } else {
+        HIP_TRY(hipMemcpyAsync(e.label_own, src_lb, sizeof(int16_t) * Fz * per, hipMemcpyHostToDevice, p.up));
+        e.defer_unary_from_label(e.label_own, conf);
+    }
+    for (int k = 0; k < b->desc.n_kernels; ++k) {
+        KernelState &ks = e.kernels[k];
+        HIP_TRY(hipMemcpyAsync(ks.feat_own, src_ft[k], sizeof(float) * Fz * per * ks.dev.d, hipMemcpyHostToDevice, p.up));
+        ks.dev.feat = ks.feat_own;
+    }
+    HIP_TRY(hipEventRecord(p.ev_up, p.up));
+    HIP_TRY(hipStreamWaitEvent(e.stream, p.ev_up, 0));
+    p.up_pending = true;
+    e.sync_views();
+    e.unary_set = true;
+    b->inputs_set = true;
+    return LCCRF_OK;
+}
+
+int lccrf_batch_wait_inputs(lccrf_batch_handle b)
+{
+    CHECK_H(b);
+    if (b->pipe.up_pending) {
+        HIP_TRY(hipEventSynchronize(b->pipe.ev_up));
+        b->pipe.up_pending = false;
+    }
+    return LCCRF_OK;
+}
+
+static int pipe_queue_download(lccrf_batch *b, hipStream_t on)
+{
+    Engine &e = b->eng;
+    HostPipe &p = b->pipe;
+    const size_t Fz = (size_t)p.down_frames, per = (size_t)e.maxN;
+    if (p.down_what & LCCRF_DOWNLOAD_LABEL_BITS)
+        HIP_TRY(hipMemcpyAsync(p.bits, e.crf.map_bits, sizeof(uint64_t) * Fz * e.crf.bits_stride, hipMemcpyDeviceToHost, on));
+    if (p.down_what & LCCRF_DOWNLOAD_MAP)
+        HIP_TRY(hipMemcpyAsync(p.map, e.crf.map, sizeof(int16_t) * Fz * per, hipMemcpyDeviceToHost, on));
+    if (p.down_what & LCCRF_DOWNLOAD_PROBABILITY)
+        HIP_TRY(hipMemcpyAsync(p.prob, e.crf.Q, sizeof(float) * Fz * per * e.L, hipMemcpyDeviceToHost, on));
+    return LCCRF_OK;
+}
+
+int lccrf_batch_download_async(lccrf_batch_handle b, int what)
+{
+    CHECK_H(b);
+    Engine &e = b->eng;
+    HostPipe &p = b->pipe;
+    if (!what || (what & ~(LCCRF_DOWNLOAD_LABEL_BITS | LCCRF_DOWNLOAD_MAP | LCCRF_DOWNLOAD_PROBABILITY)))
+        return fail(LCCRF_E_INVALID, "what = 0x%x: a combination of LCCRF_DOWNLOAD_*", what);
+    if ((what & LCCRF_DOWNLOAD_LABEL_BITS) && !e.crf.map_bits) return fail(LCCRF_E_INVALID, "label bits exist for n_labels == 2 only");
+    int rc = pipe_init(b);
+    if (rc) return rc;
+    if (p.down_pending) {                              // (the host copies of the previous download are about to be overwritten)
+        HIP_TRY(hipEventSynchronize(p.ev_down));
+        p.down_pending = false;
+    }
+    const size_t Fc = (size_t)e.Fcap, per = (size_t)e.maxN;
+    if ((what & LCCRF_DOWNLOAD_LABEL_BITS) && !p.bits && (rc = pinned_plain(e.mem, &p.bits, Fc * std::max(e.crf.bits_stride, 1)))) return rc;
+    if ((what & LCCRF_DOWNLOAD_MAP) && !p.map && (rc = pinned_plain(e.mem, &p.map, Fc * per))) return rc;
+    if ((what & LCCRF_DOWNLOAD_PROBABILITY) && !p.prob && (rc = pinned_plain(e.mem, &p.prob, Fc * per * e.L))) return rc;
+    p.down_what = what;
+    p.down_frames = e.F;
+    // behind everything queued on the batch's stream (calls on a caller's stream are ordered into it when they return), on the
+    // download stream; the batch's stream in turn waits for the copies before anything may overwrite the results
+    HIP_TRY(hipEventRecord(p.ev_q, e.stream));
+    HIP_TRY(hipStreamWaitEvent(p.down, p.ev_q, 0));
+    if ((rc = pipe_queue_download(b, p.down))) return rc;
+    HIP_TRY(hipEventRecord(p.ev_down, p.down));
+    HIP_TRY(hipStreamWaitEvent(e.stream, p.ev_down, 0));
+    p.down_pending = true;
+    return LCCRF_OK;
+}
+
+int lccrf_batch_wait_download(lccrf_batch_handle b, const uint64_t **label_bits, int *words_per_frame, const int16_t **map,
+                              const float **probability)
+{
+    CHECK_H(b);
+    Engine &e = b->eng;
+    HostPipe &p = b->pipe;
+    if (!p.down_pending) return fail(LCCRF_E_STATE, "no download queued (lccrf_batch_download_async)");
+    HIP_TRY(hipEventSynchronize(p.ev_down));
+    p.down_pending = false;
+    // a one-launch run may have flagged frames that did not fit: they are re-run here (resolve_late), and then the copies are stale
+    const bool was_late = e.late_pending;
+    int rc = e.resolve_late();
+    if (rc) return rc;
+    if (was_late && e.fallback_frames > 0) {
+        if ((rc = pipe_queue_download(b, e.stream))) return rc;
+        HIP_TRY(hipStreamSynchronize(e.stream));
+    }
+    if (label_bits) *label_bits = (p.down_what & LCCRF_DOWNLOAD_LABEL_BITS) ? p.bits : nullptr;
+    if (words_per_frame) *words_per_frame = e.crf.bits_stride;
+    if (map) *map = (p.down_what & LCCRF_DOWNLOAD_MAP) ? p.map : nullptr;
+    if (probability) *probability = (p.down_what & LCCRF_DOWNLOAD_PROBABILITY) ? p.prob : nullptr;
     return LCCRF_OK;
 }
 
@@ -1847,6 +2167,19 @@ int lccrf_batch_get_fused_shape(lccrf_batch_handle b, int *lanes_per_frame, int 
     if (!lanes_per_frame || !frames_per_cu) return fail(LCCRF_E_INVALID, "output pointer is NULL");
     *lanes_per_frame = b->eng.fused_shape & 0xffff;
     *frames_per_cu = b->eng.fused_shape >> 16;
+    return LCCRF_OK;
+}
+
+int lccrf_batch_get_locality_mode(lccrf_batch_handle b, int *internal_point_order, int *sorted_build)
+{
+    CHECK_H(b);
+    Engine &e = b->eng;
+    if (e.built) {                                      // (a build that met an overflowing / wrapping frame is redone with the hash here)
+        int rc = e.learn_sizes();
+        if (rc) return rc;
+    }
+    if (internal_point_order) *internal_point_order = e.perm_on ? 1 : 0;
+    if (sorted_build) *sorted_build = (e.perm_on && e.vorder_on && !e.vorder_broken) ? 1 : 0;
     return LCCRF_OK;
 }
 

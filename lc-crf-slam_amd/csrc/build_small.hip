@@ -473,7 +473,7 @@ bool build_small_supported(const KernelDev *kds, int n, int NA)
 void launch_build_small(const KernelDev *kds, int n, int NA, const CrfDev &c, hipStream_t s)
 {
     const SmallPlan p = small_plan(kds[0], NA);          // same d and same capacities for all n
-    static const int want_stamps = (kInstr && getenv("LCCRF_BUILD_TIMING")) ? std::max(atoi(getenv("LCCRF_BUILD_TIMING")), 1) : 0;   // 1 + kernel index
+    static const int want_stamps = (kInstr && ab_env("LCCRF_BUILD_TIMING")) ? std::max(atoi(ab_env("LCCRF_BUILD_TIMING")), 1) : 0;   // 1 + kernel index
     const dim3 grid(c.F, n);
     const KernelDev &k0 = kds[0], &k1 = kds[n - 1];
 #define BUILD_CASE(DD)                                                                                  \

@@ -10,9 +10,25 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <stdlib.h>
+
 #include "../../include/lccrf.h"
 
+#ifndef LCCRF_INSTRUMENT
+#define LCCRF_INSTRUMENT 0
+#endif
+
 namespace lccrf {
+
+// A/B, cross-check and fault-injection switches -- environment variables that choose between code paths with identical results --
+// exist in the INSTRUMENTED library only (`make INSTRUMENT=1` -> liblccrf_hip_instr.so, which tests and scripts load through
+// LCCRF_LIB).  The release library reads no environment variable: a tracker inherits its environment, and none of these should be
+// able to change its speed.  What a deployment may legitimately choose is an option of the API (lccrf_set_option).
+#if LCCRF_INSTRUMENT
+inline const char *ab_env(const char *name) { return getenv(name); }
+#else
+inline const char *ab_env(const char *) { return nullptr; }
+#endif
 
 constexpr int kMaxD = LCCRF_MAX_DIMS;
 constexpr int kEmpty = -1;

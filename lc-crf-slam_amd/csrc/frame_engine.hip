@@ -176,6 +176,7 @@ __global__ void __launch_bounds__(NT, 4) k_frame(CrfDev c, FrameArgs a)
     };
     if (N <= 0) {                                         // an empty frame has no lattice (V = 0) and nothing to infer
         if (role == 0) {
+            if (a.with_map) clear_label_bits<NT>(c, f, 0, tid);
             if (tid < K && a.V_out[tid]) a.V_out[tid][f] = 0;
             if (tid == 0 && a.frame_status) a.frame_status[f] = 0;
             publish_done();
@@ -886,18 +887,18 @@ bool launch_frame(const CrfDev &c, const KernelDev *kds, int n_iter, int with_ma
     a.dual_epoch = dual_epoch;
     a.done = c.F == 1 ? done : nullptr;
 #if LCCRF_INSTRUMENT
-    static const bool drop_helper = getenv("LCCRF_DUAL_DROP_HELPER") != nullptr;   // fault injection: not compiled into the release library
+    static const bool drop_helper = ab_env("LCCRF_DUAL_DROP_HELPER") != nullptr;   // fault injection: not compiled into the release library
     a.drop_helper = drop_helper ? 1 : 0;
 #endif
     a.n_single = (c.F == 1 && done && c.activeN > 0) ? c.activeN : -1;   // (object API: activeN IS the frame's count)
     a.done_epoch = done_epoch;
     static long long *timing_buf = nullptr;
-    static const bool want_timing = kInstr && getenv("LCCRF_FRAME_TIMING") != nullptr;
+    static const bool want_timing = kInstr && ab_env("LCCRF_FRAME_TIMING") != nullptr;
     if (want_timing && !timing_buf) (void)hipMalloc(&timing_buf, 64 * sizeof(long long));
     a.timing = want_timing ? timing_buf : nullptr;
-    a.timing_block = want_timing ? std::max(atoi(getenv("LCCRF_FRAME_TIMING")) - 1, 0) : 0;
+    a.timing_block = want_timing ? std::max(atoi(ab_env("LCCRF_FRAME_TIMING")) - 1, 0) : 0;
     if (a.timing_block >= (dual ? 2 : 1) * c.F) a.timing_block = 0;     // (two-workgroup form: block 2f is frame f's main workgroup, 2f + 1 its helper)
-    a.timing_lane = (want_timing && getenv("LCCRF_FRAME_TIMING_LANE")) ? atoi(getenv("LCCRF_FRAME_TIMING_LANE")) & (kNT - 1) : 0;
+    a.timing_lane = (want_timing && ab_env("LCCRF_FRAME_TIMING_LANE")) ? atoi(ab_env("LCCRF_FRAME_TIMING_LANE")) & (kNT - 1) : 0;
     // Small frames: 512 lanes and half the CU's LDS per frame, so that two frames share a CU.  A frame whose lattices
     // do not fit that plan (or whose long rows need more chain lanes than four wavefront pairs have) flags itself
     // and is re-run like any other frame that does not fit.
@@ -906,7 +907,7 @@ bool launch_frame(const CrfDev &c, const KernelDev *kds, int n_iter, int with_ma
     // vertices, a smoothness kernel of min(NA + 350, 1150) (734 vertices at 400 points, 985 at 700, 1071 at 1000 on
     // 640x480 images with an 18-pixel kernel) -- i.e. up to 1024 points.  Frames with larger lattices flag themselves and
     // are re-run; an engine that sees more than 1/8 of a batch flagged stops asking for this shape (allow_small).
-    static const bool no_small = getenv("LCCRF_NO_SMALL_WG") != nullptr;   // A/B switch: same results either way
+    static const bool no_small = ab_env("LCCRF_NO_SMALL_WG") != nullptr;   // A/B switch: same results either way
     bool small = allow_small && !no_small && NA <= 2 * kNTSmall && c.F >= kSmallMinFrames;
     if (small) {
         int vest[kMaxFusedK], tables = 0;
@@ -923,7 +924,7 @@ bool launch_frame(const CrfDev &c, const KernelDev *kds, int n_iter, int with_ma
         if (c.K == 1) launch_frame_ppt<NT, P, 1>(c, a, s);     \
         else launch_frame_ppt<NT, P, 2>(c, a, s);              \
         break;
-    static const bool no_dual = getenv("LCCRF_NO_DUAL") != nullptr;         // A/B switch: same results either way
+    static const bool no_dual = ab_env("LCCRF_NO_DUAL") != nullptr;         // A/B switch: same results either way
     if (dual && !no_dual && c.K == 2 && !small) {                           // a frame alone: two workgroups, one per lattice build
         switch ((NA + kNT - 1) / kNT) {
         case 1: launch_frame_dual<1>(c, a, s); break;

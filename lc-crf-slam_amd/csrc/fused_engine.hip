@@ -65,7 +65,10 @@ __global__ void __launch_bounds__(NT, 4) k_fused(CrfDev c, FusedArgs a)
 #pragma unroll
     for (int k = 0; k < K; ++k) V[k] = a.kd[k].V[f];
 
-    if (N <= 0) return;                   // nothing to infer (and nothing below may index an empty frame)
+    if (N <= 0) {                         // nothing to infer (and nothing below may index an empty frame)
+        if (a.with_map) clear_label_bits<NT>(c, f, 0, tid);
+        return;
+    }
     const FusedLayout &lay = a.lay;
     if (FL_DBG(4)) {                      // debugging aid: NaN-poison the LDS so that reads of unwritten LDS show up
         for (int i = tid; i < lay.total / 4; i += NT) reinterpret_cast<unsigned *>(smem)[i] = 0x7fc00000u + (unsigned)i;
@@ -188,7 +191,10 @@ __global__ void __launch_bounds__(NT, NT == 384 ? 3 : 4) k_fused_lean(CrfDev c, 
     int V[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) V[k] = a.kd[k].V[f];
-    if (N <= 0) return;
+    if (N <= 0) {
+        if (a.with_map) clear_label_bits<NT>(c, f, 0, tid);
+        return;
+    }
     const FusedLayout &lay = a.lay;
 
     // per-point records first (the long pole of the prologue), then the lattice tables
@@ -289,7 +295,7 @@ bool make_layout(const CrfDev &c, const KernelDev *kds, const int *maxV, const i
 // kernel 0 has long rows -- few enough vertices for the chain lanes of four wavefront pairs.
 bool small_layout(const CrfDev &c, const KernelDev *kds, const int *maxV, const int *maxRow, FusedLayout *lay)
 {
-    static const bool off = getenv("LCCRF_NO_SMALL_WG") != nullptr;      // A/B switch: same results either way
+    static const bool off = ab_env("LCCRF_NO_SMALL_WG") != nullptr;      // A/B switch: same results either way
     const int NA = c.activeN > 0 ? c.activeN : c.maxN;
     if (off || c.F < kSmallMinFrames || NA > 2 * kNTSmall || maxV[0] > kNTSmall) return false;
     const int row0 = maxRow ? maxRow[0] : 0;
@@ -306,7 +312,7 @@ bool small_layout(const CrfDev &c, const KernelDev *kds, const int *maxV, const 
 // against 3.67e7 for one 1024-lane frame per CU: twelve wavefronts per CU do not keep the LDS pipe busy)
 int lean_shape()
 {
-    static const char *e = getenv("LCCRF_LEAN_SHAPE");                   // A/B switch: 0 = one 1024-lane frame per CU (same results)
+    static const char *e = ab_env("LCCRF_LEAN_SHAPE");                   // A/B switch: 0 = one 1024-lane frame per CU (same results)
     static const int v = e ? atoi(e) : 2;
     return v;
 }
@@ -387,7 +393,7 @@ int launch_inference_fused(const CrfDev &c, const KernelDev *kds, const int *max
     int lean_nt = 0;
     const bool lean = !small && lean_layout(c, kds, maxV, maxRow, &a.lay, &lean_nt);
     if (!small && !lean && !make_layout(c, kds, maxV, maxRow, &a.lay)) return 0;
-    static const bool no_chain = getenv("LCCRF_NO_CHAIN") != nullptr;     // debugging aid: compiler-scheduled S phase
+    static const bool no_chain = ab_env("LCCRF_NO_CHAIN") != nullptr;     // debugging aid: compiler-scheduled S phase
     if (no_chain) a.lay.chain0 = 0;                                        // (the padded plane size is harmless)
     for (int k = 0; k < c.K; ++k) a.kd[k] = kds[k];
     a.n_iter = n_iter;
@@ -395,13 +401,13 @@ int launch_inference_fused(const CrfDev &c, const KernelDev *kds, const int *max
     a.relax = relax;
     a.omr = 1 - relax;
     static long long *timing_buf = nullptr;
-    static const bool want_timing = kInstr && getenv("LCCRF_FUSED_TIMING") != nullptr;
+    static const bool want_timing = kInstr && ab_env("LCCRF_FUSED_TIMING") != nullptr;
     if (want_timing && !timing_buf) (void)hipMalloc(&timing_buf, 64 * sizeof(long long));
     a.timing = want_timing ? timing_buf : nullptr;
-    a.timing_block = want_timing ? std::max(atoi(getenv("LCCRF_FUSED_TIMING")) - 1, 0) : 0;
+    a.timing_block = want_timing ? std::max(atoi(ab_env("LCCRF_FUSED_TIMING")) - 1, 0) : 0;
     if (a.timing_block >= c.F) a.timing_block = 0;
-    a.timing_lane = (want_timing && getenv("LCCRF_FUSED_TIMING_LANE")) ? atoi(getenv("LCCRF_FUSED_TIMING_LANE")) & (kNT - 1) : 0;
-    static const int dbg = (kInstr && getenv("LCCRF_FUSED_DBG")) ? atoi(getenv("LCCRF_FUSED_DBG")) : 0;
+    a.timing_lane = (want_timing && ab_env("LCCRF_FUSED_TIMING_LANE")) ? atoi(ab_env("LCCRF_FUSED_TIMING_LANE")) & (kNT - 1) : 0;
+    static const int dbg = (kInstr && ab_env("LCCRF_FUSED_DBG")) ? atoi(ab_env("LCCRF_FUSED_DBG")) : 0;
     a.dbg = dbg;
     const int NAp = c.activeN > 0 ? c.activeN : c.maxN;
     if (small) {

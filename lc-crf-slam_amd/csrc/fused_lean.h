@@ -357,21 +357,46 @@ __device__ __forceinline__ void mean_field_lean(unsigned char *smem, const Fused
             }
             return;
         }
+        // short rows: one lane per vertex sums both labels (products are stored label-interleaved), 8 at a time; a lane past the
+        // end of its row reads the zero block (x + 0 is exact, see chain_rows).  This lane's rows (vertices t, t + NT, ...) are walked
+        // TOGETHER: every row's pointers first, then every row's first eight products -- most rows of a smoothness kernel end there --
+        // so the phase waits for two rounds of LDS latency instead of two per row; each row is still added strictly left to right.
         const float2 *pl = reinterpret_cast<const float2 *>(smem + lay.prod[k]);
         const float2 *zero = reinterpret_cast<const float2 *>(smem + lay.zero);
         const unsigned short *row = reinterpret_cast<const unsigned short *>(smem + lay.row[k]);
-        for (int v = t; v < V[k]; v += NT) {
-            const int pe = row[v + 1];
-            float a0 = 0.0f, a1 = 0.0f;
-            for (int p = row[v]; p < pe; p += 8) {
-                float2 x[8];
+        // (two large short-row lattices -- K = 2 without a chain kernel, which rarely fits this plan's LDS anyway -- keep one row at a
+        // time: 48 registers of products beside that variant's other state would spill)
+        constexpr int RS = (K == 2 && CH == 0) ? 1 : lean_rounds(NT);
+        for (int base = 0; base < lean_rounds(NT); base += RS) {
+            int p0[RS], pe[RS];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) x[u] = *((p + u < pe) ? pl + p + u : zero);
-#pragma unroll
-                for (int u = 0; u < 8; ++u) { a0 += x[u].x; a1 += x[u].y; }   // strictly left to right
+            for (int r = 0; r < RS; ++r) {
+                const int v = t + (base + r) * NT;
+                p0[r] = pe[r] = 0;
+                if (v < V[k]) { p0[r] = row[v]; pe[r] = row[v + 1]; }
             }
-            reinterpret_cast<float2 *>(val)[v + 1] = make_float2(a0, a1);
+            float2 x[RS][8];
+#pragma unroll
+            for (int r = 0; r < RS; ++r)
+#pragma unroll
+                for (int u = 0; u < 8; ++u) x[r][u] = *((p0[r] + u < pe[r]) ? pl + p0[r] + u : zero);
+#pragma unroll
+            for (int r = 0; r < RS; ++r) {
+                const int v = t + (base + r) * NT;
+                float a0 = 0.0f, a1 = 0.0f;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { a0 += x[r][u].x; a1 += x[r][u].y; }   // strictly left to right
+                for (int p = p0[r] + 8; p < pe[r]; p += 8) {                         // (rows of more than eight products)
+                    float2 y[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) y[u] = *((p + u < pe[r]) ? pl + p + u : zero);
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) { a0 += y[u].x; a1 += y[u].y; }
+                }
+                if (v < V[k]) reinterpret_cast<float2 *>(val)[v + 1] = make_float2(a0, a1);
+            }
         }
+        (void)V;
     };
     // neighbour words of a lattice whose table stays in HBM / L2: all d+1 passes' words of this lane's vertices (t, t + NT, ...) are
     // requested at the top of the iteration and land under the row sums (requested pass by pass they were what a pass waited for:

@@ -583,6 +583,15 @@ __device__ __forceinline__ void mean_field(unsigned char *smem, const FusedLayou
     }
 }
 
+// The label bits beyond a frame's points are 0 (include/lccrf.h: lccrf_batch_device_label_bits): the words from `first_word` on are
+// cleared, so that a batch handle used again with smaller frames does not hand the gather the last batch's bits.
+template <int NT>
+__device__ __forceinline__ void clear_label_bits(const CrfDev &c, int f, int first_word, int tid)
+{
+    if (c.map_bits)
+        for (int w = first_word + tid; w < c.bits_stride; w += NT) c.map_bits[(size_t)f * c.bits_stride + w] = 0ull;
+}
+
 // Q and the MAP labels (densecrf3d.h:136-151: first maximum wins, ties -> label 0) of this lane's points.
 template <int PPT, int K, int NT = kNT>
 __device__ __forceinline__ void store_results(const CrfDev &c, int f, int N, int tid, const PointRegs<PPT, K> &pr, int with_map)
@@ -599,6 +608,7 @@ __device__ __forceinline__ void store_results(const CrfDev &c, int f, int N, int
             if ((tid & 63) == 0) c.map_bits[(size_t)f * c.bits_stride + (i >> 6)] = m;
         }
     }
+    if (with_map) clear_label_bits<NT>(c, f, (N + 63) >> 6, tid);
 }
 
 }  // namespace fl

@@ -591,7 +591,7 @@ hipError_t launch_pose_optimization(int F, int maxN, const int *n_points, const 
     a.maxN = maxN; a.n_points = n_points; a.Xw = Xw; a.kp = kp; a.ur = ur; a.is2 = is2; a.valid = valid; a.label = label;
     a.fx = K4[0]; a.fy = K4[1]; a.cx = K4[2]; a.cy = K4[3]; a.bf = bf;
     a.Tcw_in = Tcw_in; a.Tcw_out = Tcw_out; a.outlier = outlier; a.n_inliers = n_inliers; a.n_initial = n_initial;
-    static const bool want_prof = kInstr && getenv("LCCRF_POSE_PROF") != nullptr;
+    static const bool want_prof = kInstr && ab_env("LCCRF_POSE_PROF") != nullptr;
     if (want_prof) {
         if (hipHostMalloc(reinterpret_cast<void **>(&a.prof), 16 * sizeof(long long)) != hipSuccess) return hipErrorOutOfMemory;
         for (int i = 0; i < 16; ++i) a.prof[i] = 0;

@@ -54,7 +54,7 @@ __device__ __forceinline__ FrameBlock frame_block(XcdMap m)
 // `FRAMES=1 scripts/gpu_c5_env_ab.sh LCCRF_SMALL_F_BLOCK=256 ""`: one frame 41.0 -> 40.2 us per iteration, two 32.8 -> 32.1, four +-0)
 inline int iter_block(int F)
 {
-    static const char *e = getenv("LCCRF_SMALL_F_BLOCK");             // A/B switch: same results
+    static const char *e = ab_env("LCCRF_SMALL_F_BLOCK");             // A/B switch: same results
     static const int small = e ? std::min(std::max(atoi(e), 64), 256) & ~63 : kSmallFBlock;
     return F <= 2 ? small : 256;
 }
@@ -62,7 +62,7 @@ inline dim3 grid_xcd(long work, int F, XcdMap *m, int block = 256)
 {
     const long n = (work + block - 1) / block;
     if (n < 1) { *m = XcdMap{0, 1}; return dim3(1u, (unsigned)F); }
-    static const bool no_chunk = getenv("LCCRF_NO_XCD_CHUNK") != nullptr;   // A/B switch (same results): plain (x, frame) grid below 8 frames
+    static const bool no_chunk = ab_env("LCCRF_NO_XCD_CHUNK") != nullptr;   // A/B switch (same results): plain (x, frame) grid below 8 frames
     if (no_chunk && F < 8) { *m = XcdMap{0, 1}; return dim3((unsigned)n, (unsigned)F); }
     const long per = (n * F + 7) / 8;
     *m = XcdMap{(int)n, (int)per};
@@ -87,7 +87,7 @@ __device__ __forceinline__ void vertex_grid_coords(const int16_t (&key)[D], int 
 // VB: also leave, per workgroup, the bounds of the grid coordinates of every corner this workgroup's points touch (locality mode's
 // vertex order, see launch_sort_vertices below) in vpartial[f][blockIdx.x][2 * kMaxD]
 template <int D, bool VB>
-__global__ void __launch_bounds__(kBlock) k_points(KernelDev kd, const int *__restrict__ n_points, int *__restrict__ vpartial)
+__global__ void __launch_bounds__(kBlock) k_points(KernelDev kd, const int *__restrict__ n_points, int *__restrict__ vpartial, int *__restrict__ vbad)
 {
     constexpr int D1 = D + 1;
     __shared__ int red[VB ? kBlock / 64 : 1][2 * D];
@@ -106,6 +106,17 @@ __global__ void __launch_bounds__(kBlock) k_points(KernelDev kd, const int *__re
         const float *fp = kd.feat + ((size_t)f * kd.maxN + src) * D;
 #pragma unroll
         for (int j = 0; j < D; ++j) feat[j] = (n < N) ? fp[j] : 0.0f;   // phantom lanes, :299
+        if (VB) {
+            // Keys are int16 (the reference's `short`, permutohedral_cpu.h:304-366).  A feature thousands of cells wide wraps them, and a
+            // wrapped key is no lattice point any more: the sorted build matches neighbours by code +- stride, the hash build by the
+            // wrapped key itself -- they differ at the +-32768 seam (and when d + 1 divides 65536 the integrality check of k_ecode
+            // cannot see the wrap: ADVICE r4).  Every |elevated coordinate| <= (d+1) sum |f_j scale_j|, a key is within 2 (d+1) of it:
+            // a point that could leave the int16 range hands the frame to the hash build (pinned flag, conservative).
+            float mag = 2.0f;
+#pragma unroll
+            for (int j = 0; j < D; ++j) mag += fabsf(feat[j] * kd.scale[j]);
+            if (!(mag * (float)D1 < 32000.0f) && vbad) *vbad = 1;
+        }
 
         int16_t r0[D];
         uint8_t rk[D];
@@ -1838,8 +1849,8 @@ constexpr int kPairFuseMaxFrames = 1;        // (measured, `FRAMES=1 scripts/gpu
 constexpr long kPairFuseMaxVertices = 700000;
 inline bool pair_fuse(int F, int maxV)
 {
-    static const bool off = getenv("LCCRF_NO_PAIR_FUSE") != nullptr;      // A/B switch: same results either way
-    static const char *force = getenv("LCCRF_PAIR_FUSE_MAX");             //  (A/B: frames-in-flight threshold)
+    static const bool off = ab_env("LCCRF_NO_PAIR_FUSE") != nullptr;      // A/B switch: same results either way
+    static const char *force = ab_env("LCCRF_PAIR_FUSE_MAX");             //  (A/B: frames-in-flight threshold)
     if (off) return false;
     if (force) return F <= atoi(force);
     return F <= kPairFuseMaxFrames || (long)F * maxV <= kPairFuseMaxVertices;
@@ -1852,8 +1863,8 @@ inline void launch_blur2(const KernelDev &kd, const float *src, float *dst, int 
     XcdMap nb;
     const int blk = iter_block(F);
     const dim3 g = grid_xcd((maxV + 1) / 2, F, &nb, blk);
-    static const bool no_compact = getenv("LCCRF_NO_COMPACT_NBR") != nullptr;      // A/B switch: same results either way
-    static const char *env_nt = getenv("LCCRF_BLUR_NT");                            // A/B: 0 plain loads, 1 non-temporal
+    static const bool no_compact = ab_env("LCCRF_NO_COMPACT_NBR") != nullptr;      // A/B switch: same results either way
+    static const char *env_nt = ab_env("LCCRF_BLUR_NT");                            // A/B: 0 plain loads, 1 non-temporal
     const bool nt = env_nt ? atoi(env_nt) != 0 : F >= kBlurNtMinFrames;
     if (kd.nbrc && kd.nbrc_ok && !no_compact) {
         if (nt) k_blur2c<true><<<g, blk, 0, s>>>(kd, src, dst, j, F, nb);
@@ -2028,8 +2039,8 @@ __global__ void __launch_bounds__(kBlock) k_map(CrfDev c, const float *__restric
         lab = argmax_row(p, c.L);
         map[(size_t)f * c.maxN + i] = (int16_t)lab;
     }
-    if (c.map_bits && map == c.map && c.L == 2 && (i & ~63) < N) {           // one bit per label: the label gather's wire format
-        const unsigned long long m = __ballot(lab == 1);
+    if (c.map_bits && map == c.map && c.L == 2 && (i >> 6) < c.bits_stride) {   // one bit per label: the label gather's wire format
+        const unsigned long long m = __ballot(lab == 1);                           // (words beyond the frame's points: 0)
         if ((threadIdx.x & 63) == 0) c.map_bits[(size_t)f * c.bits_stride + (i >> 6)] = m;
     }
 }
@@ -2053,7 +2064,7 @@ void build_kernel_d(const KernelDev &kd, const CrfDev &c, hipStream_t s, const S
         // the sorted build (locality mode): entries sorted by the row-major code of their vertex
         const SortScratch &ss = *vsort;
         const int nbk = (1 << ss.vbits) + 1;
-        k_points<D, true><<<grid_for(kd.maxNpad, F), kBlock, 0, s>>>(kd, c.n_points, ss.vpartial);
+        k_points<D, true><<<grid_for(kd.maxNpad, F), kBlock, 0, s>>>(kd, c.n_points, ss.vpartial, ss.vbad);
         k_vsort_plan<<<F, kBlock, 0, s>>>(D, (int)grid_for(kd.maxNpad, F).x, ss);
         (void)hipMemsetAsync(ss.vhist, 0, (size_t)F * nbk * sizeof(int), s);
         (void)hipMemsetAsync(kd.rowmax, 0, (size_t)F * sizeof(int), s);                 // (the count of long buckets, until k_row_max)
@@ -2076,13 +2087,13 @@ void build_kernel_d(const KernelDev &kd, const CrfDev &c, hipStream_t s, const S
         if (kd.nbrc && F >= kNbrcMinFrames && F <= kNbrcMaxFrames) {
             int limit = 0xffff;
 #if LCCRF_INSTRUMENT
-            if (const char *e = getenv("LCCRF_NBRC_SPAN")) limit = std::min(std::max(atoi(e), 1), 0xffff);   // test hook: spans the table "cannot" hold
+            if (const char *e = ab_env("LCCRF_NBRC_SPAN")) limit = std::min(std::max(atoi(e), 1), 0xffff);   // test hook: spans the table "cannot" hold
 #endif
             k_nbr_compact<<<dim3(kNbrcGrid, D1, F), kBlock, 0, s>>>(kd, limit);
         }
     } else {
         (void)hipMemsetAsync(kd.slot, 0xff, (size_t)F * kd.cap * sizeof(int), s);
-        k_points<D, false><<<grid_for(kd.maxNpad, F), kBlock, 0, s>>>(kd, c.n_points, nullptr);
+        k_points<D, false><<<grid_for(kd.maxNpad, F), kBlock, 0, s>>>(kd, c.n_points, nullptr, nullptr);
         {
             XcdMap nb;
             const dim3 g = grid_xcd(kd.Epad, F, &nb);
@@ -2196,7 +2207,7 @@ void launch_step_stream(const CrfDev &c, const KernelDev *kds, const int *maxV, 
             const int blk = iter_block(c.F);
             const bool pairs = pair_fuse(c.F, maxV[k]);
             // sorted build, one pass per launch: the first pass (axis 0 = the code's fastest coordinate) rides in the splat
-            static const bool no_sb = getenv("LCCRF_NO_SPLAT_BLUR") != nullptr;               // A/B switch: same results either way
+            static const bool no_sb = ab_env("LCCRF_NO_SPLAT_BLUR") != nullptr;               // A/B switch: same results either way
             const int j0 = (kd.vorder && kd.fast0_ok && !no_sb && !kd.long_mode) ? std::max(kd.splat_passes, 1) : 0;   // passes the splat takes along
             if (j0 >= 2) {
                 const int B = kd.splat_block, core = B - 2 * kd.splat_halo;
@@ -2204,7 +2215,7 @@ void launch_step_stream(const CrfDev &c, const KernelDev *kds, const int *maxV, 
                 // many frames in flight: 256 lanes x 1 / 2 / 4 vertices (C5 x 8, window 1024: 20.6 -> 18.9 us per frame-iteration against
                 // 1024 lanes x 1: workgroups of four wavefronts wait less at the barriers); one or two frames: one or two vertices per lane
                 // (a lane's four row walks in a row cost a single frame 33.3 -> 36.1)
-                static const char *env_w = getenv("LCCRF_SPLAT_WIDE_MAX");                  // (A/B: frames-in-flight threshold)
+                static const char *env_w = ab_env("LCCRF_SPLAT_WIDE_MAX");                  // (A/B: frames-in-flight threshold)
                 const bool wide = c.F <= (env_w ? atoi(env_w) : 2);
                 const int lanes = wide ? B : kBlock;
                 const dim3 g = grid_xcd(((long)maxV[k] + core - 1) / core * lanes, c.F, &nb, lanes);
@@ -2236,13 +2247,13 @@ void launch_step_stream(const CrfDev &c, const KernelDev *kds, const int *maxV, 
             const float *src = kd.val0;
             float *dst = kd.val1;
             // the pass left over by the pairs rides in the slice; with a few frames in flight (one pass per launch) the last pass does
-            static const char *sf = getenv("LCCRF_SLICE_BLUR_MAX");                          // (A/B: frames-in-flight threshold)
+            static const char *sf = ab_env("LCCRF_SLICE_BLUR_MAX");                          // (A/B: frames-in-flight threshold)
             const bool blur_in_slice = kd.D1 <= 9 && j0 < kd.D1 && (pairs ? ((kd.D1 - j0) & 1) && kd.D1 >= 3 : c.F <= (sf ? atoi(sf) : kSliceBlurMaxFrames));   // (j0 == d + 1: a 2-D lattice's three passes can all ride in the splat)
             const int n_own = blur_in_slice ? kd.D1 - 1 : kd.D1;                           // blur passes with a launch of their own
             for (int j = j0; j < n_own;) {
                 if (pairs && j + 1 < n_own) {             // one frame in flight: two passes per launch
                     const dim3 gp = grid_xcd(maxV[k], c.F, &nb, blk);
-                    static const bool no_tbl = getenv("LCCRF_NO_2HOP_TABLE") != nullptr;      // A/B switch: same results either way
+                    static const bool no_tbl = ab_env("LCCRF_NO_2HOP_TABLE") != nullptr;      // A/B switch: same results either way
                     const int jt = j - kd.nbr2_first;     // the table holds the pairs (first, first + 1), (first + 2, first + 3) ...
                     if (kd.nbr2 && kd.nbr2_ok && !no_tbl && jt >= 0 && !(jt & 1))
                         k_blur2x2t<<<gp, blk, 0, s>>>(kd, src, dst, jt / 2, (kd.D1 - kd.nbr2_first) / 2, c.F, nb);

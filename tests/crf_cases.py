@@ -5,7 +5,22 @@ A "backend" is any class with the reference's operator surface on numpy arrays
   cls(N, L); set_unary | set_unary_from_label; add_pairwise(features, w);
   start_inference(); step_inference(relax); build_map(); probability(); map(); kernel(k)
 """
+import os
+
 import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+INSTR_LIB = os.path.join(ROOT, "lc-crf-slam_amd", "liblccrf_hip_instr.so")
+
+
+def switch_env(env=None, **more):
+    """Environment for a child process that sets A/B / cross-check switches: they exist in the INSTRUMENTED library only
+    (csrc/engine.h: ab_env), so a non-empty set of switches also selects that library through LCCRF_LIB."""
+    sw = dict(env or {}, **more)
+    out = dict(os.environ, **sw)
+    if sw:
+        out["LCCRF_LIB"] = INSTR_LIB
+    return out
 
 
 def bits(a):

@@ -364,7 +364,7 @@ def test_done_word_switch_gives_the_same_bits(wl):
     with tempfile.TemporaryDirectory() as td:
         for j, env in enumerate(({}, {"LCCRF_NO_DONE_WORD": "1"})):
             fn = os.path.join(td, "o%d.npy" % j)
-            subprocess.run([sys.executable, "-c", code, fn], check=True, env=dict(os.environ, **env), timeout=300)
+            subprocess.run([sys.executable, "-c", code, fn], check=True, env=cc.switch_env(env), timeout=300)
             res.append(np.load(fn))
     assert cc.same_bits(res[0], res[1])
 
@@ -387,7 +387,7 @@ np.save(sys.argv[1], np.concatenate([o.ravel() for o in out]))
     for env in ({}, {"LCCRF_NO_FRAME": "1"}):
         path = os.path.join(ROOT, "gpurun_out", "noframe_%d.npy" % len(res))
         os.makedirs(os.path.dirname(path), exist_ok=True)
-        subprocess.run([sys.executable, "-c", code, path], check=True, env=dict(os.environ, **env), timeout=600)
+        subprocess.run([sys.executable, "-c", code, path], check=True, env=cc.switch_env(env), timeout=600)
         res.append(np.load(path))
     assert cc.same_bits(res[0], res[1])
 
@@ -428,7 +428,7 @@ np.save(sys.argv[1], np.concatenate([o.ravel() for o in out]))
     for env in ({}, {"LCCRF_NO_DUAL": "1"}):
         path = os.path.join(ROOT, "gpurun_out", "dual_%d.npy" % len(res))
         os.makedirs(os.path.dirname(path), exist_ok=True)
-        subprocess.run([sys.executable, "-c", code, path], check=True, env=dict(os.environ, **env), timeout=600)
+        subprocess.run([sys.executable, "-c", code, path], check=True, env=cc.switch_env(env), timeout=600)
         res.append(np.load(path))
     assert cc.same_bits(res[0], res[1])
 
@@ -644,6 +644,6 @@ for pick in ((0,), (1,), (1, 1)):
         o.close()
 print("ok")
 """ % (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle"), shape)
-    env = dict(os.environ, LCCRF_LEAN_SHAPE=shape)
+    env = cc.switch_env(LCCRF_LEAN_SHAPE=shape)
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout[-2000:] + r.stderr[-4000:]

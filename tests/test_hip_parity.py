@@ -302,31 +302,43 @@ def test_handle_cache_reuses_resources_across_frame_sizes(po, wl):
 
 @pytest.mark.parametrize("N", [5, 700, 2000, 3000])
 def test_fused_build_equals_streaming_build(po, wl, N):
-    """build_small.hip (one launch) vs the 19-launch streaming build: identical lattices."""
-    pb = wl.slam_problem(N, seed=123)
+    """build_small.hip (one launch) vs the 19-launch streaming build: identical lattices.  The streaming build of a SLAM-size
+    frame is a cross-check switch (LCCRF_NO_FUSED_BUILD) of the instrumented library: it runs in a child process."""
+    code = r"""
+import importlib, sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import crf_cases as cc
+pkg = importlib.import_module("lc-crf-slam_amd")
+wl = importlib.import_module("lc-crf-slam_amd.workloads")
+pb = wl.slam_problem(int(sys.argv[2]), seed=123)
+h = cc.setup(pkg.DenseCRFHIP, pb)
+ks = [h.kernel(k) for k in range(2)]
+h.inference(3, True)
+out = {"Q": h.probability()}
+for k in range(2):
+    out["V%%d" %% k] = np.int64(ks[k]["V"])
+    for name in ("offset", "bary", "nbr", "norm"):
+        out["%%s%%d" %% (name, k)] = ks[k][name]
+h.close()
+np.savez(sys.argv[1], **out)
+""" % (ROOT, os.path.join(ROOT, "tests"))
     res = {}
-    for mode in ("fused", "streaming"):
-        if mode == "streaming":
-            os.environ["LCCRF_NO_FUSED_BUILD"] = "1"
-        try:
-            h = cc.setup(pkg.DenseCRFHIP, pb)
-            res[mode] = [h.kernel(k) for k in range(2)]
-            h.inference(3, True)
-            res[mode].append(h.probability())
-            h.close()
-        finally:
-            os.environ.pop("LCCRF_NO_FUSED_BUILD", None)
+    for mode, env in (("fused", {}), ("streaming", {"LCCRF_NO_FUSED_BUILD": "1"})):
+        path = os.path.join(ROOT, "gpurun_out", "build_%s_%d.npz" % (mode, N))
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        subprocess.run([sys.executable, "-c", code, path, str(N)], check=True, env=cc.switch_env(env), timeout=300)
+        res[mode] = np.load(path)
     for k in range(2):
-        a, b = res["fused"][k], res["streaming"][k]
-        assert a["V"] == b["V"]
+        assert int(res["fused"]["V%d" % k]) == int(res["streaming"]["V%d" % k])
         for name in ("offset", "bary", "nbr", "norm"):
-            assert cc.same_bits(a[name], b[name]), (k, name)
-    assert cc.same_bits(res["fused"][2], res["streaming"][2])
+            assert cc.same_bits(res["fused"]["%s%d" % (name, k)], res["streaming"]["%s%d" % (name, k)]), (k, name)
+    assert cc.same_bits(res["fused"]["Q"], res["streaming"]["Q"])
+    pb = wl.slam_problem(N, seed=123)
     o = cc.setup(po.OracleCRF, pb)
     for k in range(2):
         ko = o.kernel(k)
         for name in ("offset", "bary", "nbr", "norm"):
-            assert cc.same_bits(ko[name], res["fused"][k][name]), (k, name)
+            assert cc.same_bits(ko[name], res["fused"]["%s%d" % (name, k)]), (k, name)
 
 
 def test_step_api_after_deferred_build(po, wl):
@@ -897,7 +909,7 @@ if __name__ == "__main__":
 """ % ROOT
     path = os.path.join(ROOT, "gpurun_out", "switch_%s.npy" % "_".join(env))
     os.makedirs(os.path.dirname(path), exist_ok=True)
-    subprocess.run([sys.executable, "-c", code, path], check=True, env=dict(os.environ, **env), timeout=600)
+    subprocess.run([sys.executable, "-c", code, path], check=True, env=cc.switch_env(env), timeout=600)
     got = np.load(path)
     ns = {}
     exec(compile(code.replace('if __name__ == "__main__":', "if False:"), "<switch>", "exec"), ns)
@@ -960,13 +972,15 @@ np.save(sys.argv[1], np.concatenate([b.probability().ravel(), b.map().astype(np.
 
 
 @pytest.mark.gpu
-def test_sorted_build_leaves_wrapped_keys_to_the_hash(wl):
-    """Features thousands of lattice cells wide make the int16 keys wrap (the reference's `short` arithmetic wraps the same way); such
+@pytest.mark.parametrize("d", [3, 4])
+def test_sorted_build_leaves_wrapped_keys_to_the_hash(wl, d):
+    """(d = 3: d + 1 divides 65536, so a key wrapped by 65536 still has integral grid coordinates and only the range check of
+    k_points can see it -- ADVICE r4; d = 4: the integrality check of k_ecode sees it too.)  Features thousands of lattice cells wide make the int16 keys wrap (the reference's `short` arithmetic wraps the same way); such
     keys are no lattice points any more and a row-major code cannot tell them apart, but 3 dimensions of them still fit 62 bits.  The
     sorted build notices (a key whose grid coordinates are not integers) and the engine rebuilds with the hash table, which compares
     the keys themselves: automatic == the hash build, bit for bit.  (No oracle here: out-of-range float -> short conversions are
     outside what the reference's own tests pin.)"""
-    N, F, d = 8300, 2, 3
+    N, F = 8300, 2
     pb = wl.generic_problem(N, [d], 2, seed=99, spread=6000.0)
     f = np.clip(pb["kernels"][0][0], -20000, 20000).astype(np.float32)
     res = []
@@ -976,9 +990,17 @@ def test_sorted_build_leaves_wrapped_keys_to_the_hash(wl):
         b.set_inputs_host([N] * F, [np.repeat(f[None], F, 0)], unary=np.repeat(pb["unary"][None], F, 0))
         b.build()
         b.inference(2, True)
+        assert b.locality_mode() == (True, False)          # the points keep their internal order, the vertices came from the hash: the fallback fired
         res.append((b.probability(), b.map(), b.lattice_sizes(0)))
         b.close()
     assert cc.same_bits(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])
+    # ... and frames of ordinary width keep the sorted build
+    pb = wl.bilateral_problem(N, seed=5)
+    b = pkg.BatchCRF(1, N, 2, [6], [10.0])
+    b.set_inputs_host([N], [pb["kernels"][0][0][None]], label=pb["label"][None], conf=0.7)
+    b.build()
+    assert b.locality_mode() == (True, True)
+    b.close()
 
 
 @pytest.mark.gpu

@@ -46,15 +46,18 @@ def test_replay_multi_builds_against_rccl_and_refuses_to_run_without_a_gpu(tool)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("batch", [3, 64])
-def test_replay_multi_reproduces_the_recorded_labels_with_one_gpu(tool, batch):
-    r = subprocess.run([tool, SAMPLE, "--gpus", "1", "--batch", str(batch)], capture_output=True, text=True, timeout=600,
+@pytest.mark.parametrize("batch,serial", [(3, False), (64, False), (1, False), (3, True)])
+def test_replay_multi_reproduces_the_recorded_labels_with_one_gpu(tool, batch, serial):
+    """batch = 3 / 1: three / eight rounds, i.e. the three-deep pipeline (upload + launch of round t, gather of t-1, check of t-2 on
+    three handles) wraps around; --serial is the same work one round at a time."""
+    r = subprocess.run([tool, SAMPLE, "--gpus", "1", "--batch", str(batch)] + (["--serial"] if serial else []), capture_output=True, text=True, timeout=600,
                        env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")))
     assert r.returncode == 0, (r.stdout[-500:], r.stderr[-2000:])
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert out["frames"] == 8 and out["checked_frames"] == 8 and out["gpus"] == 1 and out["batch"] == batch
     assert out["label_mismatches"] == 0 and out["prob_mismatches"] == 0 and out["max_abs_dQ"] == 0.0
     assert out["label_gathers"] == (8 + batch - 1) // batch and out["points"] > 0 and 0 < out["dynamic_points"] < out["points"]
+    assert out["rccl_comm_ranks"] == 1 and len(out["rank_seconds"]) == 1 and out["pipeline"].startswith("serial" if serial else "three rounds")
     # the same keys (and the same counts) as the single-process Python tool
     import importlib
     import sys

@@ -2,16 +2,19 @@
 // directly: the C++ twin of `tools/replay.py` + `lc-crf-slam_amd/sharding.py` (BASELINE north_star:
 // "Host stays C++ ... sharded over independent sequence frames ... RCCL only for the final label gather").
 //
-//   replay_multi frames.lccrfrec [--gpus G] [--batch B] [--single-workgroup]
+//   replay_multi frames.lccrfrec [--gpus G] [--batch B] [--single-workgroup] [--serial]
 //
 // Every frame is run exactly as the call site does (reference src/Tracking.cc:1919-1930): unary from the recorded initial
 // labels and confidence, appearance kernel (vobservs / stdev_beta, verrors / stdev_alpha), smoothness kernel
 // (coord2d / point2d_stdev), n_iterations mean-field iterations, MAP.
 //   sharding     frame f -> GPU f mod G; one host thread per GPU (ncclCommInitAll); a frame is never split.  G defaults to
 //                hipGetDeviceCount(), so the first 8-GPU box needs no flag.
-//   per batch    B frames per GPU in flight: lccrf_batch_run (lattices + inference, one launch per frame) on the thread's
-//                stream, then ONE ncclAllGather of lccrf_batch_device_label_bits (the MAP labels one bit per point, written
-//                by the inference kernel itself) on the same stream -- the path's only collective; no other inter-GPU traffic.
+//   per batch    B frames per GPU: lccrf_batch_set_inputs_host_async (pinned staging, upload on the batch's copy stream) ->
+//                lccrf_batch_run (lattices + inference, one launch per frame) -> ONE ncclAllGather of
+//                lccrf_batch_device_label_bits (the MAP labels one bit per point, written by the inference kernel itself) -- the
+//                path's only collective; no other inter-GPU traffic.  Three batches are in flight per GPU (rank_main), so a
+//                batch's kernels run under the previous batch's gather and the next batch's upload; --serial runs them one at a
+//                time for the A/B.  The index arithmetic (frame -> rank, slot, round, gathered word) is include/lccrf_sharding.h.
 //   check        thread 0 compares EVERY frame's gathered labels (its own and the other GPUs') with the labels the reference
 //                recorded (ref_label); every thread compares its own frames' probabilities with ref_prob bit for bit.
 // Prints one JSON line with the keys of tools/replay.py (+ gpus, batch, label_gathers); exit status 1 on any mismatch.
@@ -34,6 +37,7 @@
 
 #include "lccrf.h"
 #include "lccrf_record.h"
+#include "lccrf_sharding.h"
 
 namespace {
 
@@ -106,6 +110,7 @@ struct Totals {
     std::string error;
     std::atomic_flag error_lock = ATOMIC_FLAG_INIT;
     std::vector<ncclComm_t> *comms = nullptr;
+    std::vector<double> rank_seconds;                   // wall clock of every rank's share
     void fail(const std::string &what)
     {
         if (errors.fetch_add(1) == 0) {
@@ -134,14 +139,32 @@ struct Totals {
         if (r_ != ncclSuccess) { tot.fail(std::string(#expr) + ": " + ncclGetErrorString(r_)); return; } \
     } while (0)
 
-// One GPU's share of the replay.  Every rank walks the same groups and the same number of batches per group (a rank whose
-// share of the last batch is short pads with empty frames), so the collectives line up.
-void rank_main(int rank, int G, int B, bool single_wg, const std::vector<Frame> &frames, const std::vector<Group> &groups, ncclComm_t comm,
-               Totals &tot)
+// One GPU's share of the replay.  Every rank walks the same groups and the same number of rounds per group (a rank whose
+// share of the last round is short pads with empty frames), so the collectives line up.
+//
+// Three rounds are in flight per rank, each on a batch handle and a stream of its own (slot = round mod 3):
+//     iteration t:   stage + upload + launch round t        lccrf_batch_set_inputs_host_async -> lccrf_batch_run
+//                    settle + gather round t-1              lccrf_batch_synchronize (frames the one-launch kernel could not take),
+//                                                           ncclAllGather of the label bits, its copy to the host and the
+//                                                           probabilities' download -- all queued, nothing waited for
+//                    check round t-2                        wait for ITS copies only, compare on the host
+// so round t's kernels run under round t-1's gather and round t+1's staging and upload: what an 8-GPU run then measures is the
+// split, not a serialised upload -> launch -> synchronise -> gather -> download per batch.
+struct Slot {
+    lccrf_batch_handle b = nullptr;
+    hipStream_t stream = nullptr;
+    const uint64_t *d_bits = nullptr;
+    uint64_t *d_all = nullptr;
+    uint64_t *h_all = nullptr;                          // pinned
+    bool need_prob = false;
+};
+
+void rank_main(int rank, int G, int B, bool single_wg, bool serial, const std::vector<Frame> &frames, const std::vector<Group> &groups,
+               ncclComm_t comm, Totals &tot)
 {
     TRY_HIP(hipSetDevice(rank));
-    hipStream_t stream;
-    TRY_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    constexpr int kSlots = 3;
+    const auto t_rank0 = std::chrono::steady_clock::now();
     for (const Group &g : groups) {
         const Frame &f0 = frames[g.first];
         const int maxn = std::max(g.max_n, 1);
@@ -153,38 +176,44 @@ void rank_main(int rank, int G, int B, bool single_wg, const std::vector<Frame> 
         desc.feat_dims[0] = desc.feat_dims[1] = 2;
         desc.weights[0] = f0.h.w1;                          // Tracking.cc:1923-1927: appearance kernel first, then smoothness
         desc.weights[1] = f0.h.w2;
-        lccrf_batch_handle b = nullptr;
-        TRY_LCCRF(lccrf_batch_create(&b, rank, &desc));
-        if (single_wg) TRY_LCCRF(lccrf_batch_set_option(b, LCCRF_OPT_SINGLE_WORKGROUP, 1));
-        const uint64_t *d_bits = nullptr;
+        Slot slots[kSlots];
         int words = 0;
-        TRY_LCCRF(lccrf_batch_device_label_bits(b, &d_bits, &words));
+        for (Slot &sl : slots) {
+            TRY_HIP(hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking));
+            TRY_LCCRF(lccrf_batch_create(&sl.b, rank, &desc));
+            if (single_wg) TRY_LCCRF(lccrf_batch_set_option(sl.b, LCCRF_OPT_SINGLE_WORKGROUP, 1));
+            TRY_LCCRF(lccrf_batch_device_label_bits(sl.b, &sl.d_bits, &words));
+        }
         const size_t per_rank = (size_t)B * words;
-        uint64_t *d_all = nullptr;
-        TRY_HIP(hipMalloc(reinterpret_cast<void **>(&d_all), per_rank * G * sizeof(uint64_t)));
-        std::vector<uint64_t> h_all(per_rank * G);
-        std::vector<float> app((size_t)B * maxn * 2), smooth((size_t)B * maxn * 2), prob((size_t)B * maxn * 2);
+        for (Slot &sl : slots) {
+            TRY_HIP(hipMalloc(reinterpret_cast<void **>(&sl.d_all), per_rank * G * sizeof(uint64_t)));
+            TRY_HIP(hipHostMalloc(reinterpret_cast<void **>(&sl.h_all), per_rank * G * sizeof(uint64_t), hipHostMallocDefault));
+        }
+        // (one set of staging arrays: lccrf_batch_set_inputs_host_async has copied them out when it returns)
+        std::vector<float> app((size_t)B * maxn * 2), smooth((size_t)B * maxn * 2);
         std::vector<int16_t> label((size_t)B * maxn);
         std::vector<int32_t> npts(B);
-        const size_t per_round = (size_t)B * G;            // frames all ranks take together
-        const size_t rounds = (g.count + per_round - 1) / per_round;
-        for (size_t t = 0; t < rounds; ++t) {
-            // slot i of rank r holds frame g.first + (t B + i) G + r of the file (round-robin: f mod G = r inside a group that
-            // starts at a multiple of G; in general "the i-th frame of rank r's share")
-            auto frame_of = [&](int r, int i) -> long {
-                const size_t k = (t * B + i) * G + r;
-                return k < g.count ? (long)(g.first + k) : -1;
-            };
+        const size_t rounds = lccrf_shard_rounds(g.count, G, B);
+        const float conf[2] = {f0.h.confidence, f0.h.confidence};      // setUnaryEnergyFromLabel(label, mConf), Tracking.cc:1921
+        auto frame_of = [&](size_t t, int r, int i) -> long {
+            const long k = lccrf_shard_frame(t, r, i, G, B, g.count);
+            return k < 0 ? -1 : (long)g.first + k;
+        };
+
+        auto launch = [&](size_t t) {                       // stage + upload + launch round t
+            Slot &sl = slots[t % kSlots];
             std::fill(app.begin(), app.end(), 0.0f);
             std::fill(smooth.begin(), smooth.end(), 0.0f);
             std::fill(label.begin(), label.end(), (int16_t)-1);
+            sl.need_prob = false;
             for (int i = 0; i < B; ++i) {
-                const long fi = frame_of(rank, i);
+                const long fi = frame_of(t, rank, i);
                 npts[i] = 0;
                 if (fi < 0) continue;
                 const Frame &fr = frames[fi];
                 const int n = (int)fr.h.n_points;
                 npts[i] = n;
+                sl.need_prob |= fr.has_ref_prob;
                 float *a = &app[(size_t)i * maxn * 2], *s = &smooth[(size_t)i * maxn * 2];
                 for (int p = 0; p < n; ++p) {               // pairwise3d.h:41-44 and :64-66: fp32 divisions on the host, as the reference
                     a[2 * p + 0] = fr.vobservs[p] / fr.h.stdev_beta;
@@ -194,25 +223,27 @@ void rank_main(int rank, int G, int B, bool single_wg, const std::vector<Frame> 
                 }
                 memcpy(&label[(size_t)i * maxn], fr.init_label.data(), (size_t)n * sizeof(int16_t));
             }
-            const float conf[2] = {f0.h.confidence, f0.h.confidence};      // setUnaryEnergyFromLabel(label, mConf), Tracking.cc:1921
             const float *feats[2] = {app.data(), smooth.data()};
-            TRY_LCCRF(lccrf_batch_set_inputs_host(b, B, npts.data(), nullptr, label.data(), conf, feats));
-            TRY_LCCRF(lccrf_batch_run(b, (int)f0.h.n_iterations, 1, 1.0f, stream));
-            TRY_LCCRF(lccrf_batch_synchronize(b));          // (settles frames the one-launch kernel could not take: the bits are complete behind this)
-            // the path's one collective: every rank's bit-packed labels to every rank, on the batch's stream
-            TRY_NCCL(ncclAllGather(d_bits, d_all, per_rank, ncclUint64, comm, stream));
-            TRY_HIP(hipMemcpyAsync(h_all.data(), d_all, h_all.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
-            TRY_HIP(hipStreamSynchronize(stream));
+            TRY_LCCRF(lccrf_batch_set_inputs_host_async(sl.b, B, npts.data(), nullptr, label.data(), conf, feats, 0));
+            TRY_LCCRF(lccrf_batch_run(sl.b, (int)f0.h.n_iterations, 1, 1.0f, sl.stream));
+        };
+        auto gather = [&](size_t t) {                       // settle + gather round t: queued, not waited for
+            Slot &sl = slots[t % kSlots];
+            TRY_LCCRF(lccrf_batch_synchronize(sl.b));       // (settles frames the one-launch kernel could not take: the bits are complete behind this)
+            // the path's one collective: every rank's bit-packed labels to every rank
+            TRY_NCCL(ncclAllGather(sl.d_bits, sl.d_all, per_rank, ncclUint64, comm, sl.stream));
+            TRY_HIP(hipMemcpyAsync(sl.h_all, sl.d_all, per_rank * G * sizeof(uint64_t), hipMemcpyDeviceToHost, sl.stream));
+            if (sl.need_prob) TRY_LCCRF(lccrf_batch_download_async(sl.b, LCCRF_DOWNLOAD_PROBABILITY));
             if (rank == 0) tot.gathers.fetch_add(1);
+        };
+        auto check = [&](size_t t) {                        // wait for round t's copies and compare
+            Slot &sl = slots[t % kSlots];
+            TRY_HIP(hipStreamSynchronize(sl.stream));
+            const float *prob = nullptr;
+            if (sl.need_prob) TRY_LCCRF(lccrf_batch_wait_download(sl.b, nullptr, nullptr, nullptr, &prob));
             // every rank checks the probabilities of its own frames ...
-            bool need_prob = false;
             for (int i = 0; i < B; ++i) {
-                const long fi = frame_of(rank, i);
-                need_prob |= fi >= 0 && frames[fi].has_ref_prob;
-            }
-            if (need_prob) TRY_LCCRF(lccrf_batch_get_probability_host(b, prob.data()));
-            for (int i = 0; i < B; ++i) {
-                const long fi = frame_of(rank, i);
+                const long fi = frame_of(t, rank, i);
                 if (fi < 0 || !frames[fi].has_ref_prob) continue;
                 const Frame &fr = frames[fi];
                 const float *q = &prob[(size_t)i * maxn * 2];
@@ -234,10 +265,10 @@ void rank_main(int rank, int G, int B, bool single_wg, const std::vector<Frame> 
             if (rank == 0) {
                 for (int r = 0; r < G; ++r)
                     for (int i = 0; i < B; ++i) {
-                        const long fi = frame_of(r, i);
+                        const long fi = frame_of(t, r, i);
                         if (fi < 0) continue;
                         const Frame &fr = frames[fi];
-                        const uint64_t *w = &h_all[(size_t)r * per_rank + (size_t)i * words];
+                        const uint64_t *w = &sl.h_all[lccrf_gather_word(r, i, B, words)];
                         long dyn = 0, bad = 0;
                         for (size_t p = 0; p < fr.h.n_points; ++p) {
                             const int lab = (int)((w[p >> 6] >> (p & 63)) & 1u);
@@ -252,11 +283,25 @@ void rank_main(int rank, int G, int B, bool single_wg, const std::vector<Frame> 
                         }
                     }
             }
+        };
+        if (serial) {                                       // --serial: one round at a time (the A/B of the pipeline)
+            for (size_t t = 0; t < rounds && !tot.errors.load(); ++t) { launch(t); gather(t); check(t); }
+        } else {
+            for (size_t t = 0; t < rounds + 2 && !tot.errors.load(); ++t) {
+                if (t < rounds) launch(t);
+                if (t >= 1 && t - 1 < rounds) gather(t - 1);
+                if (t >= 2) check(t - 2);
+            }
         }
-        (void)hipFree(d_all);
-        lccrf_batch_destroy(b);
+        for (Slot &sl : slots) {
+            if (sl.stream) (void)hipStreamSynchronize(sl.stream);
+            (void)hipFree(sl.d_all);
+            (void)hipHostFree(sl.h_all);
+            lccrf_batch_destroy(sl.b);
+            if (sl.stream) (void)hipStreamDestroy(sl.stream);
+        }
     }
-    (void)hipStreamDestroy(stream);
+    tot.rank_seconds[rank] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_rank0).count();
 }
 
 }  // namespace
@@ -265,15 +310,16 @@ int main(int argc, char **argv)
 {
     const char *path = nullptr;
     int G = 0, B = 64;
-    bool single_wg = false;
+    bool single_wg = false, serial = false;
     for (int i = 1; i < argc; ++i) {
         if (!strcmp(argv[i], "--gpus") && i + 1 < argc) G = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--batch") && i + 1 < argc) B = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--single-workgroup")) single_wg = true;
+        else if (!strcmp(argv[i], "--serial")) serial = true;
         else if (argv[i][0] != '-' && !path) path = argv[i];
-        else { fprintf(stderr, "usage: %s frames.lccrfrec [--gpus G] [--batch B] [--single-workgroup]\n", argv[0]); return 2; }
+        else { fprintf(stderr, "usage: %s frames.lccrfrec [--gpus G] [--batch B] [--single-workgroup] [--serial]\n", argv[0]); return 2; }
     }
-    if (!path || B < 1) { fprintf(stderr, "usage: %s frames.lccrfrec [--gpus G] [--batch B] [--single-workgroup]\n", argv[0]); return 2; }
+    if (!path || B < 1) { fprintf(stderr, "usage: %s frames.lccrfrec [--gpus G] [--batch B] [--single-workgroup] [--serial]\n", argv[0]); return 2; }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { fprintf(stderr, "no HIP device: this tool has no CPU path\n"); return 2; }
     if (G <= 0) G = ndev;                                   // every GPU of the node by default
@@ -304,9 +350,12 @@ int main(int argc, char **argv)
 
     Totals tot;
     tot.comms = &comms;
+    tot.rank_seconds.assign(G, 0.0);
+    int comm_ranks = 0;                                  // what RCCL itself says the communicator spans
+    (void)ncclCommCount(comms[0], &comm_ranks);
     const auto t0 = std::chrono::steady_clock::now();
     std::vector<std::thread> threads;
-    for (int r = 0; r < G; ++r) threads.emplace_back(rank_main, r, G, B, single_wg, std::cref(frames), std::cref(groups), comms[r], std::ref(tot));
+    for (int r = 0; r < G; ++r) threads.emplace_back(rank_main, r, G, B, single_wg, serial, std::cref(frames), std::cref(groups), comms[r], std::ref(tot));
     for (auto &t : threads) t.join();
     const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     if (!tot.errors.load())
@@ -319,14 +368,24 @@ int main(int argc, char **argv)
     float max_dq;
     const int mb = tot.max_dq_bits.load();
     memcpy(&max_dq, &mb, 4);
+    std::string rank_list;
+    for (int r = 0; r < G; ++r) {
+        char buf[32];
+        snprintf(buf, sizeof(buf), "%s%.6f", r ? ", " : "", tot.rank_seconds[r]);
+        rank_list += buf;
+    }
     const char *base = strrchr(path, '/');
     printf("{\"file\": \"%s\", \"frames\": %zu, \"points\": %ld, \"checked_frames\": %ld, \"label_mismatches\": %ld, \"prob_mismatches\": %ld, "
            "\"max_abs_dQ\": %.9g, \"dynamic_points\": %ld, \"origin\": \"%s\", \"gpus\": %d, \"batch\": %d, \"label_gathers\": %ld, "
            "\"label_gather\": \"ncclAllGather of the bit-packed labels (uint64 words), one per batch, on the batch's stream\", "
-           "\"sharding\": \"frame f -> GPU f mod G, one host thread per GPU\", \"frames_per_s_host_to_host\": %.6g}\n",
+           "\"sharding\": \"frame f -> GPU f mod G, one host thread per GPU\", \"pipeline\": \"%s\", \"rccl_comm_ranks\": %d, "
+           "\"rank_seconds\": [%s], \"frames_per_s_host_to_host\": %.6g}\n",
            base ? base + 1 : path, frames.size(), tot.points.load(), tot.checked_frames.load(), tot.label_mismatches.load(),
            tot.prob_mismatches.load(), (double)max_dq, tot.dynamic_points.load(),
            origin == LCCRF_REC_ORIGIN_SYNTHETIC ? "synthetic (outputs from this repository's restatements: pins nothing)" : "reference", G, B,
-           tot.gathers.load(), secs > 0 ? frames.size() / secs : 0.0);
+           tot.gathers.load(),
+           serial ? "serial: upload, launch, settle, gather, download and check one round at a time"
+                  : "three rounds in flight per rank: round t uploads and launches while round t-1 gathers and round t-2 is checked",
+           comm_ranks, rank_list.c_str(), secs > 0 ? frames.size() / secs : 0.0);
     return (tot.label_mismatches.load() || tot.prob_mismatches.load()) ? 1 : 0;
 }
