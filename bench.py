@@ -62,7 +62,7 @@ def algorithmic_bytes_per_iter(N, L, dims, Vs):
     return b
 
 
-def fused_lds_model(N, dims, Vs, chain0):
+def fused_lds_model(N, dims, Vs, chain0, lean=False):
     """LDS bytes one mean-field iteration of one frame moves in the fused engine, by instruction class
     (DESIGN.md section 4.5 states the same table).  L = 2, every kernel 2-D:
       P     every point stores 3 products x 2 labels per kernel (chain kernel: 6 ds_write_b32, others 3 ds_write_b64)
@@ -70,6 +70,8 @@ def fused_lds_model(N, dims, Vs, chain0):
             pointers, one u16 slot index and one 8-byte value store
       blur  3 passes x per vertex: neighbour pair (b32), centre + two neighbours (3 x b64), one b64 store
       X     every point gathers 3 float2 values per kernel (ds_read_b64)
+    lean (round 5, two full-size frames per CU: csrc/fused_lean.h): every kernel's neighbour pairs but the chain kernel's come from
+    HBM / L2 through buffer loads, not from LDS -- they are not counted.
     Returns (total bytes, minimum LDS-pipe clocks at the per-instruction peak rates)."""
     by = {k: 0.0 for k in LDS_RATE}
     for k, (d, V) in enumerate(zip(dims, Vs)):
@@ -79,7 +81,8 @@ def fused_lds_model(N, dims, Vs, chain0):
         by["read_b128" if chain else "read_b64"] += 8.0 * E           # S: products
         by["read_u16"] += 6.0 * V                                      # S: row[v], row[v+1], perm[v]
         by["write_b64"] += 8.0 * V                                     # S: value store
-        by["read_b32"] += 3 * 4.0 * V                                  # blur: neighbour pairs
+        if not lean or chain:
+            by["read_b32"] += 3 * 4.0 * V                              # blur: neighbour pairs
         by["read_b64"] += 3 * 24.0 * V                                 # blur: centre + 2 neighbours
         by["write_b64"] += 3 * 8.0 * V                                 # blur: store
         by["read_b64"] += 8.0 * E                                      # X: gathers
@@ -399,7 +402,8 @@ def slam_subrecord(pkg, wl, torch, dev, name, steps=10, warmup=3, distinct=32):
     b.synchronize()
     run_ms = (time.perf_counter() - t0) / max(steps // 2, 3) * 1e3
     run_engine, fb = b.engine(), b.fallback_frames()
-    lds_bytes, lds_clocks, _ = fused_lds_model(N, dims, Vs, True)
+    lanes, per_cu = b.fused_shape()
+    lds_bytes, lds_clocks, _ = fused_lds_model(N, dims, Vs, True, per_cu == 2 and N > 1024)
     row = longest_rows(pkg, pbs)
     t_floor = lds_clocks * n_iter * F / N_CU / CLK_HZ
     achieved = lds_bytes * n_iter * F / (inf_ms * 1e-3) / 1e9
@@ -408,6 +412,7 @@ def slam_subrecord(pkg, wl, torch, dev, name, steps=10, warmup=3, distinct=32):
            "engine": {1: "streaming", 2: "fused"}.get(engine, str(engine)), "mean_lattice_vertices": Vs,
            "roofline": {"bound": "lds" if engine == 2 else "hbm", "achieved": achieved, "peak": peak, "unit": "GB/s",
                         "frac": achieved / peak, "launch_ms": inf_ms, "lds_bytes_per_iteration_frame": lds_bytes,
+                        "lanes_per_frame": lanes, "frames_per_cu": per_cu,
                         "lds_floor_ms": t_floor * 1e3, "longest_row": row, "chain_floor_ms": chain_floor(row, n_iter, F, N),
                         "algorithmic_hbm_bytes_per_iteration_frame": algorithmic_bytes_per_iter(N, 2, dims, Vs)},
            "build_ms_per_batch": build_ms,
@@ -1043,7 +1048,9 @@ def main():
             # The one-workgroup-per-frame engine keeps the mean-field state in registers and LDS: HBM carries the
             # per-frame records once per launch.  Its roof is the CU's LDS pipe.
             chain0 = True                                           # SLAM frames: the appearance kernel takes the chain path
-            lds_bytes, lds_clocks, by = fused_lds_model(N, dims, Vs, chain0)
+            lanes, per_cu = b.fused_shape()
+            lean = per_cu == 2 and N > 1024                         # (frames of up to 1024 points share a CU on the 137 KB plan's small form)
+            lds_bytes, lds_clocks, by = fused_lds_model(N, dims, Vs, chain0, lean)
             row = longest_rows(pkg, pbs)
             lds_launch = lds_bytes * n_iter * F
             t_floor = lds_clocks * n_iter * F / N_CU / CLK_HZ       # every CU streaming at the per-instruction peak
@@ -1054,7 +1061,7 @@ def main():
             roof = {"bound": "lds", "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": achieved / peak,
                     "traffic": traffic,
                     "kernel": "inference launch (start + %d mean-field iterations + map), HIP events" % n_iter,
-                    "launch_ms": inf_ms, "lds_bytes_per_iteration_frame": lds_bytes,
+                    "launch_ms": inf_ms, "lds_bytes_per_iteration_frame": lds_bytes, "lanes_per_frame": lanes, "frames_per_cu": per_cu,
                     "lds_floor_ms": t_floor * 1e3, "longest_row": row, "chain_floor_ms": chain_floor(row, n_iter, F, N),
                     "chain_floor_note": "the appearance kernel's longest row is a strictly sequential fp32 sum (one lane per label): 5.1 cycles "
                                         "x longest row x n_iter per frame / 2.4 GHz x frames / 256 CUs -- the latency floor next to the LDS "

@@ -402,6 +402,7 @@ struct Engine {
             if ((rc = mem.alloc(&k.fastn, Fz * E))) return rc;
             if ((rc = mem.alloc(&k.ndist, (size_t)kNdistAxes))) return rc;
             if ((rc = mem.alloc(&k.nearoff, Fz * 2 * E * 2))) return rc;
+            if (maxN < (1 << 24) && (rc = mem.alloc(&k.srec, Fz * E))) return rc;
             if (!ndist_host && (rc = mem.alloc_pinned(&ndist_host, (size_t)LCCRF_MAX_KERNELS * kNdistAxes))) return rc;
         }
         // large frames, a few in flight: the sorted build also leaves the neighbour table in its compact form (16-bit offsets), for
@@ -553,7 +554,7 @@ struct Engine {
             const bool small_ok = !no_small && !perm_on;
             if (small_ok && k + 1 < k0 + n && build_small_supported(&kdevs[k], 2, NA)) m = 2;
             if (small_ok && build_small_supported(&kdevs[k], m, NA)) {
-                for (int u = 0; u < m; ++u) kernels[k + u].dev.nbr2_ok = kernels[k + u].dev.nbrc_ok = kernels[k + u].dev.fast0_ok = kernels[k + u].dev.longrow_ok = 0;
+                for (int u = 0; u < m; ++u) kernels[k + u].dev.nbr2_ok = kernels[k + u].dev.nbrc_ok = kernels[k + u].dev.fast0_ok = kernels[k + u].dev.longrow_ok = kernels[k + u].dev.srec_ok = 0;
                 launch_build_small(&kdevs[k], m, NA, crf, stream);   // writes V / rowmax to the pinned mirrors itself
             } else {
                 m = 1;
@@ -561,6 +562,7 @@ struct Engine {
                 kernels[k].dev.longrow_ok = kdevs[k].longrow_ok = kernels[k].dev.longrow != nullptr;   // (... and lists the long rows: the normalisation below reads the list)
                 kernels[k].dev.nbrc_ok = kernels[k].dev.nbrc != nullptr && kernels[k].dev.vorder && F >= kNbrcMinFrames && F <= kNbrcMaxFrames;   // (... and the sorted build the compact one)
                 kernels[k].dev.fast0_ok = kernels[k].dev.tbl_bad != nullptr && kernels[k].dev.vorder;
+                kernels[k].dev.srec_ok = kernels[k].dev.srec != nullptr && kernels[k].dev.vorder;          // (the sorted build packs the splat records)
                 kernels[k].dev.nbr2_first = kernels[k].dev.fast0_ok;              // (what build_kernel_d derives from the same two fields)
                 launch_build_kernel(kdevs[k], crf, kernels[k].maxV, stream, perm_on ? &sort : nullptr);
                 launch_norm(kdevs[k], crf, kernels[k].maxV, stream);

@@ -94,6 +94,13 @@ struct KernelDev {
     // axes 1 (and 2) fit a workgroup's halo those passes ride in the splat as well, on an overlapped window in LDS (k_splat2w)
     int8_t *nearoff;      // [F][2][Epad][2] or null: axes 1 and 2, {n1 - v, n2 - v} as signed bytes, 0 = absent (valid when ndist <= 127:
                           //   the window passes read 2 instead of 8 table bytes per vertex)
+    // ... and everything the window splat wants to know about a vertex in ONE 16-byte record (round 5; k_pack_srec after the sorted build):
+    //   .x row start s   .y first entry's point | min(row length, 127) << 24 | fastn << 31   .z first entry's weight (bits)
+    //   .w the four nearoff bytes {axis 1: n1 - v, n2 - v, axis 2: n1 - v, n2 - v}
+    // one load per vertex instead of seven (two row pointers, fastn, two offset pairs, the first entry's point and weight): the pass
+    // is bound by vector-memory instructions, not bytes.  Frames of < 2^24 points only (the point id's 24 bits).
+    uint4 *srec;          // [F][Epad] or null
+    int srec_ok;          // the records describe the lattices now in HBM
     int *ndist;           // [kNdistAxes] or null: largest |neighbour id - id| along axes 0 .. kNdistAxes-1 over all frames (device)
     int splat_passes;     // blur passes the splat takes along for the lattices now in HBM: 0 (none), 1 (k_splat2<true>), 2 or 3 (k_splat2w)
     int splat_halo;       // ... the halo that takes on each side of a window (1 + distance of axis 1 [+ distance of axis 2])

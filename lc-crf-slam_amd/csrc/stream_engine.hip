@@ -825,6 +825,28 @@ __global__ void __launch_bounds__(kBlock) k_ebucket_vertices(KernelDev kd, SortS
     ss.vhist[(size_t)f * nbk + b] = kd.prefix[(size_t)f * (kd.Epad + 1) + ss.vstart[(size_t)f * nbk + b]];   // (prefix[live] = V)
 }
 
+// The window splat's per-vertex record (KernelDev::srec), packed once per build from the arrays the sorted build has just written.
+__global__ void __launch_bounds__(kBlock) k_pack_srec(KernelDev kd, int F, XcdMap nb)
+{
+    const FrameBlock fb = frame_block(nb);
+    const int f = fb.f;
+    if (f >= F) return;
+    const int V = kd.V[f];
+    const int v = fb.bx * kBlock + threadIdx.x;
+    if (v >= V) return;
+    const size_t fe = (size_t)f * kd.Epad, f1 = (size_t)f * (kd.Epad + 1);
+    const int s = kd.rowptr[f1 + v], t = kd.rowptr[f1 + v + 1];
+    const char2 *off1 = reinterpret_cast<const char2 *>(kd.nearoff) + (size_t)f * 2 * kd.Epad, *off2 = off1 + kd.Epad;
+    const char2 o1 = off1[v], o2 = off2[v];
+    const unsigned len7 = (unsigned)min(t - s, 127), nx = kd.fastn[fe + v] ? 1u : 0u;
+    uint4 r;
+    r.x = (unsigned)s;
+    r.y = (s < t ? ((unsigned)kd.csr_pt[fe + s] & 0xffffffu) : 0u) | (len7 << 24) | (nx << 31);
+    r.z = s < t ? __float_as_uint(kd.csr_w[fe + s]) : 0u;
+    r.w = (unsigned)(unsigned char)o1.x | ((unsigned)(unsigned char)o1.y << 8) | ((unsigned)(unsigned char)o2.x << 16) | ((unsigned)(unsigned char)o2.y << 24);
+    kd.srec[fe + v] = r;
+}
+
 // One thread per vertex v, all d + 1 axes at once: n2_j(v) by code -- +1 along grid coordinate j (j < d), -1 along every coordinate
 // (j = d); a step off the box lands in a guard column or beyond `range` and matches nothing -- among the vertices of the bucket the
 // code falls in (ids are bucket-major: bucket b holds the vertices [bvert[b], bvert[b+1])).  The look-ups of the d + 1 axes are
@@ -1605,7 +1627,7 @@ __global__ void __launch_bounds__(kBlock) k_splat2(KernelDev kd, const float2 *_
 // outside the window reads as zero, which spoils its neighbours' values pass by pass -- by at most `halo` = 1 + dist_1 (+ dist_2)
 // positions from either end, so the inner B - 2 halo results are exactly what P launches of k_blur2 would have stored (the same
 // operations on the same values in the same order) and only those are written.  One launch, one table read per extra pass.
-template <int LANES, int U>
+template <int LANES, int U, bool REC = false>
 __global__ void __launch_bounds__(LANES) k_splat2w(KernelDev kd, const float2 *__restrict__ in, int in_stride, int F, XcdMap nb, int P, int halo)
 {
     constexpr int B = LANES * U;                          // the window: U vertices per lane, at stride LANES (coalesced)
@@ -1625,31 +1647,59 @@ __global__ void __launch_bounds__(LANES) k_splat2w(KernelDev kd, const float2 *_
     char2 o1[U], o2[U];
     uint8_t nx[U];
     int s[U], t[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-        const int v = v0 + tid + u * LANES;
-        const bool live = v >= 0 && v < V;
-        s[u] = t[u] = 0;
-        nx[u] = 0;
-        o1[u] = o2[u] = make_char2(0, 0);
-        if (live) {
-            s[u] = kd.rowptr[f1 + v];
-            t[u] = kd.rowptr[f1 + v + 1];
-            nx[u] = kd.fastn[fe + v];
-            o1[u] = off1[v];
-            if (P > 2) o2[u] = off2[v];
-        }
-    }
-    // the first entry of each of the lane's U rows together (rows hold 1.2 entries on average: most are done after this), then
-    // whatever is left of each row in order
     int pt0[U];
     float w0[U];
     float2 q0[U];
+    if (REC) {
+        // REC: one 16-byte record per vertex (KernelDev::srec) says what seven loads said -- row start and length, the first entry's
+        // point and weight, fastn and the four byte offsets; a row of 127 entries or more reads its end from the row pointers
+        uint4 r[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-        const bool any = s[u] < t[u];
-        pt0[u] = any ? kd.csr_pt[fe + s[u]] : 0;
-        w0[u] = any ? kd.csr_w[fe + s[u]] : 0.0f;
+        for (int u = 0; u < U; ++u) {
+            const int v = v0 + tid + u * LANES;
+            typedef unsigned u4v __attribute__((ext_vector_type(4)));
+            r[u] = make_uint4(0u, 0u, 0u, 0u);
+            if (v >= 0 && v < V) {                        // (read once per iteration: non-temporal, out of the value arrays' way in L2)
+                const u4v q = __builtin_nontemporal_load(reinterpret_cast<const u4v *>(kd.srec + fe + v));
+                r[u] = make_uint4(q.x, q.y, q.z, q.w);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int len7 = (int)((r[u].y >> 24) & 127u);
+            s[u] = (int)r[u].x;
+            t[u] = s[u] + len7;
+            if (len7 == 127) t[u] = kd.rowptr[f1 + v0 + tid + u * LANES + 1];
+            nx[u] = (uint8_t)(r[u].y >> 31);
+            pt0[u] = (int)(r[u].y & 0xffffffu);
+            w0[u] = __uint_as_float(r[u].z);
+            o1[u] = make_char2((signed char)(r[u].w & 0xffu), (signed char)((r[u].w >> 8) & 0xffu));
+            o2[u] = make_char2((signed char)((r[u].w >> 16) & 0xffu), (signed char)(r[u].w >> 24));
+        }
+    } else {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int v = v0 + tid + u * LANES;
+            const bool live = v >= 0 && v < V;
+            s[u] = t[u] = 0;
+            nx[u] = 0;
+            o1[u] = o2[u] = make_char2(0, 0);
+            if (live) {
+                s[u] = kd.rowptr[f1 + v];
+                t[u] = kd.rowptr[f1 + v + 1];
+                nx[u] = kd.fastn[fe + v];
+                o1[u] = off1[v];
+                if (P > 2) o2[u] = off2[v];
+            }
+        }
+        // the first entry of each of the lane's U rows together (rows hold 1.2 entries on average: most are done after this), then
+        // whatever is left of each row in order
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const bool any = s[u] < t[u];
+            pt0[u] = any ? kd.csr_pt[fe + s[u]] : 0;
+            w0[u] = any ? kd.csr_w[fe + s[u]] : 0.0f;
+        }
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) q0[u] = x[pt0[u]];
@@ -2084,6 +2134,7 @@ void build_kernel_d(const KernelDev &kd, const CrfDev &c, hipStream_t s, const S
         if (kd.ndist) (void)hipMemsetAsync(kd.ndist, 0, kNdistAxes * sizeof(int), s);
         if (kd.nearoff) (void)hipMemsetAsync(kd.nearoff, 0, (size_t)F * 2 * kd.Epad * 2, s);
         k_eneighbors<D><<<g, kBlock, 0, s>>>(kd, F, nb, ss);
+        if (kd.srec && kd.nearoff && kd.fastn) k_pack_srec<<<g, kBlock, 0, s>>>(kd, F, nb);
         if (kd.nbrc && F >= kNbrcMinFrames && F <= kNbrcMaxFrames) {
             int limit = 0xffff;
 #if LCCRF_INSTRUMENT
@@ -2219,15 +2270,21 @@ void launch_step_stream(const CrfDev &c, const KernelDev *kds, const int *maxV, 
                 const bool wide = c.F <= (env_w ? atoi(env_w) : 2);
                 const int lanes = wide ? B : kBlock;
                 const dim3 g = grid_xcd(((long)maxV[k] + core - 1) / core * lanes, c.F, &nb, lanes);
-                if (B == 256) k_splat2w<256, 1><<<g, 256, 0, s>>>(kd, q2, c.maxN, c.F, nb, j0, kd.splat_halo);
-                else if (B == 512 && wide) k_splat2w<512, 1><<<g, 512, 0, s>>>(kd, q2, c.maxN, c.F, nb, j0, kd.splat_halo);
-                else if (B == 512) k_splat2w<256, 2><<<g, 256, 0, s>>>(kd, q2, c.maxN, c.F, nb, j0, kd.splat_halo);
+                // (REC: the per-vertex records of the sorted build, one load instead of seven -- KernelDev::srec)
+                static const bool no_rec = ab_env("LCCRF_NO_SPLAT_REC") != nullptr;            // A/B switch: same results either way
+                const bool rec = kd.srec && kd.srec_ok && !no_rec;
+#define LCCRF_SPLAT2W(LN, UU, GRID) do { if (rec) k_splat2w<LN, UU, true><<<GRID, LN, 0, s>>>(kd, q2, c.maxN, c.F, nb, j0, kd.splat_halo); \
+                                         else k_splat2w<LN, UU, false><<<GRID, LN, 0, s>>>(kd, q2, c.maxN, c.F, nb, j0, kd.splat_halo); } while (0)
+                if (B == 256) LCCRF_SPLAT2W(256, 1, g);
+                else if (B == 512 && wide) LCCRF_SPLAT2W(512, 1, g);
+                else if (B == 512) LCCRF_SPLAT2W(256, 2, g);
                 else if (c.F == 1) {                      // (one frame: 663 workgroups of 1024 lanes are 1.3 rounds of the chip's 512 slots;
                     const dim3 g5 = grid_xcd(((long)maxV[k] + core - 1) / core * 512, c.F, &nb, 512);    //  512 lanes x 2 vertices all run at once: 33.6 -> 32.5 us)
-                    k_splat2w<512, 2><<<g5, 512, 0, s>>>(kd, q2, c.maxN, c.F, nb, j0, kd.splat_halo);
+                    LCCRF_SPLAT2W(512, 2, g5);
                 }
-                else if (wide) k_splat2w<1024, 1><<<g, 1024, 0, s>>>(kd, q2, c.maxN, c.F, nb, j0, kd.splat_halo);
-                else k_splat2w<256, 4><<<g, 256, 0, s>>>(kd, q2, c.maxN, c.F, nb, j0, kd.splat_halo);
+                else if (wide) LCCRF_SPLAT2W(1024, 1, g);
+                else LCCRF_SPLAT2W(256, 4, g);
+#undef LCCRF_SPLAT2W
             } else if (j0 == 1) {
                 const dim3 g = grid_xcd(((long)maxV[k] + blk - 3) / (blk - 2) * blk, c.F, &nb, blk);
                 k_splat2<true><<<g, blk, 0, s>>>(kd, reinterpret_cast<const float2 *>(c.Q), c.maxN, c.F, nb);
