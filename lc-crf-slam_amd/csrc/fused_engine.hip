@@ -273,7 +273,8 @@ __global__ void __launch_bounds__(NT, NT == 384 ? 3 : 4) k_fused_lean(CrfDev c, 
     float alpha[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) alpha[k] = a.kd[k].alpha;
-    int t = tid;                          // (the loop makes its copy of the lane id opaque; what follows uses that copy)
+    int t = tid;                          // (the loop makes its copy of the lane id opaque; what follows uses that copy --
+    asm volatile("" : "+v"(t));           //  severed from `tid` here, so that no second copy has to outlive the loop)
     mean_field_lean<PPT, K, CH, NT, RELOAD>(smem, lay, V, N, t, pr, cl, alpha, wk, src, a.n_iter, a.relax, a.omr, ins);
 
     store_results<PPT, K, NT>(c, f, N, t, pr, a.with_map);

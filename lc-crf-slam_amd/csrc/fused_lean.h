@@ -86,7 +86,7 @@ __host__ __device__ inline bool layout_lean(int NA, int K, const int *V, int row
     "v_cmp_lt_i32_e32 vcc, " #off ", %[rem]\n\tv_cndmask_b32_e32 %[" #S "], 0, %[ad], vcc\n\t"                     \
     "ds_read_b128 v[" #vlo ":" #vhi "], %[" #S "] offset:" #off "\n\t"
 
-// keep0 / keep1: two values of the caller that must survive the ring.  They pass through the asm statement as operands, which pins
+// keep0 / keep1: two values of the caller that must survive the ring (the chain lane's two words).  They pass through the asm statement as operands, which pins
 // them to registers the ring does not clobber; left to itself the register allocator parks loop-long values (the chain lane's two
 // words) in v96..v127 and spills them to scratch around the ring.
 __device__ __forceinline__ float chain_rows_sel(unsigned addr, int bytes, unsigned trips, unsigned &keep0, unsigned &keep1)
@@ -301,10 +301,26 @@ __device__ __forceinline__ void mean_field_lean(unsigned char *smem, const Fused
 {
     constexpr int D1 = kD1;
     constexpr int KF = K - 1;                             // the kernel whose products follow the softmax
-    // everything below indexes with `t`, the caller's lane id, which the compiler cannot see through: re-made opaque at the top of every
-    // iteration and phase, so that the offsets and LDS addresses derived from it are recomputed where they are used instead of
-    // being hoisted out of the loop into registers the loop does not have (cf. opaque())
+    // everything below indexes with `t`, the caller's lane id, RE-FORMED at the top of every iteration and phase from the wavefront's
+    // base (a scalar register: it survives the rings, which clobber v96..v127) and the lane's position in the wavefront (mbcnt over
+    // an opaque zero, so that it cannot be hoisted): the offsets and LDS addresses derived from it are then computed where they are
+    // used instead of being carried through the loop in registers the loop does not have (cf. opaque()), and no copy of the id has
+    // to live across a ring -- left to itself the allocator parks it in the clobbered range and spills it around the asm.
+    const int wave_base = __builtin_amdgcn_readfirstlane(t & ~63);
+    (void)wave_base;
+#ifndef LCCRF_LEAN_T_MBCNT
+#define LCCRF_LEAN_T_MBCNT 1              // A/B (scripts/gpu_ab_build.sh "" "-DLCCRF_LEAN_T_MBCNT=0"): 0 = one opaque copy kept through the loop
+#endif
+#if LCCRF_LEAN_T_MBCNT
+#define LEAN_FRESH_T()                                                                                               \
+    do {                                                                                                             \
+        int z_ = 0;                                                                                                  \
+        asm volatile("" : "+v"(z_));                                                                                 \
+        t = wave_base + (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, (unsigned)z_));          \
+    } while (0)
+#else
 #define LEAN_FRESH_T() asm volatile("" : "+v"(t))
+#endif
     auto load_weights = [&]() {
         if (!RELOAD) return;
 #pragma unroll
@@ -352,6 +368,7 @@ __device__ __forceinline__ void mean_field_lean(unsigned char *smem, const Fused
                                                       : chain_rows_sel(row_addr, (int)((cl.b & 0x1fffu) * 16u), (m + 7u) >> 3, cl.a, cl.b);
                     val[cl.b >> 16] = acc;
                 }
+                LEAN_FRESH_T();                               // (nothing of the lane id was kept across the ring)
                 if ((t >> 7) == 0) __builtin_amdgcn_s_setprio(0);
                 FL_PSTAMP();
             }
@@ -441,9 +458,9 @@ __device__ __forceinline__ void mean_field_lean(unsigned char *smem, const Fused
     // ---- K = 2 with a chain kernel (the SLAM configuration): the blur passes are dealt to the wavefronts so that they hide ------
     //   under the chain (S of kernel 0): the wavefronts behind the first pair, once their own chain rows are summed, run blur
     //       pass 0 of kernel 1 -- its row sums were complete two barriers ago -- beside the pair that adds the longest rows;
-    //   behind the next barrier: the last wavefront alone runs ALL three passes of kernel 0's small lattice (one wavefront's LDS
-    //       operations execute in order, so its passes need no workgroup barrier between them) while the others run pass 1 of kernel 1;
-    //   then pass 2 of kernel 1.  Three barriers from the chain to X instead of four, kernel 0's passes and a third of kernel 1's
+    //   behind the next barrier: the last wavefront alone runs the passes of kernel 0's small lattice (one wavefront's LDS operations
+    //       execute in order, so its passes need no workgroup barrier between them) -- passes 0 and 1 while the others run pass 1 of
+    //       kernel 1, pass 2 beside their pass 2.  Three barriers from the chain to X instead of four, kernel 0's passes and a third of kernel 1's
     //   off the critical path.  Same operations on the same values per vertex: only who executes them, and when, differs.
     constexpr bool OVL = K == 2 && CH == 1;
     constexpr int NA0 = NT - 128, RA = 4;                 // pass 0 of kernel 1: lanes 128 .. NT-1, vertex (t - 128) + r * NA0
@@ -484,10 +501,11 @@ __device__ __forceinline__ void mean_field_lean(unsigned char *smem, const Fused
             }
         }
     };
-    auto blur_small_all = [&](int lane) {                 // kernel 0, passes 0 .. d by ONE wavefront (lane = 0 .. 63)
+    auto blur_small = [&](int lane, int j_lo, int j_hi) {  // kernel 0, passes j_lo .. j_hi - 1 by ONE wavefront (lane = 0 .. 63)
         const unsigned *tbl = reinterpret_cast<const unsigned *>(smem + lay.nbr[0]);
 #pragma unroll
         for (int j = 0; j < D1; ++j) {
+            if (j < j_lo || j >= j_hi) continue;
             const float2 *src_v = reinterpret_cast<const float2 *>(smem + lay.val[0][j & 1]);
             float2 *dst = reinterpret_cast<float2 *>(smem + lay.val[0][(j & 1) ^ 1]);
             for (int v = lane; v < V[0]; v += 64) blur_vertex(src_v, dst, v, tbl[j * V[0] + v]);
@@ -539,11 +557,12 @@ __device__ __forceinline__ void mean_field_lean(unsigned char *smem, const Fused
             __syncthreads();
             FL_STAMP();
             LEAN_FRESH_T();
-            if (t >= NB) blur_small_all(t - NB);
-            else blur_big(1, t, NB, RB, wb[0]);
+            if (t >= NB) blur_small(t - NB, 0, 2);        // (two of its three dependent passes here, the third beside pass 2 below:
+            else blur_big(1, t, NB, RB, wb[0]);           //  all three in one phase made that phase as long as this one wavefront)
             __syncthreads();
             load_weights();                               // (requested before the last pass: they land under it)
             if (t < NB) blur_big(2, t, NB, RB, wb[1]);
+            else blur_small(t - NB, 2, D1);
             __syncthreads();
         } else {
             __syncthreads();

@@ -1627,7 +1627,7 @@ __global__ void __launch_bounds__(kBlock) k_splat2(KernelDev kd, const float2 *_
 // outside the window reads as zero, which spoils its neighbours' values pass by pass -- by at most `halo` = 1 + dist_1 (+ dist_2)
 // positions from either end, so the inner B - 2 halo results are exactly what P launches of k_blur2 would have stored (the same
 // operations on the same values in the same order) and only those are written.  One launch, one table read per extra pass.
-template <int LANES, int U, bool REC = false>
+template <int LANES, int U, bool REC = false, bool RNT = true>
 __global__ void __launch_bounds__(LANES) k_splat2w(KernelDev kd, const float2 *__restrict__ in, int in_stride, int F, XcdMap nb, int P, int halo)
 {
     constexpr int B = LANES * U;                          // the window: U vertices per lane, at stride LANES (coalesced)
@@ -1660,7 +1660,8 @@ __global__ void __launch_bounds__(LANES) k_splat2w(KernelDev kd, const float2 *_
             typedef unsigned u4v __attribute__((ext_vector_type(4)));
             r[u] = make_uint4(0u, 0u, 0u, 0u);
             if (v >= 0 && v < V) {                        // (read once per iteration: non-temporal, out of the value arrays' way in L2)
-                const u4v q = __builtin_nontemporal_load(reinterpret_cast<const u4v *>(kd.srec + fe + v));
+                const u4v *rp = reinterpret_cast<const u4v *>(kd.srec + fe + v);
+                const u4v q = RNT ? __builtin_nontemporal_load(rp) : *rp;
                 r[u] = make_uint4(q.x, q.y, q.z, q.w);
             }
         }
@@ -2273,7 +2274,9 @@ void launch_step_stream(const CrfDev &c, const KernelDev *kds, const int *maxV, 
                 // (REC: the per-vertex records of the sorted build, one load instead of seven -- KernelDev::srec)
                 static const bool no_rec = ab_env("LCCRF_NO_SPLAT_REC") != nullptr;            // A/B switch: same results either way
                 const bool rec = kd.srec && kd.srec_ok && !no_rec;
-#define LCCRF_SPLAT2W(LN, UU, GRID) do { if (rec) k_splat2w<LN, UU, true><<<GRID, LN, 0, s>>>(kd, q2, c.maxN, c.F, nb, j0, kd.splat_halo); \
+                static const bool rec_plain = ab_env("LCCRF_SPLAT_REC_PLAIN") != nullptr;      // A/B switch: records through plain (cached) loads
+#define LCCRF_SPLAT2W(LN, UU, GRID) do { if (rec && rec_plain) k_splat2w<LN, UU, true, false><<<GRID, LN, 0, s>>>(kd, q2, c.maxN, c.F, nb, j0, kd.splat_halo); \
+                                         else if (rec) k_splat2w<LN, UU, true><<<GRID, LN, 0, s>>>(kd, q2, c.maxN, c.F, nb, j0, kd.splat_halo); \
                                          else k_splat2w<LN, UU, false><<<GRID, LN, 0, s>>>(kd, q2, c.maxN, c.F, nb, j0, kd.splat_halo); } while (0)
                 if (B == 256) LCCRF_SPLAT2W(256, 1, g);
                 else if (B == 512 && wide) LCCRF_SPLAT2W(512, 1, g);
@@ -2283,7 +2286,13 @@ void launch_step_stream(const CrfDev &c, const KernelDev *kds, const int *maxV, 
                     LCCRF_SPLAT2W(512, 2, g5);
                 }
                 else if (wide) LCCRF_SPLAT2W(1024, 1, g);
-                else LCCRF_SPLAT2W(256, 4, g);
+                else {
+                    static const bool w512 = ab_env("LCCRF_SPLAT_512X2") != nullptr;            // A/B switch: 512 lanes x 2 vertices with many frames in flight
+                    if (w512) {
+                        const dim3 g5 = grid_xcd(((long)maxV[k] + core - 1) / core * 512, c.F, &nb, 512);
+                        LCCRF_SPLAT2W(512, 2, g5);
+                    } else LCCRF_SPLAT2W(256, 4, g);
+                }
 #undef LCCRF_SPLAT2W
             } else if (j0 == 1) {
                 const dim3 g = grid_xcd(((long)maxV[k] + blk - 3) / (blk - 2) * blk, c.F, &nb, blk);
