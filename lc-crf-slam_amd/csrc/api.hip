@@ -402,7 +402,9 @@ struct Engine {
             if ((rc = mem.alloc(&k.fastn, Fz * E))) return rc;
             if ((rc = mem.alloc(&k.ndist, (size_t)kNdistAxes))) return rc;
             if ((rc = mem.alloc(&k.nearoff, Fz * 2 * E * 2))) return rc;
-            if (maxN < (1 << 24) && (rc = mem.alloc(&k.srec, Fz * E))) return rc;
+            // (the window splat's 16-byte vertex records: measured +-1 % on C5 x 8, round 5 -- notes/r5_experiments.md; kept as an
+            // experiment of the instrumented library, LCCRF_SPLAT_REC=1)
+            if (maxN < (1 << 24) && ab_env("LCCRF_SPLAT_REC") && (rc = mem.alloc(&k.srec, Fz * E))) return rc;
             if (!ndist_host && (rc = mem.alloc_pinned(&ndist_host, (size_t)LCCRF_MAX_KERNELS * kNdistAxes))) return rc;
         }
         // large frames, a few in flight: the sorted build also leaves the neighbour table in its compact form (16-bit offsets), for

@@ -2271,9 +2271,9 @@ void launch_step_stream(const CrfDev &c, const KernelDev *kds, const int *maxV, 
                 const bool wide = c.F <= (env_w ? atoi(env_w) : 2);
                 const int lanes = wide ? B : kBlock;
                 const dim3 g = grid_xcd(((long)maxV[k] + core - 1) / core * lanes, c.F, &nb, lanes);
-                // (REC: the per-vertex records of the sorted build, one load instead of seven -- KernelDev::srec)
-                static const bool no_rec = ab_env("LCCRF_NO_SPLAT_REC") != nullptr;            // A/B switch: same results either way
-                const bool rec = kd.srec && kd.srec_ok && !no_rec;
+                // (REC: the per-vertex records of the sorted build, one load instead of seven -- KernelDev::srec; allocated by the
+                // instrumented library under LCCRF_SPLAT_REC=1 only: +-1 % on two boxes)
+                const bool rec = kd.srec && kd.srec_ok;
                 static const bool rec_plain = ab_env("LCCRF_SPLAT_REC_PLAIN") != nullptr;      // A/B switch: records through plain (cached) loads
 #define LCCRF_SPLAT2W(LN, UU, GRID) do { if (rec && rec_plain) k_splat2w<LN, UU, true, false><<<GRID, LN, 0, s>>>(kd, q2, c.maxN, c.F, nb, j0, kd.splat_halo); \
                                          else if (rec) k_splat2w<LN, UU, true><<<GRID, LN, 0, s>>>(kd, q2, c.maxN, c.F, nb, j0, kd.splat_halo); \

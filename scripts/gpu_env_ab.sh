@@ -1,7 +1,7 @@
 #!/bin/bash
 # A/B by ENVIRONMENT on one GPU box: bench lines under a list of settings, interleaved twice.  The switches live in the INSTRUMENTED
 # library only (csrc/engine.h: ab_env), which this script selects; "" is the default behaviour of the same library.
-#   scripts/gpu_env_ab.sh "" "LCCRF_NO_SPLAT_REC=1"                     C5, 8 frames in flight
+#   scripts/gpu_env_ab.sh "" "LCCRF_SPLAT_REC=1"                        C5, 8 frames in flight
 #   WORKLOAD=c5 FRAMES=1 scripts/gpu_env_ab.sh "" "LCCRF_NO_PAIR_FUSE=1"
 #   WORKLOAD="c2 c3" scripts/gpu_env_ab.sh "LCCRF_LEAN_SHAPE=0" ""        the fused engine's shape for full-size SLAM frames
 #   WORKLOAD="c1 n500" scripts/gpu_env_ab.sh "" "LCCRF_NO_SMALL_WG=1"     512-lane shapes for small frames

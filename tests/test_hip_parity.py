@@ -882,7 +882,8 @@ def test_object_api_large_frame_runs_inference_in_locality_mode(po, wl, d_list, 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("env", [{"LCCRF_SPLAT_PASSES": "1"}, {"LCCRF_SPLAT_PASSES": "2"}, {"LCCRF_NO_SPLAT_BLUR": "1"}, {"LCCRF_NO_XCD_CHUNK": "1"},
-                                 {"LCCRF_NO_COMPACT_NBR": "1"}, {"LCCRF_NO_PAIR_FUSE": "1"}])
+                                 {"LCCRF_NO_COMPACT_NBR": "1"}, {"LCCRF_NO_PAIR_FUSE": "1"}, {"LCCRF_SPLAT_REC": "1"},
+                                 {"LCCRF_SPLAT_REC": "1", "LCCRF_SPLAT_512X2": "1"}])
 def test_streaming_engine_switches_do_not_change_a_bit(po, wl, env):
     """The sorted build lets the splat take the first blur passes along (axis 0: adjacent ids; axes 1 and 2: ids within the halo of an
     LDS window), reads a compact neighbour table with 3-5 frames in flight, pairs the passes of a single frame ...: every one of
