@@ -324,7 +324,12 @@ bool lean_layout(const CrfDev &c, const KernelDev *kds, const int *maxV, const i
     if (shape != 2) return false;
     const int nt = kNTSmall, max_ppt = 4;
     const int NA = c.activeN > 0 ? c.activeN : c.maxN;
-    if (c.L != 2 || c.K < 1 || c.K > kMaxFusedK || c.F < kSmallMinFrames || NA <= 2 * kNTSmall || NA > max_ppt * nt) return false;
+    // Frames of 513 .. 1024 points take the plan too (two points per lane, everything in registers -- no re-reads): C1 6.47 -> 7.03e7
+    // iterations/s against the half-CU form of the 137 KB plan (shared product buffer there as well, but no fused X + P and no
+    // overlapped blur schedule).  Up to 512 points both kernels' products fit half a CU with buffers of their OWN: 9.94e7 against 9.05e7
+    // on this plan -- those keep small_layout() (LCCRF_LEAN_SMALL, instrumented library, forces the plan for the A/B).
+    static const bool lean_small = ab_env("LCCRF_LEAN_SMALL") != nullptr;
+    if (c.L != 2 || c.K < 1 || c.K > kMaxFusedK || c.F < kSmallMinFrames || (NA <= kNTSmall && !lean_small) || NA > max_ppt * nt) return false;
     for (int k = 0; k < c.K; ++k)
         if (kds[k].d != 2 || kds[k].Epad >= 65535) return false;
     FusedLayout L;
@@ -390,9 +395,11 @@ int launch_inference_fused(const CrfDev &c, const KernelDev *kds, const int *max
                            int with_map, float relax, hipStream_t s)
 {
     FusedArgs a{};
-    const bool small = small_layout(c, kds, maxV, maxRow, &a.lay);
     int lean_nt = 0;
-    const bool lean = !small && lean_layout(c, kds, maxV, maxRow, &a.lay, &lean_nt);
+    const int NAp0 = c.activeN > 0 ? c.activeN : c.maxN;
+    const bool lean_first = NAp0 <= 2 * kNTSmall && lean_layout(c, kds, maxV, maxRow, &a.lay, &lean_nt);      // (LCCRF_LEAN_SMALL experiment)
+    const bool small = !lean_first && small_layout(c, kds, maxV, maxRow, &a.lay);
+    const bool lean = lean_first || (!small && lean_layout(c, kds, maxV, maxRow, &a.lay, &lean_nt));
     if (!small && !lean && !make_layout(c, kds, maxV, maxRow, &a.lay)) return 0;
     static const bool no_chain = ab_env("LCCRF_NO_CHAIN") != nullptr;     // debugging aid: compiler-scheduled S phase
     if (no_chain) a.lay.chain0 = 0;                                        // (the padded plane size is harmless)
@@ -415,7 +422,9 @@ int launch_inference_fused(const CrfDev &c, const KernelDev *kds, const int *max
         if (NAp <= kNTSmall) launch_fused_ppt<kNTSmall, 1>(c, a, s);
         else launch_fused_ppt<kNTSmall, 2>(c, a, s);
     } else if (lean) {
-        if (NAp <= 3 * 512) launch_lean_ppt<512, 3, true>(c, a, s);
+        if (NAp <= 512) launch_lean_ppt<512, 1, false>(c, a, s);
+        else if (NAp <= 2 * 512) launch_lean_ppt<512, 2, false>(c, a, s);
+        else if (NAp <= 3 * 512) launch_lean_ppt<512, 3, true>(c, a, s);
         else launch_lean_ppt<512, 4, true>(c, a, s);
     } else {
         switch ((NAp + kNT - 1) / kNT) {

@@ -625,6 +625,20 @@ for n_iter, relax in ((5, 1.0), (3, 0.5)):
             assert cc.same_bits(Q[f, :n], o.probability()), (n_iter, f, n)
             assert np.array_equal(M[f, :n], o.map()), (n_iter, f, n)
         o.close()
+# frames of 513 .. 1024 points take the plan too (two points per lane, everything in registers)
+small = [wl.slam_problem(n, seed=5300 + i) for i, n in enumerate([1024, 513, 700, 1000, 0, 640, 1023, 514])]
+pbs2 = [small[f %% len(small)] for f in range(F)]
+b = _batch_of(pbs2, maxN=1024)
+b.build(); b.inference(5, True)
+Q, M = b.probability(), b.map()
+assert b.engine() == 2 and b.fused_shape() == (512, 2), (b.engine(), b.fused_shape())
+b.close()
+for i, pb in enumerate(small):
+    o = cc.setup(po.OracleCRF, pb)
+    o.inference_native(5, True)
+    for f in range(i, F, len(small)):
+        assert cc.same_bits(Q[f, :pb["N"]], o.probability()) and np.array_equal(M[f, :pb["N"]], o.map()), ("small", f)
+    o.close()
 # one kernel only (the chain kernel alone, then the short-row kernel alone), and two short-row kernels
 for pick in ((0,), (1,), (1, 1)):
     pb1 = []
