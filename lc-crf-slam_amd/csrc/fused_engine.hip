@@ -339,6 +339,10 @@ bool lean_layout(const CrfDev &c, const KernelDev *kds, const int *maxV, const i
     return true;
 }
 
+// (Measured and dropped: the same schedule in ONE 1024-lane workgroup per CU for frames beyond 2048 points -- C4, whose products share a
+// buffer in fused_loop.h's loop as well: 2.04e7 against 2.42e7 iterations/s.  With nobody else on the CU the re-reads' latency and the
+// seven barriers are all exposed; the plan pays through co-residency, not through its schedule alone.)
+
 template <int NT, int PPT, int K, int CH, bool RELOAD>
 void launch_lean(const CrfDev &c, const FusedArgs &a, hipStream_t s)
 {
