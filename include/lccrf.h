@@ -199,7 +199,7 @@ int  lccrf_batch_set_inputs_host(lccrf_batch_handle b, int n_frames, const int32
  * copied into pinned staging owned by the batch before the call returns -- the caller's buffers may be reused at once -- and
  * uploaded on the batch's copy stream; whatever is queued on the batch afterwards (lccrf_batch_run / _build / ..., on its own or a
  * caller's stream) waits for the upload on the device, and the upload itself waits for the kernels queued before it.  With
- * LCCRF_HOST_PINNED the caller vouches that every array is pinned (hipHostMalloc / hipHostRegister) and stays untouched until
+ * LCCRF_HOST_PINNED the caller vouches that the label / unary and feature arrays are pinned (hipHostMalloc / hipHostRegister) and stay untouched until
  * lccrf_batch_wait_inputs returns (or any later result of this batch has been seen): no staging copy, the DMA reads the caller's
  * memory.  One batch is in flight per handle: to upload batch i+1 under batch i's kernels alternate between two or three handles
  * (tools/replay_multi.cpp does).                                                                       */

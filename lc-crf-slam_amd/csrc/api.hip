@@ -1807,11 +1807,12 @@ int lccrf_batch_set_inputs_host_async(lccrf_batch_handle b, int n_frames, const 
     const float *src_un = unary;
     const int16_t *src_lb = label;
     std::vector<const float *> src_ft(features, features + b->desc.n_kernels);
+    // (the point counts are always staged: a few bytes per frame, and the caller's array is usually a local one)
+    if (!p.npoints && (rc = pinned_plain(e.mem, &p.npoints, Fc))) return rc;
+    memcpy(p.npoints, n_points, sizeof(int) * Fz);
+    src_np = p.npoints;
     if (!direct) {                                     // copy out of the caller's buffers before returning
         std::vector<CopyPool::Job> jobs;
-        if (!p.npoints && (rc = pinned_plain(e.mem, &p.npoints, Fc))) return rc;
-        memcpy(p.npoints, n_points, sizeof(int) * Fz);
-        src_np = p.npoints;
         if (unary) {
             if (!p.unary && (rc = pinned_plain(e.mem, &p.unary, Fc * per * e.L))) return rc;
             jobs.push_back({(char *)p.unary, (const char *)unary, sizeof(float) * Fz * per * e.L});
