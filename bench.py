@@ -951,6 +951,13 @@ def main():
     def barrier():
         if gather is not None:                      # every gather of the timed region has finished when the clock stops
             gather.wait_all()
+        # The host polls for the end of the queued work before the (contractual) barrier + synchronize: a thread that SLEEPS in
+        # hipDeviceSynchronize wakes up tens of microseconds to a millisecond after the GPU has finished, which a 38 ms timed
+        # region of 20 steps reads as up to 4 % (profiles/r5_fused_c2/bench_repeat.txt, first run of a process).
+        ev = torch.cuda.Event()
+        ev.record()
+        while not ev.query():
+            pass
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
