@@ -63,6 +63,7 @@ __host__ __device__ inline bool layout_lean(int NA, int K, const int *V, int row
             const size_t pb = (size_t)L.Ecap[k] * 2 * sizeof(float);
             shared_prod = pb > shared_prod ? pb : shared_prod;
         }
+        if (o > 65535) return false;                       // (the vertex words hold 16-bit absolute addresses into the value arrays)
         L.pstart = chain0 ? take((size_t)(V[0] + 2) * sizeof(unsigned short)) : 0;
         const int p = take(shared_prod < 1024 ? 1024 : shared_prod);        // (the head of it is chain_setup's scratch)
         for (int k = 0; k < K; ++k) L.prod[k] = p;
@@ -135,6 +136,31 @@ __device__ __forceinline__ float chain_rows_keep(unsigned addr, unsigned end, un
                  : [e0] "v"(end), [e1] "v"(e1), [e2] "v"(e2), [e3] "v"(e3)
                  : "scc", "memory", LCCRF_CHAIN_RING_CLOBBERS);
     return acc;
+}
+
+// LDS by absolute byte address (the plan starts at LDS address 0, as the rings assume): no `smem +` in the address arithmetic
+__device__ __forceinline__ float2 lds_f2(unsigned addr)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef float lean_f2 __attribute__((ext_vector_type(2)));
+    const lean_f2 v = *reinterpret_cast<const __attribute__((address_space(3))) lean_f2 *>((unsigned long)addr);
+    return make_float2(v.x, v.y);
+#else
+    (void)addr;                           // (host pass of the translation unit: never called)
+    return make_float2(0.f, 0.f);
+#endif
+}
+
+// slice_point of fused_loop.h for the lean plan's vertex words (absolute addresses, place_products_lean)
+template <int PPT, int K>
+__device__ __forceinline__ float2 slice_point_lean(const PointRegs<PPT, K> &pr, int s, int k, float alpha)
+{
+    const float2 x0 = lds_f2(pr.ix[s][k][0] & 0xffffu), x1 = lds_f2(pr.ix[s][k][0] >> 16), x2 = lds_f2(pr.ix[s][k][1] & 0xffffu);
+    const float w0 = pr.bary[s][k][0] * alpha, w1 = pr.bary[s][k][1] * alpha, w2 = pr.bary[s][k][2] * alpha;   // permutohedral_cpu.h:689
+    float t0 = w0 * x0.x, t1 = w0 * x0.y;
+    t0 += w1 * x1.x; t1 += w1 * x1.y;
+    t0 += w2 * x2.x; t1 += w2 * x2.y;
+    return make_float2(t0, t1);
 }
 
 // Chain lanes of the lean plan.  Ranking as chain_setup (counting sort on the rows' 16-product block count, longest first); then
@@ -244,8 +270,12 @@ __device__ __forceinline__ void place_products_lean(unsigned char *smem, const F
         const unsigned short *pstart = reinterpret_cast<const unsigned short *>(smem + lay.pstart);
 #pragma unroll
         for (int s = 0; s < PPT; ++s) {
-            pr.ix[s][k][0] = (pk[s][k][0] & 0xffffu) | (pk[s][k][1] << 16);
-            pr.ix[s][k][1] = pk[s][k][2] & 0xffffu;
+            // the three vertices as ABSOLUTE LDS byte addresses of their values in the array the slice reads (val[k][d+1 & 1]; the plan
+            // keeps the value arrays in its first 64 KB): a gather is then one bit-field extract away from its ds_read (the index
+            // form costs a second instruction per gather, 24 per wavefront and iteration)
+            const unsigned vb = (unsigned)lay.val[k][kD1 & 1];
+            pr.ix[s][k][0] = (vb + 8u * (pk[s][k][0] & 0xffffu)) | ((vb + 8u * (pk[s][k][1] & 0xffffu)) << 16);
+            pr.ix[s][k][1] = vb + 8u * (pk[s][k][2] & 0xffffu);
             pr.ix[s][k][2] = 0;
             if (tid + s * NT < N) {
                 unsigned sl[kD1];
@@ -392,11 +422,16 @@ __device__ __forceinline__ void mean_field_lean(unsigned char *smem, const Fused
                 p0[r] = pe[r] = 0;
                 if (v < V[k]) { p0[r] = row[v]; pe[r] = row[v + 1]; }
             }
+            // (element u of a row: its product, or -- past the row's end -- LDS bytes [8u, 8u + 8) of the plan's all-zero first 128
+            // bytes: one compare + one select between the row's base address and 0 per element, the element's offset in the instruction)
             float2 x[RS][8];
 #pragma unroll
-            for (int r = 0; r < RS; ++r)
+            for (int r = 0; r < RS; ++r) {
+                const unsigned base = (unsigned)lay.prod[k] + 8u * (unsigned)p0[r];
+                const int n = pe[r] - p0[r];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) x[r][u] = *((p0[r] + u < pe[r]) ? pl + p0[r] + u : zero);
+                for (int u = 0; u < 8; ++u) x[r][u] = lds_f2(((u < n) ? base : 0u) + 8u * u);
+            }
 #pragma unroll
             for (int r = 0; r < RS; ++r) {
                 const int v = t + (base + r) * NT;
@@ -519,7 +554,7 @@ __device__ __forceinline__ void mean_field_lean(unsigned char *smem, const Fused
         float nx[2] = {-pr.un[s].x, -pr.un[s].y};                 // stepInit, densecrf3d.h:154-158
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-            const float2 t = slice_point(smem, lay, pr, s, k, alpha[k]);
+            const float2 t = slice_point_lean(pr, s, k, alpha[k]);
             nx[0] += pr.wn[s][k] * t.x;                           // pairwise3d.h:77
             nx[1] += pr.wn[s][k] * t.y;
         }
