@@ -174,7 +174,21 @@ __device__ __forceinline__ float fast_exp_nonpos(float x)
     static_assert(kFe4 == 4.0f * kFe1 && kFe8 == 8.0f * kFe1, "thresholds are power-of-two multiples of one another");
     float a = -x;
     const bool cut = a > 20;
+#ifndef LCCRF_EXP_FREXP
+#define LCCRF_EXP_FREXP 1                 // A/B (scripts/gpu_ab_build.sh "" "-DLCCRF_EXP_FREXP=0"): 0 = the five compares
+#endif
+#if LCCRF_EXP_FREXP
+    // ... and those five compares are a frexp: kFe1 = 0.69f is its own mantissa (in [0.5, 1), exponent 0), a = m * 2^e with m in
+    // [0.5, 1), so  a > kFe1 * 2^i  <=>  e > i or (e == i and m > kFe1)  and the count over i = 0 .. 4 is clamp(e + [m > kFe1], 0, 5)
+    // (a = 0: e = 0, m = 0 -> 0; a < 0.5: e <= -1 -> 0; a >= 16: e >= 5 -> 5).  Two frexp instructions, a compare, an add, a clamp
+    // instead of five compare / select / add rounds: the X phase is VALU-bound once two frames share a CU (round 5).
+    static_assert(kFe1 >= 0.5f && kFe1 < 1.0f, "kFe1 must be its own frexp mantissa");
+    const int e2 = __builtin_amdgcn_frexp_expf(a);
+    const float m2 = __builtin_amdgcn_frexp_mantf(a);
+    const int mult = min(max(e2 + (m2 > kFe1 ? 1 : 0), 0), 5);
+#else
     const int mult = (a > kFe1 ? 1 : 0) + (a > 2.0f * kFe1 ? 1 : 0) + (a > kFe4 ? 1 : 0) + (a > kFe8 ? 1 : 0) + (a > 16.0f * kFe1 ? 1 : 0);
+#endif
     a = __builtin_amdgcn_ldexpf(a, -mult);
     float r = very_fast_exp(a);
 #pragma unroll
