@@ -191,8 +191,17 @@ __global__ void __launch_bounds__(NT, NT == 384 ? 3 : 4) k_fused_lean(CrfDev c, 
     int V[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) V[k] = a.kd[k].V[f];
+    // (the lane id as scalar wave base + mbcnt wherever it is needed far from here -- the empty-frame exit, which the compiler lays out
+    // as a guarded block at the END of the kernel, and everything behind the loop: a vector register holding `tid` for those would be
+    // live across the whole loop, and the allocator parks such values in the rings' v96..v127 and spills them around the asm)
+    const int wave_base = __builtin_amdgcn_readfirstlane(tid & ~63);
+    auto lane_id = [&]() {
+        int z = 0;
+        asm volatile("" : "+v"(z));
+        return wave_base + (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, (unsigned)z));
+    };
     if (N <= 0) {
-        if (a.with_map) clear_label_bits<NT>(c, f, 0, tid);
+        if (a.with_map) clear_label_bits<NT>(c, f, 0, lane_id());
         return;
     }
     const FusedLayout &lay = a.lay;
@@ -273,9 +282,9 @@ __global__ void __launch_bounds__(NT, NT == 384 ? 3 : 4) k_fused_lean(CrfDev c, 
     float alpha[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) alpha[k] = a.kd[k].alpha;
-    int t = tid;                          // (the loop makes its copy of the lane id opaque; what follows uses that copy --
-    asm volatile("" : "+v"(t));           //  severed from `tid` here, so that no second copy has to outlive the loop)
+    int t = lane_id();                    // (the loop re-forms it per phase the same way)
     mean_field_lean<PPT, K, CH, NT, RELOAD>(smem, lay, V, N, t, pr, cl, alpha, wk, src, a.n_iter, a.relax, a.omr, ins);
+    t = lane_id();
 
     store_results<PPT, K, NT>(c, f, N, t, pr, a.with_map);
     FL_STAMP();

@@ -151,6 +151,48 @@ __device__ __forceinline__ float2 lds_f2(unsigned addr)
 #endif
 }
 
+__device__ __forceinline__ void lds_store_f(unsigned addr, float v)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    *reinterpret_cast<__attribute__((address_space(3))) float *>((unsigned long)addr) = v;
+#else
+    (void)addr; (void)v;
+#endif
+}
+__device__ __forceinline__ void lds_store_f2(unsigned addr, float a, float b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef float lean_f2 __attribute__((ext_vector_type(2)));
+    lean_f2 v;
+    v.x = a;
+    v.y = b;
+    *reinterpret_cast<__attribute__((address_space(3))) lean_f2 *>((unsigned long)addr) = v;
+#else
+    (void)addr; (void)a; (void)b;
+#endif
+}
+
+// point_products of fused_loop.h for the lean plan's slot words: a product's ABSOLUTE LDS byte address / 4 (16 bits: the plan is < 256 KB),
+// so that a store's address is one shift away (the slot-index form costs an extract, a scale and a base add per store)
+template <int PPT, int K, int CH>
+__device__ __forceinline__ void point_products_lean(const FusedLayout &lay, const PointRegs<PPT, K> &pr, int s, int k)
+{
+    const unsigned a0 = (pr.ix[s][k][1] >> 16) << 2, a1 = (pr.ix[s][k][2] & 0xffffu) << 2, a2 = (pr.ix[s][k][2] >> 16) << 2;
+    if (chain_k<CH>(lay, k)) {                             // chain kernel: one plane per label
+        const unsigned pb = (unsigned)lay.Ecap[k] * 4u;
+        lds_store_f(a0, pr.bary[s][k][0] * pr.q[s].x);
+        lds_store_f(a0 + pb, pr.bary[s][k][0] * pr.q[s].y);
+        lds_store_f(a1, pr.bary[s][k][1] * pr.q[s].x);
+        lds_store_f(a1 + pb, pr.bary[s][k][1] * pr.q[s].y);
+        lds_store_f(a2, pr.bary[s][k][2] * pr.q[s].x);
+        lds_store_f(a2 + pb, pr.bary[s][k][2] * pr.q[s].y);
+    } else {                                              // short rows: labels interleaved
+        lds_store_f2(a0, pr.bary[s][k][0] * pr.q[s].x, pr.bary[s][k][0] * pr.q[s].y);
+        lds_store_f2(a1, pr.bary[s][k][1] * pr.q[s].x, pr.bary[s][k][1] * pr.q[s].y);
+        lds_store_f2(a2, pr.bary[s][k][2] * pr.q[s].x, pr.bary[s][k][2] * pr.q[s].y);
+    }
+}
+
 // slice_point of fused_loop.h for the lean plan's vertex words (absolute addresses, place_products_lean)
 template <int PPT, int K>
 __device__ __forceinline__ float2 slice_point_lean(const PointRegs<PPT, K> &pr, int s, int k, float alpha)
@@ -285,6 +327,9 @@ __device__ __forceinline__ void place_products_lean(unsigned char *smem, const F
                     if (chain_k<CH>(lay, k)) {
                         const int v = (int)(pk[s][k][j] & 0xffffu) - 1;
                         sl[j] = (unsigned)((int)pstart[v] + ((int)(pk[s][k][j] >> 16) - (int)row[v]));
+                        sl[j] = ((unsigned)lay.prod[k] >> 2) + sl[j];              // absolute byte address / 4 (label plane 0)
+                    } else {
+                        sl[j] = ((unsigned)lay.prod[k] >> 2) + 2u * sl[j];         // ... of the float2
                     }
                 }
                 pr.ix[s][k][1] |= sl[0] << 16;
@@ -376,7 +421,7 @@ __device__ __forceinline__ void mean_field_lean(unsigned char *smem, const Fused
     auto phase_P = [&](int k) {
 #pragma unroll
         for (int s = 0; s < PPT; ++s)
-            if (t + s * NT < N) point_products<PPT, K, CH>(smem, lay, pr, s, k);
+            if (t + s * NT < N) point_products_lean<PPT, K, CH>(lay, pr, s, k);
         if (chain_k<CH>(lay, k)) chain_pads_lean(smem, cl, t);      // (the buffer held the other kernel's products)
     };
     auto phase_S = [&](int k) {
@@ -565,7 +610,7 @@ __device__ __forceinline__ void mean_field_lean(unsigned char *smem, const Fused
     load_weights();
 #pragma unroll
     for (int s = 0; s < PPT; ++s)
-        if (t + s * NT < N) point_products<PPT, K, CH>(smem, lay, pr, s, KF);
+        if (t + s * NT < N) point_products_lean<PPT, K, CH>(lay, pr, s, KF);
     if (chain_k<CH>(lay, KF)) chain_pads_lean(smem, cl, t);
     for (int it = 0; it < n_iter; ++it) {
         LEAN_FRESH_T();
@@ -624,7 +669,7 @@ __device__ __forceinline__ void mean_field_lean(unsigned char *smem, const Fused
         for (int s = 0; s < PPT; ++s) {
             if (t + s * NT < N) {
                 point_update(s);
-                if (more) point_products<PPT, K, CH>(smem, lay, pr, s, KF);
+                if (more) point_products_lean<PPT, K, CH>(lay, pr, s, KF);
             }
         }
         FL_STAMP();
