@@ -32,6 +32,7 @@
 #include "engine.h"
 #include "device_math.h"
 #include "fused_loop.h"
+#include "frame_build.h"
 #include <type_traits>
 
 #include <algorithm>
@@ -43,33 +44,7 @@ namespace lccrf {
 namespace {
 
 using namespace fl;
-
-constexpr unsigned kEmptyKey = 0x80008000u;       // (-32768, -32768): not a key any sane feature produces; a frame that does is sent to the fallback path
-constexpr int kHdr = 512;                          // [0,128) unused, [128,192) zero block, [192,512) scan scratch / flags
-
-struct FrameArgs {
-    const float *feat[kMaxFusedK];        // [F][maxN][2] features of kernel k (already divided by the stdev)
-    float w[kMaxFusedK];                  // kernel weights (PottsPotential3D::w_)
-    float scale[2], inv_dp1, alpha;       // d = 2 constants: permutohedral_cpu.h:249,282-285,681
-    int maxN;                             // per-frame stride of feat / label / unary / Q / map
-    const int16_t *label;                 // non-null: unary energies from labels and tbl (densecrf3d.h:100-130, L = 2)
-    float tbl[5];                         //   {u, n0, n1, p0, p1}
-    int n_iter, with_map;
-    float relax;
-    int hcap;                             // hash capacity (power of two >= 1024)
-    int lds_total;                        // dynamic LDS bytes of the launch
-    int *V_out[kMaxFusedK];               // [F] vertices per kernel (reference M_), or null
-    int *status;                          // pinned host word: set to 1 when a frame does not fit this kernel's LDS plan
-    int *frame_status;                    // device [F] or null: 1 for exactly the frames that did not fit (they alone are re-run), else 0
-    unsigned *dual;                       // DUAL launches: [F][kDualWords] hand-off area between a frame's two workgroups, else null
-    unsigned dual_epoch;                  //   value the helper publishes in word 0 when its tables are complete (changes every launch)
-    int n_single;                         // >= 0: the point count of the launch's only frame (else c.n_points[f])
-    int drop_helper;                      // instrumented builds only (LCCRF_DUAL_DROP_HELPER): the helper workgroup leaves at once -- the main one must time out and fall back
-    unsigned *done;                       // single-frame launches: pinned host word that receives done_epoch when the frame's results (labels in
-    unsigned done_epoch;                  //   pinned memory, status words) are visible to the host -- earlier than the runtime's completion signal
-    long long *timing;                    // instrumented builds only
-    int timing_block, timing_lane;
-};
+using namespace fb;
 
 struct Hdr {                              // lives at smem + 192
     int wave_sum[16];
@@ -94,53 +69,6 @@ __device__ __forceinline__ unsigned dual_load(const unsigned *p)       // device
 __device__ __forceinline__ unsigned long long dual_load2(const unsigned *p)   // the same, 8 bytes (p 8-byte aligned)
 {
     return __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-__device__ __forceinline__ unsigned hash32(unsigned key)
-{
-    unsigned h = key * 2654435761u;
-    h ^= h >> 15;
-    h *= 2246822519u;
-    h ^= h >> 13;
-    return h;
-}
-
-// Inclusive scan over the 64 lanes of a wavefront with DPP: Hillis-Steele inside each row of 16 lanes (row_shr),
-// then the row totals are handed on with row_bcast:15 (into rows 1, 3) and row_bcast:31 (into rows 2, 3).
-__device__ __forceinline__ int wave_incl_scan(int x)
-{
-    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);
-    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);
-    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);
-    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);
-    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);
-    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);
-    return x;
-}
-
-// Exclusive scan of one int per lane over the workgroup; returns the prefix, `total` the grand total.
-// Two barriers; wave_sum may be reused right after the call returns only behind another barrier.
-template <int NT>
-__device__ __forceinline__ int block_excl_scan(int x, int tid, int *wave_sum, int &total)
-{
-    const int lane = tid & 63, wave = tid >> 6;
-    const int incl = wave_incl_scan(x);
-    __syncthreads();                                      // a previous scan's readers are done with wave_sum
-    if (lane == 63) wave_sum[wave] = incl;
-    __syncthreads();
-    const int ws = lane < NT / 64 ? wave_sum[lane] : 0;  // the 16 wavefront totals, scanned again inside every wavefront
-    const int wincl = wave_incl_scan(ws);
-    total = __builtin_amdgcn_readlane(wincl, NT / 64 - 1);
-    const int wbase = __builtin_amdgcn_readlane(wincl - ws, __builtin_amdgcn_readfirstlane(wave));
-    return wbase + incl - x;
-}
-
-// key of the simplex corner with remainder `rem` of a point record, packed (x | y << 16)
-__device__ __forceinline__ unsigned corner_key(const int16_t (&r0)[2], const uint8_t (&rk)[2], int rem)
-{
-    const unsigned x = (unsigned short)vertex_coord<2>(r0[0], rk[0], rem);
-    const unsigned y = (unsigned short)vertex_coord<2>(r0[1], rk[1], rem);
-    return x | (y << 16);
 }
 
 // NT = 1024 lanes, or 512 for frames of up to 1024 points whose plan fits half the CU's LDS: two frames per CU
@@ -857,9 +785,9 @@ bool frame_supported(const CrfDev &c, const KernelDev *kds)
 
 size_t frame_dual_bytes(int frames) { return (size_t)frames * kDualWords * sizeof(unsigned); }
 
-bool launch_frame(const CrfDev &c, const KernelDev *kds, int n_iter, int with_map, float relax, int *status, int *frame_status,
-                  const int16_t *label, const float *tbl5, hipStream_t s, bool allow_small, unsigned *dual, unsigned dual_epoch,
-                  unsigned *done, unsigned done_epoch)
+int launch_frame(const CrfDev &c, const KernelDev *kds, int n_iter, int with_map, float relax, int *status, int *frame_status,
+                 const int16_t *label, const float *tbl5, hipStream_t s, bool allow_small, unsigned *dual, unsigned dual_epoch,
+                 unsigned *done, unsigned done_epoch, bool allow_lean)
 {
     FrameArgs a{};
     for (int k = 0; k < c.K; ++k) {
@@ -878,6 +806,13 @@ bool launch_frame(const CrfDev &c, const KernelDev *kds, int n_iter, int with_ma
     a.n_iter = n_iter;
     a.with_map = with_map;
     a.relax = relax;
+    a.omr = 1 - relax;
+    for (int k = 0; k < c.K; ++k) {
+        a.bary_out[k] = kds[k].bary;
+        a.norm_out[k] = kds[k].norm;
+        a.nbr_out[k] = kds[k].nbr16;
+    }
+    a.Epad = kds[0].Epad;
     const int NA = c.activeN > 0 ? c.activeN : c.maxN;
     a.hcap = frame_hcap(NA);
     a.lds_total = (int)kLdsLimit;
@@ -925,7 +860,15 @@ bool launch_frame(const CrfDev &c, const KernelDev *kds, int n_iter, int with_ma
         else launch_frame_ppt<NT, P, 2>(c, a, s);              \
         break;
     static const bool no_dual = ab_env("LCCRF_NO_DUAL") != nullptr;         // A/B switch: same results either way
-    if (dual && !no_dual && c.K == 2 && !small) {                           // a frame alone: two workgroups, one per lattice build
+    // Full-size frames (1025 .. 2048 points, the two-kernel SLAM configuration): 512 lanes and half the CU's LDS per frame as well
+    // (frame_lean.hip) -- flagged frames and the engine's give-up rule as for the small shape.
+    static const bool no_lean = ab_env("LCCRF_NO_FRAME_LEAN") != nullptr;  // A/B switch: same results either way
+    const bool lean = allow_lean && !no_lean && !small && frame_lean_plausible(NA, c.K, c.F) && kds[0].Epad == kds[c.K - 1].Epad &&
+                      kds[0].Epad < 65535;
+    if (lean) {
+        a.lds_total = (int)kLdsHalf;
+        launch_frame_lean(c, a, NA, s);
+    } else if (dual && !no_dual && c.K == 2 && !small) {                           // a frame alone: two workgroups, one per lattice build
         switch ((NA + kNT - 1) / kNT) {
         case 1: launch_frame_dual<1>(c, a, s); break;
         case 2: launch_frame_dual<2>(c, a, s); break;
@@ -958,7 +901,7 @@ bool launch_frame(const CrfDev &c, const KernelDev *kds, int n_iter, int with_ma
         for (int i = 1; i < h[63] && i < 63; ++i) fprintf(stderr, " %lld", h[i] - h[i - 1]);
         fprintf(stderr, "\n");
     }
-    return small;
+    return lean ? 2 : small ? 1 : 0;
 }
 
 }  // namespace lccrf

@@ -35,6 +35,24 @@ __host__ __device__ inline bool lean_chain_wanted(int NA, int V0, int row0, int 
     return row0 >= kChainMinRow && V0 <= chain_max_v(nt) && V0 <= 256 && lean_plane_floats(NA, V0) < 65535;
 }
 
+// The persistent tables of one kernel, carved at byte offset `o` of the plan (advanced past them): both value arrays, the neighbour
+// table (the chain kernel's only: its lattice is small, <= chain_max_v vertices; -1 = the table stays in HBM) and the row starts.
+// Kernel k's places depend on the vertex counts of kernels 0 .. k only -- the one-launch frame kernel (frame_lean.hip) builds its
+// tables straight into them, kernel after kernel, before the plan as a whole is known.
+struct LeanTables {
+    int val0, val1, nbr, row;
+};
+__host__ __device__ inline LeanTables lean_tables(size_t &o, int Vk, bool chain)
+{
+    auto take = [&](size_t bytes) { size_t r = o; o += (bytes + 15) & ~(size_t)15; return (int)r; };
+    LeanTables t;
+    t.val0 = take((size_t)(Vk + 1) * sizeof(float2));
+    t.val1 = take((size_t)(Vk + 1) * sizeof(float2));
+    t.nbr = chain ? take((size_t)kD1 * Vk * sizeof(unsigned)) : -1;
+    t.row = take((size_t)(Vk + 2) * sizeof(unsigned short));
+    return t;
+}
+
 // LDS plan (see FusedLayout; nbr[k] < 0: kernel k's neighbour table stays in HBM -- every kernel's but the chain kernel's;
 // pstart: u16 [V0 + 2] row starts of the chain kernel)
 __host__ __device__ inline bool layout_lean(int NA, int K, const int *V, int row0, FusedLayout *lay, int nt, size_t lds_limit)
@@ -56,10 +74,11 @@ __host__ __device__ inline bool layout_lean(int NA, int K, const int *V, int row
         for (int k = 0; k < K; ++k) {
             const bool chain = k == 0 && chain0;
             L.Ecap[k] = chain ? lean_plane_floats(NA, V[k]) : ((NA * D1 + 63) & ~63);
-            L.val[k][0] = take((size_t)(V[k] + 1) * sizeof(float2));
-            L.val[k][1] = take((size_t)(V[k] + 1) * sizeof(float2));
-            L.nbr[k] = chain ? take((size_t)D1 * V[k] * sizeof(unsigned)) : -1;   // the chain kernel's lattice is small (<= chain_max_v vertices): its table stays in LDS
-            L.row[k] = take((size_t)(V[k] + 2) * sizeof(unsigned short));
+            const LeanTables lt = lean_tables(o, V[k], chain);
+            L.val[k][0] = lt.val0;
+            L.val[k][1] = lt.val1;
+            L.nbr[k] = lt.nbr;
+            L.row[k] = lt.row;
             const size_t pb = (size_t)L.Ecap[k] * 2 * sizeof(float);
             shared_prod = pb > shared_prod ? pb : shared_prod;
         }
@@ -369,7 +388,9 @@ __device__ __forceinline__ void opaque_ids(PointRegs<PPT, K> &pr)
 //   blur pass 0 | 1 | 2 (every kernel)
 // RELOAD: the unary energies, barycentric weights and norms are not kept in registers across the iteration -- every X re-reads this
 // lane's (L2-resident) records; what a lane holds between iterations is Q and the packed ids / slots (8 registers per point).
-template <int PPT, int K, int CH, int NT, bool RELOAD>
+// NORM (the one-launch frame kernel): ONE pass that leaves every kernel's norm = 1 / (K * 1 + 1e-20) (pairwise3d.h:20-28) in src.norm
+// instead of updating Q -- the caller sets Q = 1; the same splat / row sums / blur / slice as an iteration's, phase by phase.
+template <int PPT, int K, int CH, int NT, bool RELOAD, bool NORM = false>
 __device__ __forceinline__ void mean_field_lean(unsigned char *smem, const FusedLayout &lay, const int (&V)[K], int N, int &t,
                                                 PointRegs<PPT, K> &pr, ChainLane &cl, const float (&alpha)[K],
                                                 const float (&wk)[K], const LeanSrc &src, int n_iter, float relax, float omr, Instr &ins)
@@ -396,23 +417,27 @@ __device__ __forceinline__ void mean_field_lean(unsigned char *smem, const Fused
 #else
 #define LEAN_FRESH_T() asm volatile("" : "+v"(t))
 #endif
+    static_assert(!NORM || RELOAD, "the normalisation pass is built for the re-reading shapes only");
     auto load_weights = [&]() {
         if (!RELOAD) return;
 #pragma unroll
         for (int s = 0; s < PPT; ++s) {
             const int i = t + s * NT;                   // (a lane without a point in this slot reads the slice's spare rows or 0: unused)
-            typedef unsigned lean_u2 __attribute__((ext_vector_type(2)));
-            const lean_u2 u = __builtin_amdgcn_raw_buffer_load_b64(src.unary, i * 8, 0, 0);
-            pr.un[s] = make_float2(__uint_as_float(u.x), __uint_as_float(u.y));
+            if (!NORM) {
+                typedef unsigned lean_u2 __attribute__((ext_vector_type(2)));
+                const lean_u2 u = __builtin_amdgcn_raw_buffer_load_b64(src.unary, i * 8, 0, 0);
+                pr.un[s] = make_float2(__uint_as_float(u.x), __uint_as_float(u.y));
+            }
 #pragma unroll
             for (int k = 0; k < K; ++k) {
                 const lean_u3 b = __builtin_amdgcn_raw_buffer_load_b96(src.bary[k], i * (D1 * 4), 0, 0);
                 pr.bary[s][k][0] = __uint_as_float(b.x);
                 pr.bary[s][k][1] = __uint_as_float(b.y);
                 pr.bary[s][k][2] = __uint_as_float(b.z);
-                pr.wn[s][k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(src.norm[k], i * 4, 0, 0));
+                if (!NORM) pr.wn[s][k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(src.norm[k], i * 4, 0, 0));
             }
         }
+        if (NORM) return;
 #pragma unroll
         for (int s = 0; s < PPT; ++s)
 #pragma unroll
@@ -596,6 +621,14 @@ __device__ __forceinline__ void mean_field_lean(unsigned char *smem, const Fused
         }
     };
     auto point_update = [&](int s) {
+        if constexpr (NORM) {                                     // pairwise3d.h:22-27: norm_[i] = 1 / (compute(ones)[i] + 1e-20)
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const float v = slice_point_lean(pr, s, k, alpha[k]).x;
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(1.0f / (v + 1e-20f)), src.norm[k], (t + s * NT) * 4, 0, 0);
+            }
+            return;
+        }
         float nx[2] = {-pr.un[s].x, -pr.un[s].y};                 // stepInit, densecrf3d.h:154-158
 #pragma unroll
         for (int k = 0; k < K; ++k) {

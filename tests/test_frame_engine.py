@@ -661,3 +661,84 @@ print("ok")
     env = cc.switch_env(LCCRF_LEAN_SHAPE=shape)
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_full_size_frames_share_a_cu_in_the_one_launch_kernel(po, wl):
+    """Round 5: lccrf_batch_run on batches of >= 256 full-size two-kernel frames (1025 .. 2048 points) runs the WHOLE frame -- both
+    lattice builds, normalisation, inference -- in 512-lane workgroups on half a CU (csrc/frame_lean.hip: LDS scratch laid out by
+    lifetime, the per-point records through HBM/L2, fused_lean.h's loop).  Ragged sizes around the points-per-lane boundaries, an
+    empty and a tiny frame, one sparse frame that does not fit (flagged, re-run alone), labels and raw unaries, relax != 1;
+    every frame against the oracle bit for bit, V against the reference's M_; then build + inference on the same handle."""
+    sizes = [2000, 1025, 1536, 1537, 1999, 2048, 1100, 1920, 1921, 2047, 0, 700, 1152, 3, 2001, 1300]
+    base = [wl.slam_problem(n, seed=6100 + i) for i, n in enumerate(sizes)]
+    odd = _shaped_problem(wl, 1800, "sparse", seed=7)
+    F = 272
+    refs = {}
+    rng = np.random.default_rng(12)
+    for n_iter, relax, use_unary in ((5, 1.0, False), (3, 0.5, True)):
+        if use_unary:                                      # raw energies instead of labels, some beyond fast_exp's cut-off
+            def raw(pb):
+                pu = {k: v for k, v in pb.items() if k != "label"}
+                pu["unary"] = rng.uniform(0.05, 3.0, (pb["N"], 2)).astype(np.float32)
+                pu["unary"][::50] = np.float32([0.0, 45.0])
+                return pu
+            base, odd = [raw(pb) for pb in base], raw(odd)
+        pbs = [odd if f == 99 else base[f % len(base)] for f in range(F)]
+        b = _batch_of(pbs, maxN=2048, use_unary=use_unary)
+        b.run(n_iter, True, relax=relax)
+        Q, M = b.probability(), b.map()
+        assert b.engine() == 3 and b.fused_shape() == (512, 2) and b.fallback_frames() == 1, (b.engine(), b.fused_shape(), b.fallback_frames())
+        Vs = [b.lattice_sizes(k) for k in range(2)]
+        for i, pb in enumerate(base + [odd]):
+            o = cc.setup(po.OracleCRF, pb)
+            o.inference_native(n_iter, True, relax)
+            n = pb["N"]
+            for f in ([99] if i == len(base) else [f for f in range(i, F, len(base)) if f != 99]):
+                assert cc.same_bits(Q[f, :n], o.probability()), (n_iter, f, n)
+                assert np.array_equal(M[f, :n], o.map()), (n_iter, f, n)
+                assert [int(Vs[k][f]) for k in range(2)] == [o.kernel(k)["V"] if n else 0 for k in range(2)], (f, n)
+            if (n_iter, i) == (5, 0):
+                refs["q0"] = o.probability().copy()
+            o.close()
+        if n_iter == 5:
+            # the kernel kept its records in the batch's lattice arrays: a build + inference on the same handle starts over
+            b.build(); b.inference(5, True)
+            assert b.engine() in (1, 2) and cc.same_bits(b.probability()[0, :sizes[0]], refs["q0"])
+            b.run(5, True)                                 # ... and lccrf_batch_inference after ANOTHER run builds again by itself
+            assert b.engine() == 3 and cc.same_bits(b.probability(), Q)
+            b.inference(5, True)
+            assert b.engine() in (1, 2) and cc.same_bits(b.probability()[0, :sizes[0]], refs["q0"])
+        b.close()
+    # a batch whose frames mostly do NOT fit: the engine stops asking for the shape
+    pbs = [odd if f % 2 else base[0] for f in range(F)]
+    b = _batch_of(pbs, maxN=2048, use_unary=True)
+    b.run(2, True)
+    q = b.probability()
+    assert b.fallback_frames() == F // 2 and b.fused_shape() == (512, 2)
+    b.run(2, True)
+    assert b.fused_shape() == (1024, 1) and cc.same_bits(b.probability(), q)
+    b.close()
+
+
+def test_frame_lean_switch_gives_the_same_bits(wl):
+    """LCCRF_NO_FRAME_LEAN (instrumented library): the same batch through one 1024-lane workgroup per frame -- the same bits."""
+    code = r"""
+import importlib, sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import crf_cases as cc
+from test_frame_engine import _batch_of
+wl = importlib.import_module("lc-crf-slam_amd.workloads")
+pbs = [wl.slam_problem(n, seed=6200 + i) for i, n in enumerate([2000, 1500, 1900, 1026] * 64)]
+b = _batch_of(pbs, maxN=2000)
+b.run(5, True)
+np.save(sys.argv[1], np.concatenate([b.probability().ravel().view(np.uint32), np.asarray(b.fused_shape(), np.uint32)]))
+""" % (ROOT, os.path.join(ROOT, "tests"))
+    outs = []
+    for env_extra in ({}, {"LCCRF_NO_FRAME_LEAN": "1"}):
+        path = os.path.join("/tmp", "lean_switch_%d_%d.npy" % (os.getpid(), len(outs)))
+        r = subprocess.run([sys.executable, "-c", code, path], env=cc.switch_env(**env_extra), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        outs.append(np.load(path))
+        os.remove(path)
+    assert tuple(outs[0][-2:]) == (512, 2) and tuple(outs[1][-2:]) == (1024, 1)
+    assert np.array_equal(outs[0][:-2], outs[1][:-2])
