@@ -146,8 +146,6 @@ struct Engine {
     std::vector<KernelDev> kdevs;      // contiguous copy handed to the launchers
     std::vector<int> maxV, maxRow;
     bool unary_set = false, built = false, sizes_known = false, started = false;
-    bool rebuild_pending = false;      // lccrf_batch_build's lattices were overwritten by a later lccrf_batch_run (frame_lean.hip keeps its
-                                       //   records in the same arrays): the next lccrf_batch_inference builds them again first
     int built_upto = 0;                // kernels [0, built_upto) have their lattice
     int engine_pref = 0, engine_used = 1;   // engine_used is REPORT-only state (lccrf_batch_get_engine): 1 streaming, 2 fused, 3 one launch per frame
     int sized_engine = 1;              // what learn_sizes() chose for inference on lattices that sit in HBM (1 or 2)
@@ -194,6 +192,7 @@ struct Engine {
     bool frame_small_used = false;     //   more than 1/8 of a batch's frames did not fit that plan
     bool frame_lean_ok = true;         // ... and so may batches of full-size frames (frame_lean.hip), under the same rule
     bool frame_lean_used = false;
+    unsigned char *lean_rec = nullptr; //   [Fcap][kLeanRecBytes] per-point records of that kernel (lazy)
     static constexpr int kDualMaxFrames = 64;    // (measured, `scripts/small_batch_latency.py`: 4 frames 98 -> 86 us, 32 frames 93 -> 83 us, 128 frames 112 -> 114 us)
     bool opt_single_wg = false;        // LCCRF_OPT_SINGLE_WORKGROUP: never the two-workgroup form (lccrf_set_option)
     int opt_vertex_order = 0;          // LCCRF_OPT_VERTEX_ORDER: 0 automatic (= on), 1 on, 2 off -- locality mode's sorted build
@@ -760,19 +759,19 @@ struct Engine {
         if (done_armed && ++done_epoch == 0) done_epoch = 1;
         labels_armed = done_armed && with_map && L == 2 && map_host && map_host == crf.map && activeN > 0;
         if (labels_armed) memset(map_host, 0xff, (size_t)activeN * sizeof(int16_t));
-        // (frame_lean.hip writes label-derived energies into crf.unary: only into the engine's own array, never into a bound one)
-        const bool lean_ok = frame_lean_ok && (!from_label || crf.unary == unary_own) && crf.unary != nullptr;
+        // full-size frames, two per CU (frame_lean.hip): the record area its loop re-reads is allocated when a batch first wants it
+        if (frame_lean_ok && !lean_rec && frame_lean_wanted(crf)) {
+            int rc = mem.alloc(reinterpret_cast<char **>(&lean_rec), frame_lean_rec_bytes(Fcap));
+            if (rc) return rc;
+        }
         const int shape = launch_frame(crf, kdevs.data(), n_iter, with_map, relax, late_status, frame_status,
                                        from_label ? deferred_label : nullptr, deferred_tbl.v, stream, frame_small_ok, dual, dual_epoch,
-                                       done_armed ? done_word : nullptr, done_epoch, lean_ok);
+                                       done_armed ? done_word : nullptr, done_epoch, frame_lean_ok ? lean_rec : nullptr);
         HIP_TRY(hipGetLastError());
         frame_small_used = shape == 1;
         frame_lean_used = shape == 2;
         fused_shape = shape == 0 ? (1024 | 1 << 16) : (512 | 2 << 16);       // lanes per frame | frames per CU
-        if (frame_lean_used) {                             // its records sit in the kernels' HBM arrays, in its own vertex numbering:
-            built_upto = 0;                                //   whatever lattices were there are gone
-            sizes_known = false;
-        }
+
         late_pending = true;
         late_iter = n_iter;
         late_map = with_map;
@@ -1734,7 +1733,6 @@ static int batch_common_inputs(lccrf_batch *b, int n_frames, const float *conf, 
     e.sync_views();
     e.unary_set = false;
     e.built = false;
-    e.rebuild_pending = false;
     e.built_upto = 0;
     e.sizes_known = false;
     e.started = false;
@@ -2041,13 +2039,9 @@ int lccrf_batch_inference(lccrf_batch_handle b, int n_iterations, int with_map, 
 {
     CHECK_H(b);
     Engine &e = b->eng;
-    if (!e.built && !e.rebuild_pending) return fail(LCCRF_E_STATE, "lccrf_batch_build has not run for these inputs");
-    int rc = e.resolve_late();
+    if (!e.built) return fail(LCCRF_E_STATE, "lccrf_batch_build has not run for these inputs");
+    int rc = e.learn_sizes();
     if (rc) return rc;
-    rc = e.learn_sizes();                             // (builds what is pending: everything, after a run that took the arrays)
-    if (rc) return rc;
-    e.built = true;
-    e.rebuild_pending = false;
     StreamScope scope(e, stream);
     if ((rc = scope.enter())) return rc;
     HIP_TRY(hipEventRecord(e.ev[2], e.stream));
@@ -2075,9 +2069,7 @@ int lccrf_batch_run(lccrf_batch_handle b, int n_iterations, int with_map, float 
         if (er != hipSuccess) rc = fail(LCCRF_E_HIP, "hipEventRecord: %s", hipGetErrorString(er));
     }
     e.timed_inf = !rc;
-    const bool was_built = e.built || e.rebuild_pending;
     e.built = e.built_upto == (int)e.kernels.size() && !e.kernels.empty();
-    e.rebuild_pending = was_built && !e.built;
     return rc;
 }
 

@@ -214,15 +214,17 @@ bool frame_supported(const CrfDev &c, const KernelDev *kds);
 // afterwards if some frame did not fit the kernel's LDS plan; `frame_status` (device [F], or null) then holds 1 for
 // exactly those frames and the caller runs them -- and only them -- on the two-kernel path.
 // allow_small: frames of up to 1024 points may run as 512-lane workgroups in half the CU's LDS (two frames per CU);
-// allow_lean: so may batches of full-size two-kernel frames (1025 .. 2048 points; frame_lean.hip -- that kernel leaves its per-point
-// records in kds[k].bary / norm / nbr16 and c.unary, in its OWN vertex numbering: the caller must treat the lattices in HBM as unbuilt).
+// lean_rec (device memory of frame_lean_rec_bytes(F), or null): so may batches of full-size two-kernel frames (1025 .. 2048 points;
+// frame_lean.hip keeps the per-point records its loop re-reads in that area).
 // Returns the shape it launched: 0 one frame per CU, 1 the small shape, 2 the lean one (a caller that sees many frames of a
 // half-CU shape flagged turns that shape off).
 // dual (device memory of frame_dual_bytes(F), zeroed once) + a launch-unique dual_epoch != 0: two-kernel frames are given
 // two workgroups each -- one per lattice build (single frames: the other 255 CUs are idle anyway).
 int launch_frame(const CrfDev &c, const KernelDev *kds, int n_iter, int with_map, float relax, int *status, int *frame_status,
                  const int16_t *label, const float *tbl5, hipStream_t s, bool allow_small = true, unsigned *dual = nullptr,
-                 unsigned dual_epoch = 0, unsigned *done = nullptr, unsigned done_epoch = 0, bool allow_lean = false);
+                 unsigned dual_epoch = 0, unsigned *done = nullptr, unsigned done_epoch = 0, unsigned char *lean_rec = nullptr);
+bool frame_lean_wanted(const CrfDev &c);              // would launch_frame take the lean shape for this batch, given the area?
+size_t frame_lean_rec_bytes(int frames);
 size_t frame_dual_bytes(int frames);
 // rows of `bytes` bytes each between a frame-strided array and a compact one: dst[i] = src[list[i]] (gather = 1) or
 // dst[list[i]] = src[i] (gather = 0); strides in bytes, everything 4-byte aligned

@@ -36,11 +36,8 @@ struct FrameArgs {
     unsigned done_epoch;                  //   pinned memory, status words) are visible to the host -- earlier than the runtime's completion signal
     long long *timing;                    // instrumented builds only
     int timing_block, timing_lane;
-    // frame_lean.hip only: the per-point records its loop re-reads every iteration live in the batch's own arrays (KernelDev of kernel k)
-    float *bary_out[kMaxFusedK];          // [F][Epad]      barycentric weights, entry 3 i + j
-    float *norm_out[kMaxFusedK];          // [F][maxN]      1 / (K * 1 + 1e-20)
-    unsigned *nbr_out[kMaxFusedK];        // [F][3][Epad]   (n1 + 1) | (n2 + 1) << 16 per (axis, vertex) -- in THIS kernel's vertex numbering
-    int Epad;                             // entries per frame of those arrays
+    // frame_lean.hip only: [F][kLeanRecBytes] -- the per-point records its loop re-reads every iteration (fused_lean.h: kLeanRec*)
+    unsigned char *rec;
     float omr;                            // 1 - relax (fp32, densecrf3d.h:94), formed on the host
 };
 

@@ -33,6 +33,7 @@
 #include "device_math.h"
 #include "fused_loop.h"
 #include "frame_build.h"
+#include "fused_lean.h"
 #include <type_traits>
 
 #include <algorithm>
@@ -785,9 +786,16 @@ bool frame_supported(const CrfDev &c, const KernelDev *kds)
 
 size_t frame_dual_bytes(int frames) { return (size_t)frames * kDualWords * sizeof(unsigned); }
 
+bool frame_lean_wanted(const CrfDev &c)
+{
+    const int NA = c.activeN > 0 ? c.activeN : c.maxN;
+    return frame_lean_plausible(NA, c.K, c.F);
+}
+size_t frame_lean_rec_bytes(int frames) { return (size_t)frames * kLeanRecBytes; }
+
 int launch_frame(const CrfDev &c, const KernelDev *kds, int n_iter, int with_map, float relax, int *status, int *frame_status,
                  const int16_t *label, const float *tbl5, hipStream_t s, bool allow_small, unsigned *dual, unsigned dual_epoch,
-                 unsigned *done, unsigned done_epoch, bool allow_lean)
+                 unsigned *done, unsigned done_epoch, unsigned char *lean_rec)
 {
     FrameArgs a{};
     for (int k = 0; k < c.K; ++k) {
@@ -807,12 +815,7 @@ int launch_frame(const CrfDev &c, const KernelDev *kds, int n_iter, int with_map
     a.with_map = with_map;
     a.relax = relax;
     a.omr = 1 - relax;
-    for (int k = 0; k < c.K; ++k) {
-        a.bary_out[k] = kds[k].bary;
-        a.norm_out[k] = kds[k].norm;
-        a.nbr_out[k] = kds[k].nbr16;
-    }
-    a.Epad = kds[0].Epad;
+    a.rec = lean_rec;
     const int NA = c.activeN > 0 ? c.activeN : c.maxN;
     a.hcap = frame_hcap(NA);
     a.lds_total = (int)kLdsLimit;
@@ -863,8 +866,7 @@ int launch_frame(const CrfDev &c, const KernelDev *kds, int n_iter, int with_map
     // Full-size frames (1025 .. 2048 points, the two-kernel SLAM configuration): 512 lanes and half the CU's LDS per frame as well
     // (frame_lean.hip) -- flagged frames and the engine's give-up rule as for the small shape.
     static const bool no_lean = ab_env("LCCRF_NO_FRAME_LEAN") != nullptr;  // A/B switch: same results either way
-    const bool lean = allow_lean && !no_lean && !small && frame_lean_plausible(NA, c.K, c.F) && kds[0].Epad == kds[c.K - 1].Epad &&
-                      kds[0].Epad < 65535;
+    const bool lean = lean_rec && !no_lean && !small && frame_lean_plausible(NA, c.K, c.F);
     if (lean) {
         a.lds_total = (int)kLdsHalf;
         launch_frame_lean(c, a, NA, s);

@@ -31,9 +31,38 @@ namespace {
 struct LeanHdr {                          // the build's scan scratch and flags: the last bytes of the launch's LDS (dead before the loop)
     int wave_sum[16];
     int fail;
-    int rowmax;
+    int box[2][4];                        // per kernel: min u, min -u, min v, min -v over the frame's vertices (see phase A)
 };
 constexpr int kLeanHdrBytes = 128;
+static_assert(sizeof(LeanHdr) <= kLeanHdrBytes, "header");
+constexpr int kGridMaxCoord = 32000;      // key coordinates beyond this may have wrapped in the reference's int16 keys: not this kernel's case
+constexpr int kGridMaxCells = 32768;      // cells of the id map (u16 ids; what fits beside the other scratch is checked per frame)
+
+// minimum over the 64 lanes of a wavefront, valid in lane 63 (DPP: inside each row of 16 lanes, then across the rows as wave_incl_scan)
+__device__ __forceinline__ int wave_min(int x)
+{
+    x = min(x, __builtin_amdgcn_update_dpp(x, x, 0x111, 0xf, 0xf, false));
+    x = min(x, __builtin_amdgcn_update_dpp(x, x, 0x112, 0xf, 0xf, false));
+    x = min(x, __builtin_amdgcn_update_dpp(x, x, 0x114, 0xf, 0xf, false));
+    x = min(x, __builtin_amdgcn_update_dpp(x, x, 0x118, 0xf, 0xf, false));
+    x = min(x, __builtin_amdgcn_update_dpp(x, x, 0x142, 0xa, 0xf, false));
+    x = min(x, __builtin_amdgcn_update_dpp(x, x, 0x143, 0xc, 0xf, false));
+    return x;
+}
+
+// A kernel argument read where it is first needed, not at the kernel's entry: the arguments are ~70 scalar registers' worth, the compiler
+// loads them up front in wide blocks and keeps what is used late -- weights, iteration count, output pointers -- alive through the
+// build, which then spills scalar registers (and every scalar spill costs the whole kernel a vector register, which the loop of
+// fused_lean.h does not have at 4 points per lane).  The late reads go through an opaque copy of the argument segment's address.
+template <class T>
+__device__ __forceinline__ const T &late_args(int offset)
+{
+    typedef const __attribute__((address_space(4))) unsigned char *kptr;
+    kptr p = (kptr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return *(const T *)(p + offset);
+}
+constexpr int kArgOffA = (int)((sizeof(CrfDev) + alignof(FrameArgs) - 1) / alignof(FrameArgs) * alignof(FrameArgs));
 
 template <int PPT>
 __global__ void __launch_bounds__(kNTSmall, 4) k_frame_lean(CrfDev c, FrameArgs a)
@@ -67,42 +96,48 @@ __global__ void __launch_bounds__(kNTSmall, 4) k_frame_lean(CrfDev c, FrameArgs 
         return;
     }
     const int Npad = (N + 3) & ~3;                       // blocks of four, permutohedral_cpu.h:294 (quirk Q1)
-    const int hdr_off = a.lds_total - kLeanHdrBytes;
+    constexpr int kLds = (int)kLdsHalf;                   // the launch's LDS (compile time: every offset below the header is a constant)
+    constexpr int hdr_off = kLds - kLeanHdrBytes;
     LeanHdr *hdr = reinterpret_cast<LeanHdr *>(smem + hdr_off);
-    const int hcap = a.hcap;
-    const unsigned mask = (unsigned)hcap - 1u;
-    const int hk_off = hdr_off - hcap * 4, ido_off = hk_off - hcap * 2;
-    unsigned *hk = reinterpret_cast<unsigned *>(smem + hk_off);                  // hash table: the keys themselves
-    unsigned short *ido = reinterpret_cast<unsigned short *>(smem + ido_off);    // slot -> vertex id
 
-    // unary energies from the labels (densecrf3d.h:116-129 with L = 2) go straight to the batch's array: the loop re-reads them
-    if (a.label) {
+    // this frame's record block: what the loop re-reads every iteration (one buffer resource, compile-time offsets)
+    unsigned char *rec = a.rec + (size_t)f * kLeanRecBytes;
+    // unary energies: from the labels (densecrf3d.h:116-129 with L = 2), or the caller's
 #pragma unroll
-        for (int s = 0; s < PPT; ++s) {
-            const int i = tid + s * NT;
-            if (i < N) {
+    for (int s = 0; s < PPT; ++s) {
+        const int i = tid + s * NT;
+        if (i < N) {
+            float2 un;
+            if (a.label) {
                 const int t = a.label[(size_t)f * a.maxN + i];
                 const bool known = t >= 0 && t < 2;
-                float2 un;
                 un.x = !known ? a.tbl[0] : (t == 0 ? a.tbl[3] : a.tbl[1 + t]);
                 un.y = !known ? a.tbl[0] : (t == 1 ? a.tbl[4] : a.tbl[1 + t]);
-                reinterpret_cast<float2 *>(c.unary)[(size_t)f * c.maxN + i] = un;
+            } else {
+                un = reinterpret_cast<const float2 *>(c.unary)[(size_t)f * c.maxN + i];
             }
+            reinterpret_cast<float2 *>(rec + kLeanRecUnary)[i] = un;
         }
     }
     if (tid < 32) reinterpret_cast<float *>(smem)[tid] = 0.0f;       // LDS bytes [0, 128) of the loop's plan are zeros
-    if (tid == 0) { hdr->fail = 0; hdr->rowmax = 0; }
+    if (tid < 8) hdr->box[tid >> 2][tid & 3] = 0x7fffffff;
+    if (tid == 0) hdr->fail = 0;
+    __syncthreads();
 
-    FusedLayout lay{};
     size_t plan = 128;                    // the loop's plan, kernel after kernel (fused_lean.h: layout_lean)
-    int V[K], row0max = 0;
+    int V[K];
     unsigned pk[PPT][K][D1];              // (vertex id + 1) | place in the row << 16, as the HBM records of k_fused
 
     // ---- one kernel's lattice: false = the frame does not fit (uniform) ---------------------------------------------------
     auto build = [&](auto kc) -> bool {
         constexpr int k = decltype(kc)::value;
-        // A: point records (elevate, round, rank, barycentric) and the keys of their three corners
-        unsigned key[PPT][D1];
+        // A: point records (elevate, round, rank, barycentric); every corner's vertex as a CELL of a grid over the frame's key range.
+        // A 2-D key is (x, y) with x = y (mod 3) (permutohedral_cpu.h:274-279,373: remainder-0 point + canonical offset): u = (x - y) / 3,
+        // v = y is a bijection onto Z^2, and a blur neighbour along axis j (key -+ 1, coordinate j +- 2, permutohedral_cpu.h:408-421)
+        // is the cell at -+ (-1, +1), (+1, -2), (0, +1).  No hash table: a vertex is found by its cell's index, a neighbour by an offset.
+        unsigned cell[PPT][D1];                           // first (u & 0xffff) | v << 16, then the cell index
+        int umin = 0x7fffffff, umax = -0x7fffffff, vmin = 0x7fffffff, vmax = -0x7fffffff;
+        bool bad = false;
 #pragma unroll
         for (int s = 0; s < PPT; ++s) {
             const int i = tid + s * NT;
@@ -113,72 +148,84 @@ __global__ void __launch_bounds__(kNTSmall, 4) k_frame_lean(CrfDev c, FrameArgs 
             float b[D1];
             point_record<2>(feat, a.scale, a.inv_dp1, r0, rk, b);
             if (i < N) {
-                float *bo = a.bary_out[k] + (size_t)f * a.Epad + (size_t)i * D1;
+                float *bo = reinterpret_cast<float *>(rec + kLeanRecBary + k * (kLeanRecPoints * D1 * 4)) + i * D1;
 #pragma unroll
                 for (int j = 0; j < D1; ++j) bo[j] = b[j];
             }
 #pragma unroll
-            for (int j = 0; j < D1; ++j) key[s][j] = corner_key(r0, rk, j);
+            for (int j = 0; j < D1; ++j) {
+                const int x = vertex_coord<2>(r0[0], rk[0], j), y = vertex_coord<2>(r0[1], rk[1], j);
+                const int u = (x - y) / 3;
+                bad |= x <= -kGridMaxCoord || x >= kGridMaxCoord || y <= -kGridMaxCoord || y >= kGridMaxCoord;   // (int16 keys that may have wrapped: the other paths)
+                if (i < Npad) {
+                    umin = min(umin, u); umax = max(umax, u);
+                    vmin = min(vmin, y); vmax = max(vmax, y);
+                }
+                cell[s][j] = ((unsigned)u & 0xffffu) | ((unsigned)y << 16);
+            }
         }
-        for (int u = tid; u < hcap; u += NT) hk[u] = kEmptyKey;
+        {
+            // the frame's key range: wavefront minima / maxima by DPP (as wave_incl_scan), one LDS atomic per wavefront and bound
+            const int lo_u = wave_min(umin), hi_u = wave_min(-umax), lo_v = wave_min(vmin), hi_v = wave_min(-vmax);
+            if ((tid & 63) == 63) {
+                atomicMin(&hdr->box[k][0], lo_u);
+                atomicMin(&hdr->box[k][1], hi_u);
+                atomicMin(&hdr->box[k][2], lo_v);
+                atomicMin(&hdr->box[k][3], hi_v);
+            }
+            if (bad) hdr->fail = 1;
+        }
+        __syncthreads();
+        FL_PSTAMP();
+        const int u0 = __builtin_amdgcn_readfirstlane(hdr->box[k][0]) - 1, v0 = __builtin_amdgcn_readfirstlane(hdr->box[k][2]) - 2;   // (an empty border:
+        const int Wp = -__builtin_amdgcn_readfirstlane(hdr->box[k][1]) - u0 + 2, Hp = -__builtin_amdgcn_readfirstlane(hdr->box[k][3]) - v0 + 3;   //  no bounds checks)
+        const long cells_l = (long)Wp * Hp;
+        // (readfirstlane: an exit the compiler cannot prove uniform makes everything merged behind it -- V, the loop's plan -- a vector value)
+        if (__builtin_amdgcn_readfirstlane(hdr->fail) || cells_l > kGridMaxCells) return false;
+        const int cells = (int)cells_l, chunks = (cells + 7) >> 3;      // 8 cells (16 bytes of ids) per chunk
+        const int idmap_off = hdr_off - chunks * 16;      // u16 per cell: 0 = no vertex, else id + 1.  At the end of LDS, dead after D.
+        unsigned short *idmap = reinterpret_cast<unsigned short *>(smem + idmap_off);
+        if (idmap_off < (int)plan + 64) return false;
+        for (int u = tid; u < chunks; u += NT) reinterpret_cast<uint4 *>(idmap)[u] = make_uint4(0u, 0u, 0u, 0u);
+        __syncthreads();
+        // B: mark the cells that hold a vertex (phantom points of the last block of four included, quirk Q1)
+#pragma unroll
+        for (int s = 0; s < PPT; ++s)
+#pragma unroll
+            for (int j = 0; j < D1; ++j) {
+                const int u = (int)(short)(cell[s][j] & 0xffffu), v = (int)cell[s][j] >> 16;
+                cell[s][j] = (unsigned)((u - u0) * Hp + (v - v0));
+                if (tid + s * NT < Npad) idmap[cell[s][j]] = (unsigned short)1;
+            }
         __syncthreads();
         FL_PSTAMP();
 
-        // B: insert (ds_cmpst claims an empty slot for the key or returns the key that lives there; frame_engine.hip phase B)
-        unsigned slot[PPT][D1], got[PPT][D1];
-        bool bad = false;
-#pragma unroll
-        for (int s = 0; s < PPT; ++s)
-#pragma unroll
-            for (int j = 0; j < D1; ++j) {
-                slot[s][j] = hash32(key[s][j]) & mask;
-                got[s][j] = key[s][j];
-                bad |= key[s][j] == kEmptyKey;
-                if (tid + s * NT < Npad) got[s][j] = atomicCAS(&hk[slot[s][j]], kEmptyKey, key[s][j]);
+        // C: dense vertex ids in cell order: every lane counts the marked cells of its run of chunks, a scan over the lanes, then the
+        //    marks become ids.  This kernel's tables in the loop's plan, the scratch by lifetime:
+        //      up to the end of D   the id map (end of LDS), vertex -> cell, counters
+        //      from the end of D    counters, row starts, row bitmap + prefixes or entry lists (over the dead id map)
+        const int cpl = (chunks + NT - 1) / NT, c0 = tid * cpl;
+        int mine = 0;
+        for (int q = 0; q < cpl; ++q) {
+            if (c0 + q < chunks) {
+                const uint4 w = reinterpret_cast<const uint4 *>(idmap)[c0 + q];
+                mine += __popc(w.x) + __popc(w.y) + __popc(w.z) + __popc(w.w);      // (marks are 0 / 1 per half)
             }
-        int ncreated = 0;
-#pragma unroll
-        for (int s = 0; s < PPT; ++s)
-#pragma unroll
-            for (int j = 0; j < D1; ++j) {
-                const unsigned kk = key[s][j];
-                if (got[s][j] != kEmptyKey && got[s][j] != kk) {           // somebody else's key lives there: linear probing
-                    unsigned h = slot[s][j];
-                    for (int probes = 0;; ++probes) {
-                        h = (h + 1u) & mask;
-                        got[s][j] = atomicCAS(&hk[h], kEmptyKey, kk);
-                        if (got[s][j] == kEmptyKey || got[s][j] == kk) break;
-                        if (probes >= hcap) { bad = true; break; }
-                    }
-                    slot[s][j] = h;
-                }
-                ncreated += got[s][j] == kEmptyKey;
-            }
-        if (bad) hdr->fail = 1;
-        FL_PSTAMP();
-
-        // C: dense vertex ids for the entries that created their vertex; this kernel's tables in the loop's plan, the scratch by lifetime:
-        //      up to the end of D   hash table (end of LDS), vertex keys, counters, [kernel 1: neighbour table -- exported at the end of D]
-        //      from the end of D    counters, row starts, row bitmap + prefixes or entry lists (over the dead hash table)
+        }
         int Vk;
-        int id = block_excl_scan<NT>(ncreated, tid, hdr->wave_sum, Vk);       // (its barriers also close phase B)
+        int id = block_excl_scan<NT>(mine, tid, hdr->wave_sum, Vk);
         V[k] = Vk;
         FL_PSTAMP();
         if (Vk > lean_max_v(NT) || (k == 0 && (Vk > chain_max_v(NT) || Vk > 256))) return false;
         const int plan_before = (int)plan;
         const LeanTables lt = lean_tables(plan, Vk, k == 0);
-        lay.val[k][0] = lt.val0;
-        lay.val[k][1] = lt.val1;
-        lay.nbr[k] = lt.nbr;
-        lay.row[k] = lt.row;
         auto take = [&](int &o, int bytes) { const int r = o; o += (bytes + 15) & ~15; return r; };
-        // (kernel 1's scratch starts at the end of kernel 0's tables: its value arrays are not in use before the loop, and its row starts --
-        //  inside or right behind the scratch table -- are written in E, after the export)
+        // (kernel 1's scratch starts at the end of kernel 0's tables: its value arrays are not in use before the loop; its row starts are
+        //  written in E)
         int vs = k == 0 ? (int)plan : plan_before;
-        const int vkey_off = take(vs, Vk * 4);
-        const int cnt_off = take(vs, (Vk + 1) * 4);      // arrival counters (short rows), then start | length of every row list
-        const int nbs_off = k == 0 ? lt.nbr : take(vs, D1 * Vk * 4);
-        const int vs_d = vs;                              // end of what lives beside the hash table
+        const int vcell_off = take(vs, Vk * 2);           // vertex -> cell
+        const int cnt_off = take(vs, (Vk + 1) * 4);       // arrival counters (short rows), then start | length of every row list
+        const int vs_d = vs;                              // end of what lives beside the id map
         if (k != 0) vs = max(vs, (int)plan);
         const int E = N * D1;
         const int W = (((Npad + 31) >> 5) + 3) & ~3;      // bitmap words per vertex, a multiple of 4
@@ -187,26 +234,28 @@ __global__ void __launch_bounds__(kNTSmall, 4) k_frame_lean(CrfDev c, FrameArgs 
         const int list_cap = (E + 7 * Vk + 8) & ~7;       // short rows: u16 entry lists, rows padded to 8
         const int list_off = vs;
         const int vs_end = bitmap ? pre_off + Vk * W / 2 : list_off + list_cap * 2;
-        if (vs_d > ido_off || vs_end > hdr_off || Vk >= 32767 || E + 7 * Vk >= 65535 || hdr->fail) return false;
-        unsigned *vkey = reinterpret_cast<unsigned *>(smem + vkey_off);
+        if (vs_d > idmap_off || (k != 0 && (int)plan > idmap_off) || vs_end > hdr_off || Vk >= 32767 || E + 7 * Vk >= 65535) return false;
+        unsigned short *vcell = reinterpret_cast<unsigned short *>(smem + vcell_off);
         unsigned *cnt = reinterpret_cast<unsigned *>(smem + cnt_off);
         unsigned *bm = reinterpret_cast<unsigned *>(smem + bm_off);
         unsigned short *pre = reinterpret_cast<unsigned short *>(smem + pre_off);
         unsigned short *list = reinterpret_cast<unsigned short *>(smem + list_off);
+        for (int q = 0; q < cpl; ++q) {
+            if (c0 + q < chunks) {
+                uint4 w = reinterpret_cast<const uint4 *>(idmap)[c0 + q];
+                unsigned h[8] = {w.x & 0xffffu, w.x >> 16, w.y & 0xffffu, w.y >> 16, w.z & 0xffffu, w.z >> 16, w.w & 0xffffu, w.w >> 16};
 #pragma unroll
-        for (int s = 0; s < PPT; ++s)
-#pragma unroll
-            for (int j = 0; j < D1; ++j)
-                if (got[s][j] == kEmptyKey) {
-                    ido[slot[s][j]] = (unsigned short)id;
-                    vkey[id] = key[s][j];
-                    ++id;
+                for (int e = 0; e < 8; ++e) {
+                    if (h[e]) {
+                        vcell[id] = (unsigned short)((c0 + q) * 8 + e);
+                        h[e] = (unsigned)++id;
+                    }
                 }
-        for (int v = tid; v <= Vk; v += NT) cnt[v] = 0u;
-        {
-            unsigned *nbz = reinterpret_cast<unsigned *>(smem + nbs_off);   // absent neighbours stay 0
-            for (int u = tid; u < D1 * Vk; u += NT) nbz[u] = 0u;
+                w = make_uint4(h[0] | h[1] << 16, h[2] | h[3] << 16, h[4] | h[5] << 16, h[6] | h[7] << 16);
+                reinterpret_cast<uint4 *>(idmap)[c0 + q] = w;
+            }
         }
+        for (int v = tid; v <= Vk; v += NT) cnt[v] = 0u;
         __syncthreads();
         FL_PSTAMP();
 
@@ -215,7 +264,7 @@ __global__ void __launch_bounds__(kNTSmall, 4) k_frame_lean(CrfDev c, FrameArgs 
 #pragma unroll
         for (int s = 0; s < PPT; ++s)
 #pragma unroll
-            for (int j = 0; j < D1; ++j) vid[s][j] = (tid + s * NT < Npad) ? (unsigned)ido[slot[s][j]] : 0u;
+            for (int j = 0; j < D1; ++j) vid[s][j] = (tid + s * NT < Npad) ? (unsigned)idmap[cell[s][j]] - 1u : 0u;
 #pragma unroll
         for (int s = 0; s < PPT; ++s) {
 #pragma unroll
@@ -225,36 +274,20 @@ __global__ void __launch_bounds__(kNTSmall, 4) k_frame_lean(CrfDev c, FrameArgs 
             }
         }
         {
-            // permutohedral_cpu.h:408-421 with d = 2, one probe per (axis, vertex) fills both halves (frame_engine.hip phase D)
-            unsigned short *nb16 = reinterpret_cast<unsigned short *>(smem + nbs_off);   // [axis][vertex][n1+1, n2+1]
+            // (n1 + 1) | (n2 + 1) << 16 per (axis, vertex), 0 = absent: the ids of the two cells at -+ the axis' offset.  The appearance
+            // lattice's table stays in LDS (the loop's plan), the smoothness lattice's goes to HBM (the loop reads it pass by pass).
+            unsigned *tbl = reinterpret_cast<unsigned *>(smem + (k == 0 ? lt.nbr : 0));
+            unsigned *out = reinterpret_cast<unsigned *>(rec + kLeanRecNbr);
             for (int t = tid; t < D1 * Vk; t += NT) {
                 const int j = t >= 2 * Vk ? 2 : (t >= Vk ? 1 : 0), v = t - j * Vk;
-                const unsigned kk = vkey[v];
-                const unsigned qx = ((kk & 0xffffu) + (j == 0 ? 0xfffeu : 1u)) & 0xffffu, qy = ((kk >> 16) + (j == 1 ? 0xfffeu : 1u)) & 0xffffu;
-                const unsigned q = qx | (qy << 16);
-                unsigned h = hash32(q) & mask;
-                unsigned o = hk[h];
-                for (int probes = 0; o != kEmptyKey && o != q && probes < hcap; ++probes) {
-                    h = (h + 1u) & mask;
-                    o = hk[h];
-                }
-                if (o == q) {
-                    const unsigned b = ido[h];
-                    nb16[2 * t + 1] = (unsigned short)(b + 1u);                       // my n2
-                    nb16[2 * (j * Vk + (int)b)] = (unsigned short)(v + 1);          // its n1
-                }
+                const int c = vcell[v], dj = j == 0 ? 1 - Hp : (j == 1 ? Hp - 2 : 1);
+                const unsigned word = (unsigned)idmap[c - dj] | ((unsigned)idmap[c + dj] << 16);
+                if (k == 0) tbl[t] = word;
+                else out[j * (kLeanRecNbrAxis / 4) + v] = word;
             }
         }
-        __syncthreads();                                  // the hash table, the slot ids and the vertex keys are dead
+        __syncthreads();                                  // the id map and the vertices' cells are dead
         FL_PSTAMP();
-        if (k != 0) {                                     // the smoothness lattice's table: to HBM (the loop reads it pass by pass)
-            const unsigned *nbs = reinterpret_cast<const unsigned *>(smem + nbs_off);
-            unsigned *out = a.nbr_out[k] + (size_t)f * D1 * a.Epad;
-            for (int u = tid; u < D1 * Vk; u += NT) {
-                const int j = u >= 2 * Vk ? 2 : (u >= Vk ? 1 : 0);
-                out[(size_t)j * a.Epad + (u - j * Vk)] = nbs[u];
-            }
-        }
         if (bitmap) {
             uint4 *b4 = reinterpret_cast<uint4 *>(bm);
             for (int u = tid; u < Vk * W / 4; u += NT) b4[u] = make_uint4(0u, 0u, 0u, 0u);
@@ -310,13 +343,11 @@ __global__ void __launch_bounds__(kNTSmall, 4) k_frame_lean(CrfDev c, FrameArgs 
             // packed scan: low half = products before the row, high half = padded list entries before it
             const int vper = (Vk + 1 + NT - 1) / NT, v0 = tid * vper;
             unsigned sum = 0u;
-            int mx = 0;
             for (int u = 0; u < vper; ++u) {
                 const int v = v0 + u;
                 if (v < Vk) {
                     const unsigned n = cnt[v];
                     sum += n | (((n + 7u) & ~7u) << 16);
-                    mx = max(mx, (int)n);
                 }
             }
             int tot;
@@ -329,11 +360,6 @@ __global__ void __launch_bounds__(kNTSmall, 4) k_frame_lean(CrfDev c, FrameArgs 
                     cnt[v] = (run >> 16) | (n << 16);      // list start | row length
                     run += n | (((n + 7u) & ~7u) << 16);
                 }
-            }
-            if (k == 0) {                                 // longest row of kernel 0 decides the chain path
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o, 64));
-                if ((tid & 63) == 0 && mx > 0) atomicMax(&hdr->rowmax, mx);
             }
         }
         __syncthreads();
@@ -383,7 +409,6 @@ __global__ void __launch_bounds__(kNTSmall, 4) k_frame_lean(CrfDev c, FrameArgs 
                 pk[s][k][j] = (v + 1u) | (((unsigned)row[v] + (real ? r : 0u)) << 16);
             }
         }
-        if (k == 0) row0max = hdr->rowmax;
         FL_PSTAMP();
         __syncthreads();                                  // the next kernel's build (or the loop's product buffer) reuses the scratch
         return true;
@@ -395,16 +420,17 @@ __global__ void __launch_bounds__(kNTSmall, 4) k_frame_lean(CrfDev c, FrameArgs 
     FL_STAMP();
 
     // ---- the loop's plan for THIS frame's sizes; the tables built above are already in their places ----------------------
+    FusedLayout lay;
+#pragma unroll
+    for (int k = 0; k < K; ++k) V[k] = __builtin_amdgcn_readfirstlane(V[k]);     // (scalar for sure: every offset of the plan derives from them)
     {
         // (kernel 0's rows go to the chain lanes however short they are -- a frame of a few points among full-size ones is not worth a
         //  second instance of the loop; its lattice is small enough for them, or the build has already left)
-        FusedLayout L;
-        if (!layout_lean(N, K, V, max(row0max, kChainMinRow), &L, NT, (size_t)a.lds_total) || !L.chain0 || L.row[0] != lay.row[0] ||
-            L.row[1] != lay.row[1] || L.nbr[0] != lay.nbr[0]) {
+        // (layout_lean carves with the same lean_tables calls in the same order: the tables built above ARE where it says)
+        if (!layout_lean(N, K, V, kChainMinRow, &lay, NT, (size_t)kLds) || !lay.chain0) {
             flag_unfit();
             return;
         }
-        lay = L;
     }
     if (tid == 0) {
 #pragma unroll
@@ -413,18 +439,23 @@ __global__ void __launch_bounds__(kNTSmall, 4) k_frame_lean(CrfDev c, FrameArgs 
             reinterpret_cast<float2 *>(smem + lay.val[k][1])[0] = make_float2(0.f, 0.f);
         }
     }
+    const FrameArgs &al = late_args<FrameArgs>(kArgOffA);
+    const CrfDev &cl_ = late_args<CrfDev>(0);
     float wk[K], alpha[K];
     LeanSrc src;
+    const __amdgpu_buffer_rsrc_t rsrc = lean_rsrc(rec, kLeanRecBytes);
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-        wk[k] = a.w[k];
-        alpha[k] = a.alpha;
-        src.nbr[k] = lean_rsrc(a.nbr_out[k] + (size_t)f * D1 * a.Epad, (size_t)D1 * a.Epad * 4);
-        src.bary[k] = lean_rsrc(a.bary_out[k] + (size_t)f * a.Epad, (size_t)a.Epad * 4);
-        src.norm[k] = lean_rsrc(a.norm_out[k] + (size_t)f * a.maxN, (size_t)a.maxN * 4);
-        src.nbr_axis_bytes[k] = a.Epad * 4;
+        wk[k] = al.w[k];
+        alpha[k] = al.alpha;
+        src.nbr[k] = src.bary[k] = src.norm[k] = rsrc;
+        src.off_nbr[k] = kLeanRecNbr;                     // (only the last kernel's table is there, and only that one is read)
+        src.off_bary[k] = kLeanRecBary + k * (kLeanRecPoints * D1 * 4);
+        src.off_norm[k] = kLeanRecNorm + k * (kLeanRecPoints * 4);
+        src.nbr_axis_bytes[k] = kLeanRecNbrAxis;
     }
-    src.unary = lean_rsrc(c.unary + (size_t)f * c.maxN * 2, (size_t)c.maxN * 8);
+    src.unary = rsrc;
+    src.off_unary = kLeanRecUnary;
     __syncthreads();                      // (also orders this workgroup's record stores before its loads: one CU, one path to L2)
 
     ChainLane cl = chain_setup_lean<NT>(smem, lay, V[0], tid);
@@ -444,17 +475,17 @@ __global__ void __launch_bounds__(kNTSmall, 4) k_frame_lean(CrfDev c, FrameArgs 
 #pragma unroll
     for (int s = 0; s < PPT; ++s) {
         typedef unsigned lean_u2 __attribute__((ext_vector_type(2)));
-        const lean_u2 u = __builtin_amdgcn_raw_buffer_load_b64(src.unary, (t + s * NT) * 8, 0, 0);
+        const lean_u2 u = __builtin_amdgcn_raw_buffer_load_b64(src.unary, (t + s * NT) * 8, src.off_unary, 0);
         pr.un[s] = make_float2(__uint_as_float(u.x), __uint_as_float(u.y));
     }
     start_inference<PPT, K, NT>(pr, N, t);
-    mean_field_lean<PPT, K, 1, NT, true, false>(smem, lay, V, N, t, pr, cl, alpha, wk, src, a.n_iter, a.relax, a.omr, ins);
+    mean_field_lean<PPT, K, 1, NT, true, false>(smem, lay, V, N, t, pr, cl, alpha, wk, src, al.n_iter, al.relax, al.omr, ins);
     t = lane_id();
-    store_results<PPT, K, NT>(c, f, N, t, pr, a.with_map);
-    if (t < K && a.V_out[t]) a.V_out[t][f] = t == 0 ? V[0] : V[K - 1];
-    if (t == 0 && a.frame_status) a.frame_status[f] = 0;
+    store_results<PPT, K, NT>(cl_, f, N, t, pr, al.with_map);
+    if (t < K && al.V_out[t]) al.V_out[t][f] = t == 0 ? V[0] : V[K - 1];
+    if (t == 0 && al.frame_status) al.frame_status[f] = 0;
     FL_STAMP();
-    if (kInstr && a.timing && (int)blockIdx.x == a.timing_block && t == a.timing_lane) a.timing[63] = ins.n;
+    if (kInstr && al.timing && (int)blockIdx.x == al.timing_block && t == al.timing_lane) al.timing[63] = ins.n;
 }
 
 template <int PPT>

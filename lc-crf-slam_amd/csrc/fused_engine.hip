@@ -223,8 +223,10 @@ __global__ void __launch_bounds__(NT, NT == 384 ? 3 : 4) k_fused_lean(CrfDev c, 
         src.bary[k] = lean_rsrc(gbary[k], (size_t)kd.Epad * 4);
         src.norm[k] = lean_rsrc(gnorm[k], (size_t)kd.maxN * 4);
         src.nbr_axis_bytes[k] = kd.Epad * 4;
+        src.off_nbr[k] = src.off_bary[k] = src.off_norm[k] = 0;
     }
     src.unary = lean_rsrc(c.unary + (size_t)f * c.maxN * 2, (size_t)c.maxN * 8);
+    src.off_unary = 0;
 #pragma unroll
     for (int s = 0; s < PPT; ++s) {
         const int ic = min(tid + s * NT, N - 1);

@@ -367,7 +367,19 @@ struct LeanSrc {
     __amdgpu_buffer_rsrc_t norm[kMaxFusedK];  // KernelDev::norm  [maxN]
     __amdgpu_buffer_rsrc_t unary;             // CrfDev::unary    [maxN][2]
     int nbr_axis_bytes[kMaxFusedK];           // Epad * 4
+    // byte offset of each array inside its resource: 0 when every array has a resource of its own (k_fused_lean); the one-launch frame
+    // kernel keeps a frame's records in ONE block behind one resource, at compile-time offsets (kLeanRec*) -- four scalar registers
+    // instead of twenty-four
+    int off_nbr[kMaxFusedK], off_bary[kMaxFusedK], off_norm[kMaxFusedK], off_unary;
 };
+// A frame's record block of the one-launch kernel (frame_lean.hip; frames of at most 4 * 512 points):
+constexpr int kLeanRecPoints = 4 * kNTSmall;
+constexpr int kLeanRecUnary = 0;                                                    // float2 [points]
+constexpr int kLeanRecBary = kLeanRecUnary + kLeanRecPoints * 8;                     // per kernel: float [points][3]
+constexpr int kLeanRecNorm = kLeanRecBary + kMaxFusedK * kLeanRecPoints * kD1 * 4;   // per kernel: float [points]
+constexpr int kLeanRecNbr = kLeanRecNorm + kMaxFusedK * kLeanRecPoints * 4;          // the LAST kernel's table: u32 [3][lean_max_v]
+constexpr int kLeanRecNbrAxis = lean_max_v(kNTSmall) * 4;
+constexpr int kLeanRecBytes = (kLeanRecNbr + kD1 * kLeanRecNbrAxis + 255) & ~255;
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t lean_rsrc(const void *p, size_t bytes)
 {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)bytes, 0x00020000);   // raw buffer, 32-bit data format (gfx9)
@@ -425,16 +437,16 @@ __device__ __forceinline__ void mean_field_lean(unsigned char *smem, const Fused
             const int i = t + s * NT;                   // (a lane without a point in this slot reads the slice's spare rows or 0: unused)
             if (!NORM) {
                 typedef unsigned lean_u2 __attribute__((ext_vector_type(2)));
-                const lean_u2 u = __builtin_amdgcn_raw_buffer_load_b64(src.unary, i * 8, 0, 0);
+                const lean_u2 u = __builtin_amdgcn_raw_buffer_load_b64(src.unary, i * 8, src.off_unary, 0);
                 pr.un[s] = make_float2(__uint_as_float(u.x), __uint_as_float(u.y));
             }
 #pragma unroll
             for (int k = 0; k < K; ++k) {
-                const lean_u3 b = __builtin_amdgcn_raw_buffer_load_b96(src.bary[k], i * (D1 * 4), 0, 0);
+                const lean_u3 b = __builtin_amdgcn_raw_buffer_load_b96(src.bary[k], i * (D1 * 4), src.off_bary[k], 0);
                 pr.bary[s][k][0] = __uint_as_float(b.x);
                 pr.bary[s][k][1] = __uint_as_float(b.y);
                 pr.bary[s][k][2] = __uint_as_float(b.z);
-                if (!NORM) pr.wn[s][k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(src.norm[k], i * 4, 0, 0));
+                if (!NORM) pr.wn[s][k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(src.norm[k], i * 4, src.off_norm[k], 0));
             }
         }
         if (NORM) return;
@@ -534,7 +546,7 @@ __device__ __forceinline__ void mean_field_lean(unsigned char *smem, const Fused
                 for (int r = 0; r < R; ++r) {
                     w[k][j][r] = 0;
                     if (!(CH == 1 && k == 0) && (r == 0 || r * NT < V[k]))      // (uniform; v >= V: an unused word of the table)
-                        w[k][j][r] = __builtin_amdgcn_raw_buffer_load_b32(src.nbr[k], (t + r * NT) * 4, j * src.nbr_axis_bytes[k], 0);
+                        w[k][j][r] = __builtin_amdgcn_raw_buffer_load_b32(src.nbr[k], (t + r * NT) * 4, src.off_nbr[k] + j * src.nbr_axis_bytes[k], 0);
                 }
             }
         }
@@ -575,7 +587,7 @@ __device__ __forceinline__ void mean_field_lean(unsigned char *smem, const Fused
         for (int r = 0; r < RA; ++r) {
             wa[r] = 0;
             if (r == 0 || r * NA0 < V[K - 1])
-                wa[r] = __builtin_amdgcn_raw_buffer_load_b32(src.nbr[K - 1], (t - 128 + r * NA0) * 4, 0, 0);      // (lanes < 128: out of range reads 0, unused)
+                wa[r] = __builtin_amdgcn_raw_buffer_load_b32(src.nbr[K - 1], (t - 128 + r * NA0) * 4, src.off_nbr[K - 1], 0);      // (lanes < 128: out of range reads 0, unused)
         }
 #pragma unroll
         for (int j = 1; j < D1; ++j) {
@@ -583,7 +595,7 @@ __device__ __forceinline__ void mean_field_lean(unsigned char *smem, const Fused
             for (int r = 0; r < RB; ++r) {
                 wb[j - 1][r] = 0;
                 if (r == 0 || r * NB < V[K - 1])
-                    wb[j - 1][r] = __builtin_amdgcn_raw_buffer_load_b32(src.nbr[K - 1], (t + r * NB) * 4, j * src.nbr_axis_bytes[K - 1], 0);
+                    wb[j - 1][r] = __builtin_amdgcn_raw_buffer_load_b32(src.nbr[K - 1], (t + r * NB) * 4, src.off_nbr[K - 1] + j * src.nbr_axis_bytes[K - 1], 0);
             }
         }
     };
@@ -625,7 +637,7 @@ __device__ __forceinline__ void mean_field_lean(unsigned char *smem, const Fused
 #pragma unroll
             for (int k = 0; k < K; ++k) {
                 const float v = slice_point_lean(pr, s, k, alpha[k]).x;
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(1.0f / (v + 1e-20f)), src.norm[k], (t + s * NT) * 4, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(1.0f / (v + 1e-20f)), src.norm[k], (t + s * NT) * 4, src.off_norm[k], 0);
             }
             return;
         }
