@@ -866,8 +866,9 @@ int launch_frame(const CrfDev &c, const KernelDev *kds, int n_iter, int with_map
     // Full-size frames (1025 .. 2048 points, the two-kernel SLAM configuration): 512 lanes and half the CU's LDS per frame as well
     // (frame_lean.hip) -- flagged frames and the engine's give-up rule as for the small shape.
     static const bool no_lean = ab_env("LCCRF_NO_FRAME_LEAN") != nullptr;  // A/B switch: same results either way
-    const bool lean = lean_rec && !no_lean && !small && frame_lean_plausible(NA, c.K, c.F);
+    const bool lean = lean_rec && !no_lean && frame_lean_plausible(NA, c.K, c.F);
     if (lean) {
+        small = false;
         a.lds_total = (int)kLdsHalf;
         launch_frame_lean(c, a, NA, s);
     } else if (dual && !no_dual && c.K == 2 && !small) {                           // a frame alone: two workgroups, one per lattice build

@@ -68,6 +68,7 @@ template <int PPT>
 __global__ void __launch_bounds__(kNTSmall, 4) k_frame_lean(CrfDev c, FrameArgs a)
 {
     constexpr int NT = kNTSmall, K = 2, D1 = kD1;
+    constexpr bool RELOAD = PPT >= 3;     // (1-2 points per lane: weights, norms and unary energies stay in registers, fused_lean.h)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int f = blockIdx.x, tid = threadIdx.x;
     const int N = c.n_points[f];
@@ -102,6 +103,7 @@ __global__ void __launch_bounds__(kNTSmall, 4) k_frame_lean(CrfDev c, FrameArgs 
 
     // this frame's record block: what the loop re-reads every iteration (one buffer resource, compile-time offsets)
     unsigned char *rec = a.rec + (size_t)f * kLeanRecBytes;
+    PointRegs<PPT, K> pr;
     // unary energies: from the labels (densecrf3d.h:116-129 with L = 2), or the caller's
 #pragma unroll
     for (int s = 0; s < PPT; ++s) {
@@ -116,7 +118,8 @@ __global__ void __launch_bounds__(kNTSmall, 4) k_frame_lean(CrfDev c, FrameArgs 
             } else {
                 un = reinterpret_cast<const float2 *>(c.unary)[(size_t)f * c.maxN + i];
             }
-            reinterpret_cast<float2 *>(rec + kLeanRecUnary)[i] = un;
+            if (RELOAD) reinterpret_cast<float2 *>(rec + kLeanRecUnary)[i] = un;
+            else pr.un[s] = un;
         }
     }
     if (tid < 32) reinterpret_cast<float *>(smem)[tid] = 0.0f;       // LDS bytes [0, 128) of the loop's plan are zeros
@@ -147,7 +150,10 @@ __global__ void __launch_bounds__(kNTSmall, 4) k_frame_lean(CrfDev c, FrameArgs 
             uint8_t rk[2];
             float b[D1];
             point_record<2>(feat, a.scale, a.inv_dp1, r0, rk, b);
-            if (i < N) {
+            if (!RELOAD) {
+#pragma unroll
+                for (int j = 0; j < D1; ++j) pr.bary[s][k][j] = b[j];
+            } else if (i < N) {
                 float *bo = reinterpret_cast<float *>(rec + kLeanRecBary + k * (kLeanRecPoints * D1 * 4)) + i * D1;
 #pragma unroll
                 for (int j = 0; j < D1; ++j) bo[j] = b[j];
@@ -459,7 +465,6 @@ __global__ void __launch_bounds__(kNTSmall, 4) k_frame_lean(CrfDev c, FrameArgs 
     __syncthreads();                      // (also orders this workgroup's record stores before its loads: one CU, one path to L2)
 
     ChainLane cl = chain_setup_lean<NT>(smem, lay, V[0], tid);
-    PointRegs<PPT, K> pr;
     place_products_lean<PPT, K, 1, NT>(smem, lay, N, tid, pk, pr);
     FL_STAMP();
 
@@ -467,19 +472,21 @@ __global__ void __launch_bounds__(kNTSmall, 4) k_frame_lean(CrfDev c, FrameArgs 
 #pragma unroll
     for (int s = 0; s < PPT; ++s) pr.q[s] = make_float2(1.0f, 1.0f);
     int t = lane_id();
-    mean_field_lean<PPT, K, 1, NT, true, true>(smem, lay, V, N, t, pr, cl, alpha, wk, src, 1, 0.0f, 0.0f, ins);
+    mean_field_lean<PPT, K, 1, NT, RELOAD, true>(smem, lay, V, N, t, pr, cl, alpha, wk, src, 1, 0.0f, 0.0f, ins);
     __syncthreads();
     FL_STAMP();
 
     t = lane_id();
+    if (RELOAD) {
 #pragma unroll
-    for (int s = 0; s < PPT; ++s) {
-        typedef unsigned lean_u2 __attribute__((ext_vector_type(2)));
-        const lean_u2 u = __builtin_amdgcn_raw_buffer_load_b64(src.unary, (t + s * NT) * 8, src.off_unary, 0);
-        pr.un[s] = make_float2(__uint_as_float(u.x), __uint_as_float(u.y));
+        for (int s = 0; s < PPT; ++s) {
+            typedef unsigned lean_u2 __attribute__((ext_vector_type(2)));
+            const lean_u2 u = __builtin_amdgcn_raw_buffer_load_b64(src.unary, (t + s * NT) * 8, src.off_unary, 0);
+            pr.un[s] = make_float2(__uint_as_float(u.x), __uint_as_float(u.y));
+        }
     }
     start_inference<PPT, K, NT>(pr, N, t);
-    mean_field_lean<PPT, K, 1, NT, true, false>(smem, lay, V, N, t, pr, cl, alpha, wk, src, al.n_iter, al.relax, al.omr, ins);
+    mean_field_lean<PPT, K, 1, NT, RELOAD, false>(smem, lay, V, N, t, pr, cl, alpha, wk, src, al.n_iter, al.relax, al.omr, ins);
     t = lane_id();
     store_results<PPT, K, NT>(cl_, f, N, t, pr, al.with_map);
     if (t < K && al.V_out[t]) al.V_out[t][f] = t == 0 ? V[0] : V[K - 1];
@@ -501,9 +508,12 @@ void launch_lean_ppt(const CrfDev &c, const FrameArgs &a, hipStream_t s)
 // Is the half-CU form worth asking for?  Frames of NA points with lattices of the usual SLAM proportions (frame_engine.hip: an appearance
 // kernel of ~112 vertices, a smoothness kernel of min(NA + 350, 1150)) must fit the loop's plan; frames with larger lattices flag
 // themselves and are re-run, and an engine that sees more than 1/8 of a batch flagged stops asking.
+#ifndef LCCRF_FRAME_LEAN_MIN_POINTS
+#define LCCRF_FRAME_LEAN_MIN_POINTS 0                 // A/B (scripts/gpu_ab_build.sh): batches of larger frames than this take the kernel (C1 +12 %, N500 +10 % against k_frame<512>)
+#endif
 bool frame_lean_plausible(int NA, int K, int F)
 {
-    if (K != 2 || F < kSmallMinFrames || NA <= 2 * kNTSmall || NA > 4 * kNTSmall) return false;
+    if (K != 2 || F < kSmallMinFrames || NA <= LCCRF_FRAME_LEAN_MIN_POINTS || NA > 4 * kNTSmall) return false;
     const int vest[2] = {112, std::min(NA + 350, 1150)};
     FusedLayout est;
     return layout_lean(NA, K, vest, kChainMinRow, &est, kNTSmall, kLdsHalf);
@@ -511,7 +521,9 @@ bool frame_lean_plausible(int NA, int K, int F)
 
 void launch_frame_lean(const CrfDev &c, const FrameArgs &a, int NA, hipStream_t s)
 {
-    if (NA <= 3 * kNTSmall) launch_lean_ppt<3>(c, a, s);
+    if (NA <= kNTSmall) launch_lean_ppt<1>(c, a, s);
+    else if (NA <= 2 * kNTSmall) launch_lean_ppt<2>(c, a, s);
+    else if (NA <= 3 * kNTSmall) launch_lean_ppt<3>(c, a, s);
     else launch_lean_ppt<4>(c, a, s);
 }
 

@@ -401,7 +401,7 @@ __device__ __forceinline__ void opaque_ids(PointRegs<PPT, K> &pr)
 // RELOAD: the unary energies, barycentric weights and norms are not kept in registers across the iteration -- every X re-reads this
 // lane's (L2-resident) records; what a lane holds between iterations is Q and the packed ids / slots (8 registers per point).
 // NORM (the one-launch frame kernel): ONE pass that leaves every kernel's norm = 1 / (K * 1 + 1e-20) (pairwise3d.h:20-28) in src.norm
-// instead of updating Q -- the caller sets Q = 1; the same splat / row sums / blur / slice as an iteration's, phase by phase.
+// (RELOAD; else w * norm in pr.wn) instead of updating Q -- the caller sets Q = 1; the same splat / row sums / blur / slice as an iteration's, phase by phase.
 template <int PPT, int K, int CH, int NT, bool RELOAD, bool NORM = false>
 __device__ __forceinline__ void mean_field_lean(unsigned char *smem, const FusedLayout &lay, const int (&V)[K], int N, int &t,
                                                 PointRegs<PPT, K> &pr, ChainLane &cl, const float (&alpha)[K],
@@ -429,7 +429,6 @@ __device__ __forceinline__ void mean_field_lean(unsigned char *smem, const Fused
 #else
 #define LEAN_FRESH_T() asm volatile("" : "+v"(t))
 #endif
-    static_assert(!NORM || RELOAD, "the normalisation pass is built for the re-reading shapes only");
     auto load_weights = [&]() {
         if (!RELOAD) return;
 #pragma unroll
@@ -637,7 +636,9 @@ __device__ __forceinline__ void mean_field_lean(unsigned char *smem, const Fused
 #pragma unroll
             for (int k = 0; k < K; ++k) {
                 const float v = slice_point_lean(pr, s, k, alpha[k]).x;
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(1.0f / (v + 1e-20f)), src.norm[k], (t + s * NT) * 4, src.off_norm[k], 0);
+                const float nrm = 1.0f / (v + 1e-20f);
+                if (RELOAD) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(nrm), src.norm[k], (t + s * NT) * 4, src.off_norm[k], 0);
+                else pr.wn[s][k] = wk[k] * nrm;                  // pairwise3d.h:77 (w_*norm_[i])
             }
             return;
         }

@@ -82,6 +82,20 @@ def test_frame_kernel_slam_variants_do_not_spill():
 
 
 @pytest.mark.skipif(shutil.which(HIPCC) is None, reason="hipcc not installed")
+def test_half_cu_frame_kernel_has_no_scratch_and_no_scalar_spills():
+    """Round 5 (csrc/frame_lean.hip): lattice build + normalisation + inference of a frame in 512 lanes on half a CU, 1 to 4 points
+    per lane.  128 registers per lane (two workgroups per CU), no scratch -- and no SCALAR spills either: one spilled scalar register
+    reserves a vector register for the whole kernel, which the loop at 4 points per lane does not have (the late kernel-argument
+    reads and the scalar plan of that file exist for this)."""
+    use = resource_usage("frame_lean.hip")
+    lean = {k: v for k, v in use.items() if "k_frame_leanI" in k}
+    assert len(lean) == 4                                     # PPT 1..4
+    for name, r in lean.items():
+        assert r["VGPRs"] + r.get("AGPRs", 0) <= 128, name
+        assert r["ScratchSize [bytes/lane]"] == 0 and r["VGPRs Spill"] == 0 and r["SGPRs Spill"] == 0, (name, r)
+
+
+@pytest.mark.skipif(shutil.which(HIPCC) is None, reason="hipcc not installed")
 def test_fused_build_does_not_spill_vector_registers():
     use = resource_usage("build_small.hip")
     build = {k: v for k, v in use.items() if "k_build_small" in k}
