@@ -17,15 +17,16 @@ namespace lccrf {
 //        rk[i]  = rank of coordinate i                                          (i < D)
 //        b[rem] = barycentric weight of the simplex corner with remainder `rem` (rem <= D)
 // ---------------------------------------------------------------------------------------
+// the enclosing simplex: el = the elevated point, rem0 = its remainder-0 vertex (all D+1 coordinates, as floats), rank = the rank of
+// every coordinate after the off-plane fix-up.  ref: permutohedral_cpu.h:304-345
 template <int D>
-__device__ __forceinline__ void point_record(const float (&feat)[D], const float *scale, float inv_dp1,
-                                             int16_t (&r0)[D], uint8_t (&rk)[D], float (&b)[D + 1])
+__device__ __forceinline__ void lattice_simplex(const float (&feat)[D], const float *scale, float inv_dp1, float (&el)[D + 1],
+                                                float (&rem0)[D + 1], float (&rank)[D + 1])
 {
     constexpr int D1 = D + 1;
     const float dp1 = (float)D1;
 
     // elevate, :304-310
-    float el[D1];
     float sm = 0.0f;
 #pragma unroll
     for (int j = D; j > 0; --j) {
@@ -36,7 +37,6 @@ __device__ __forceinline__ void point_record(const float (&feat)[D], const float
     el[0] = sm;
 
     // nearest remainder-0 point; _mm_cvtps_epi32 rounds half to even, :313-323 (quirk Q2)
-    float rem0[D1], rank[D1];
     float sum = 0.0f;
 #pragma unroll
     for (int i = 0; i < D1; ++i) {
@@ -69,6 +69,15 @@ __device__ __forceinline__ void point_record(const float (&feat)[D], const float
         rank[i] += adj;
         rem0[i] += adj;
     }
+}
+
+template <int D>
+__device__ __forceinline__ void point_record(const float (&feat)[D], const float *scale, float inv_dp1,
+                                             int16_t (&r0)[D], uint8_t (&rk)[D], float (&b)[D + 1])
+{
+    constexpr int D1 = D + 1;
+    float el[D1], rem0[D1], rank[D1];
+    lattice_simplex<D>(feat, scale, inv_dp1, el, rem0, rank);
 
     // barycentric weights, accumulated over i = 0..D in order, :348-366.
     // bb has D+2 cells; the indexed updates are written as selects so it stays in registers.
@@ -94,6 +103,40 @@ __device__ __forceinline__ void point_record(const float (&feat)[D], const float
     }
 #pragma unroll
     for (int i = 0; i < D1; ++i) b[i] = bb[i];
+}
+
+// point_record<2> for the grid build of frame_lean.hip -- the same simplex, the same barycentric BITS, other outputs:
+//   b[rem]       barycentric weights.  The reference accumulates b[p] += v_i, b[p + 1] -= v_i over i = 0..2 with p = 2 - rank_i
+//                (:348-366); the ranks are a permutation of {0, 1, 2}, so cell q receives exactly +v of the coordinate with p = q and
+//                -v of the one with p = q - 1, in either order: (0 + a) - c and (0 - c) + a are the same fp32 value for every finite
+//                a, c (signed zeros included: both give +0 when a = c = +-0), so sorting the three v by p and differencing gives the
+//                reference's bits with a quarter of the compare / select instructions of the indexed form.
+//   r0x, r0y     first two coordinates of the remainder-0 vertex (multiples of 3), as ints
+//   f            bit 0: rank_x > 1, bit 1: rank_x > 0, bit 2: rank_y > 1, bit 3: rank_y > 0 -- corner `rem` of the simplex has the key
+//                (r0x + rem - 3 [rank_x > 2 - rem], r0y + rem - 3 [rank_y > 2 - rem])  (vertex_coord<2>; rem = 0: the vertex itself)
+//   wrapped      set when a coordinate is beyond +-32000: the reference's int16 keys may wrap there (not the grid build's case)
+__device__ __forceinline__ void point_record2_grid(const float (&feat)[2], const float *scale, float inv_dp1, float (&b)[3], int &r0x,
+                                                   int &r0y, unsigned &f, bool &wrapped)
+{
+    float el[3], rem0[3], rank[3];
+    lattice_simplex<2>(feat, scale, inv_dp1, el, rem0, rank);
+    float v[3], vq[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) v[i] = (el[i] - rem0[i]) * inv_dp1;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {                        // vq[q] = the v whose p = 2 - rank is q
+        vq[q] = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) vq[q] = (rank[i] == (float)(2 - q)) ? v[i] : vq[q];
+    }
+    const float b3 = 0.0f - vq[2];
+    b[0] = (0.0f + vq[0]) + (1.0f + b3);                 // b[0] += 1 + b[D + 1], :366
+    b[1] = (0.0f + vq[1]) - vq[0];
+    b[2] = (0.0f + vq[2]) - vq[1];
+    r0x = (int)rem0[0];
+    r0y = (int)rem0[1];
+    f = (rank[0] > 1.0f ? 1u : 0u) | (rank[0] > 0.0f ? 2u : 0u) | (rank[1] > 1.0f ? 4u : 0u) | (rank[1] > 0.0f ? 8u : 0u);
+    wrapped |= !(fabsf(rem0[0]) < 32000.0f) || !(fabsf(rem0[1]) < 32000.0f);
 }
 
 // i-th key coordinate of the corner with remainder `rem`: rem0 + canonical[rem][rank],

@@ -35,7 +35,6 @@ struct LeanHdr {                          // the build's scan scratch and flags:
 };
 constexpr int kLeanHdrBytes = 128;
 static_assert(sizeof(LeanHdr) <= kLeanHdrBytes, "header");
-constexpr int kGridMaxCoord = 32000;      // key coordinates beyond this may have wrapped in the reference's int16 keys: not this kernel's case
 constexpr int kGridMaxCells = 32768;      // cells of the id map (u16 ids; what fits beside the other scratch is checked per frame)
 
 // minimum over the 64 lanes of a wavefront, valid in lane 63 (DPP: inside each row of 16 lanes, then across the rows as wave_incl_scan)
@@ -72,7 +71,17 @@ __global__ void __launch_bounds__(kNTSmall, 4) k_frame_lean(CrfDev c, FrameArgs 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int f = blockIdx.x, tid = threadIdx.x;
     const int N = c.n_points[f];
-    Instr ins{a.timing, a.timing_block, 8, 0, a.timing_lane};
+#ifndef LCCRF_FRAME_LEAN_DBG
+#define LCCRF_FRAME_LEAN_DBG 8            // instrumented builds: 8 = a stamp per build phase; 0 + LCCRF_FRAME_LEAN_STAMP_A=1: inside phase A instead
+#endif
+#ifndef LCCRF_FRAME_LEAN_STAMP_A
+#define LCCRF_FRAME_LEAN_STAMP_A 0
+#endif
+#define FL_ASTAMP()                                \
+    do {                                           \
+        if (LCCRF_FRAME_LEAN_STAMP_A) FL_STAMP();  \
+    } while (0)
+    Instr ins{a.timing, a.timing_block, LCCRF_FRAME_LEAN_DBG, 0, a.timing_lane};
     FL_STAMP();
     // (the lane id far from here -- the exits, which the compiler lays out as guarded blocks at the END of the kernel, and everything
     // behind the loops -- as scalar wave base + mbcnt: a vector register holding `tid` for those would be live across the loops, and
@@ -104,22 +113,31 @@ __global__ void __launch_bounds__(kNTSmall, 4) k_frame_lean(CrfDev c, FrameArgs 
     // this frame's record block: what the loop re-reads every iteration (one buffer resource, compile-time offsets)
     unsigned char *rec = a.rec + (size_t)f * kLeanRecBytes;
     PointRegs<PPT, K> pr;
-    // unary energies: from the labels (densecrf3d.h:116-129 with L = 2), or the caller's
+    // unary energies: from the labels (densecrf3d.h:116-129 with L = 2), or the caller's.  Every load first, then the stores (the
+    // compiler must assume the record block aliases the inputs: a store between two loads serialises their latencies).
+    {
+        int lab[PPT];
+        float2 unr[PPT];
 #pragma unroll
-    for (int s = 0; s < PPT; ++s) {
-        const int i = tid + s * NT;
-        if (i < N) {
-            float2 un;
+        for (int s = 0; s < PPT; ++s) {
+            const int ic = min(tid + s * NT, N - 1);
+            lab[s] = 0;
+            unr[s] = make_float2(0.f, 0.f);
+            if (a.label) lab[s] = a.label[(size_t)f * a.maxN + ic];
+            else unr[s] = reinterpret_cast<const float2 *>(c.unary)[(size_t)f * c.maxN + ic];
+        }
+#pragma unroll
+        for (int s = 0; s < PPT; ++s) {
+            const int i = tid + s * NT;
+            float2 un = unr[s];
             if (a.label) {
-                const int t = a.label[(size_t)f * a.maxN + i];
+                const int t = lab[s];
                 const bool known = t >= 0 && t < 2;
-                un.x = !known ? a.tbl[0] : (t == 0 ? a.tbl[3] : a.tbl[1 + t]);
-                un.y = !known ? a.tbl[0] : (t == 1 ? a.tbl[4] : a.tbl[1 + t]);
-            } else {
-                un = reinterpret_cast<const float2 *>(c.unary)[(size_t)f * c.maxN + i];
+                un.x = !known ? a.tbl[0] : (t == 0 ? a.tbl[3] : a.tbl[2]);       // {u, n0, n1, p0, p1}: p_t for the point's label, n_l for the other
+                un.y = !known ? a.tbl[0] : (t == 1 ? a.tbl[4] : a.tbl[1]);       // (no run-time index: that would put the argument block in scratch)
             }
-            if (RELOAD) reinterpret_cast<float2 *>(rec + kLeanRecUnary)[i] = un;
-            else pr.un[s] = un;
+            if (!RELOAD) pr.un[s] = un;
+            else if (i < N) reinterpret_cast<float2 *>(rec + kLeanRecUnary)[i] = un;
         }
     }
     if (tid < 32) reinterpret_cast<float *>(smem)[tid] = 0.0f;       // LDS bytes [0, 128) of the loop's plan are zeros
@@ -138,18 +156,24 @@ __global__ void __launch_bounds__(kNTSmall, 4) k_frame_lean(CrfDev c, FrameArgs 
         // A 2-D key is (x, y) with x = y (mod 3) (permutohedral_cpu.h:274-279,373: remainder-0 point + canonical offset): u = (x - y) / 3,
         // v = y is a bijection onto Z^2, and a blur neighbour along axis j (key -+ 1, coordinate j +- 2, permutohedral_cpu.h:408-421)
         // is the cell at -+ (-1, +1), (+1, -2), (0, +1).  No hash table: a vertex is found by its cell's index, a neighbour by an offset.
-        unsigned cell[PPT][D1];                           // first (u & 0xffff) | v << 16, then the cell index
+        unsigned cell[PPT][D1];                           // cell index of every corner's vertex (formed behind the range's barrier)
+        unsigned pw[PPT], pf[PPT];                        // per point: (u of its remainder-0 vertex & 0xffff) | v << 16; corner flags (point_record2_grid)
         int umin = 0x7fffffff, umax = -0x7fffffff, vmin = 0x7fffffff, vmax = -0x7fffffff;
         bool bad = false;
+        FL_ASTAMP();
+        float2 ftv[PPT];                                  // (every load of the phase first, see above)
+#pragma unroll
+        for (int s = 0; s < PPT; ++s) ftv[s] = reinterpret_cast<const float2 *>(a.feat[k])[(size_t)f * a.maxN + min(tid + s * NT, N - 1)];
+        if (LCCRF_FRAME_LEAN_STAMP_A) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); FL_STAMP(); }
 #pragma unroll
         for (int s = 0; s < PPT; ++s) {
             const int i = tid + s * NT;
-            const float2 ft = reinterpret_cast<const float2 *>(a.feat[k])[(size_t)f * a.maxN + min(i, N - 1)];
+            const float2 ft = ftv[s];
             float feat[2] = {i < N ? ft.x : 0.0f, i < N ? ft.y : 0.0f};   // phantom lanes, :299
-            int16_t r0[2];
-            uint8_t rk[2];
+            FL_ASTAMP();
             float b[D1];
-            point_record<2>(feat, a.scale, a.inv_dp1, r0, rk, b);
+            int r0x, r0y;
+            point_record2_grid(feat, a.scale, a.inv_dp1, b, r0x, r0y, pf[s], bad);
             if (!RELOAD) {
 #pragma unroll
                 for (int j = 0; j < D1; ++j) pr.bary[s][k][j] = b[j];
@@ -158,18 +182,14 @@ __global__ void __launch_bounds__(kNTSmall, 4) k_frame_lean(CrfDev c, FrameArgs 
 #pragma unroll
                 for (int j = 0; j < D1; ++j) bo[j] = b[j];
             }
-#pragma unroll
-            for (int j = 0; j < D1; ++j) {
-                const int x = vertex_coord<2>(r0[0], rk[0], j), y = vertex_coord<2>(r0[1], rk[1], j);
-                const int u = (x - y) / 3;
-                bad |= x <= -kGridMaxCoord || x >= kGridMaxCoord || y <= -kGridMaxCoord || y >= kGridMaxCoord;   // (int16 keys that may have wrapped: the other paths)
-                if (i < Npad) {
-                    umin = min(umin, u); umax = max(umax, u);
-                    vmin = min(vmin, y); vmax = max(vmax, y);
-                }
-                cell[s][j] = ((unsigned)u & 0xffffu) | ((unsigned)y << 16);
+            const int u = (r0x - r0y) / 3;               // (exact: both are multiples of 3)
+            if (i < Npad) {                               // the corners lie within u +- 1, v - 2 .. v + 2 of the remainder-0 vertex
+                umin = min(umin, u); umax = max(umax, u);
+                vmin = min(vmin, r0y); vmax = max(vmax, r0y);
             }
+            pw[s] = ((unsigned)u & 0xffffu) | ((unsigned)r0y << 16);
         }
+        FL_ASTAMP();
         {
             // the frame's key range: wavefront minima / maxima by DPP (as wave_incl_scan), one LDS atomic per wavefront and bound
             const int lo_u = wave_min(umin), hi_u = wave_min(-umax), lo_v = wave_min(vmin), hi_v = wave_min(-vmax);
@@ -181,10 +201,13 @@ __global__ void __launch_bounds__(kNTSmall, 4) k_frame_lean(CrfDev c, FrameArgs 
             }
             if (bad) hdr->fail = 1;
         }
+        FL_ASTAMP();
         __syncthreads();
+        FL_ASTAMP();
         FL_PSTAMP();
-        const int u0 = __builtin_amdgcn_readfirstlane(hdr->box[k][0]) - 1, v0 = __builtin_amdgcn_readfirstlane(hdr->box[k][2]) - 2;   // (an empty border:
-        const int Wp = -__builtin_amdgcn_readfirstlane(hdr->box[k][1]) - u0 + 2, Hp = -__builtin_amdgcn_readfirstlane(hdr->box[k][3]) - v0 + 3;   //  no bounds checks)
+        // (the corners' margin around the remainder-0 vertices, and an empty border of one neighbour step: no bounds checks)
+        const int u0 = __builtin_amdgcn_readfirstlane(hdr->box[k][0]) - 2, v0 = __builtin_amdgcn_readfirstlane(hdr->box[k][2]) - 4;
+        const int Wp = -__builtin_amdgcn_readfirstlane(hdr->box[k][1]) - u0 + 3, Hp = -__builtin_amdgcn_readfirstlane(hdr->box[k][3]) - v0 + 5;
         const long cells_l = (long)Wp * Hp;
         // (readfirstlane: an exit the compiler cannot prove uniform makes everything merged behind it -- V, the loop's plan -- a vector value)
         if (__builtin_amdgcn_readfirstlane(hdr->fail) || cells_l > kGridMaxCells) return false;
@@ -196,13 +219,17 @@ __global__ void __launch_bounds__(kNTSmall, 4) k_frame_lean(CrfDev c, FrameArgs 
         __syncthreads();
         // B: mark the cells that hold a vertex (phantom points of the last block of four included, quirk Q1)
 #pragma unroll
-        for (int s = 0; s < PPT; ++s)
+        for (int s = 0; s < PPT; ++s) {
+            // corner rem: (u + [rank_y > 2 - rem] - [rank_x > 2 - rem], v + rem - 3 [rank_y > 2 - rem])
+            const int u = (int)(short)(pw[s] & 0xffffu), v = (int)pw[s] >> 16;
+            const int c0 = (u - u0) * Hp + (v - v0);
+            cell[s][0] = (unsigned)c0;
+            cell[s][1] = (unsigned)(c0 + 1 + ((pf[s] & 4u) ? Hp - 3 : 0) - ((pf[s] & 1u) ? Hp : 0));
+            cell[s][2] = (unsigned)(c0 + 2 + ((pf[s] & 8u) ? Hp - 3 : 0) - ((pf[s] & 2u) ? Hp : 0));
 #pragma unroll
-            for (int j = 0; j < D1; ++j) {
-                const int u = (int)(short)(cell[s][j] & 0xffffu), v = (int)cell[s][j] >> 16;
-                cell[s][j] = (unsigned)((u - u0) * Hp + (v - v0));
+            for (int j = 0; j < D1; ++j)
                 if (tid + s * NT < Npad) idmap[cell[s][j]] = (unsigned short)1;
-            }
+        }
         __syncthreads();
         FL_PSTAMP();
 
