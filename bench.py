@@ -390,6 +390,7 @@ def slam_subrecord(pkg, wl, torch, dev, name, steps=10, warmup=3, distinct=32):
         b.inference(n_iter, True)                       #  not on one that has just idled through a host-side synchronisation)
         ms.append(b.last_timing()["inference_ms"])
     inf_ms = float(np.median(ms))
+    lanes, per_cu = b.fused_shape()
     M, Q = b.map(), b.probability()
     frames_checked, label_match, max_dq = check_distinct_frames(pbs, idx, M, Q, n_iter)
     tiles_ok = tiles_identical(torch, b, dev, F, N, idx)
@@ -402,7 +403,9 @@ def slam_subrecord(pkg, wl, torch, dev, name, steps=10, warmup=3, distinct=32):
     b.synchronize()
     run_ms = (time.perf_counter() - t0) / max(steps // 2, 3) * 1e3
     run_engine, fb = b.engine(), b.fallback_frames()
-    lanes, per_cu = b.fused_shape()
+    run_lanes, run_per_cu = b.fused_shape()
+    # (the one-launch results through the same gate: every distinct frame against the CPU checker)
+    _, run_match, run_dq = check_distinct_frames(pbs, idx, b.map(), b.probability(), n_iter)
     lds_bytes, lds_clocks, _ = fused_lds_model(N, dims, Vs, True, per_cu == 2 and N > 1024)
     row = longest_rows(pkg, pbs)
     t_floor = lds_clocks * n_iter * F / N_CU / CLK_HZ
@@ -417,6 +420,8 @@ def slam_subrecord(pkg, wl, torch, dev, name, steps=10, warmup=3, distinct=32):
                         "algorithmic_hbm_bytes_per_iteration_frame": algorithmic_bytes_per_iter(N, 2, dims, Vs)},
            "build_ms_per_batch": build_ms,
            "end_to_end": {"one_launch_ms_per_batch": run_ms, "one_launch_engine": run_engine, "fallback_frames": fb,
+                          "one_launch_lanes_per_frame": run_lanes, "one_launch_frames_per_cu": run_per_cu,
+                          "one_launch_label_match_vs_cpu_reference": run_match, "one_launch_max_abs_dQ_vs_cpu_reference": run_dq,
                           "frames_per_s": F / (run_ms * 1e-3), "two_kernel_ms_per_batch": build_ms + inf_ms},
            "label_match_vs_cpu_reference": label_match, "max_abs_dQ_vs_cpu_reference": max_dq,
            "frames_checked": frames_checked, "tiles_identical": tiles_ok}
@@ -1021,6 +1026,7 @@ def main():
         b.inference(n_iter, True, stream=stream)
         kernel_ms.append(b.last_timing()["inference_ms"])
     inf_ms = float(np.median(kernel_ms))
+    inf_shape = b.fused_shape()            # (lanes per frame, frames per CU) of the inference kernel just timed
 
     # end to end per frame = PottsPotential ctors + inference, as the reference pays per frame: ONE launch per frame
     run_ms = None
@@ -1035,6 +1041,7 @@ def main():
         b.synchronize()
         run_ms = (time.perf_counter() - t0r) / n_run * 1e3
         run_engine, run_fallback = b.engine(), b.fallback_frames()
+        run_shape = b.fused_shape()
 
     # parity gate on the timed configuration: labels vs the CPU reference path
     label_match = None
@@ -1055,7 +1062,7 @@ def main():
             # The one-workgroup-per-frame engine keeps the mean-field state in registers and LDS: HBM carries the
             # per-frame records once per launch.  Its roof is the CU's LDS pipe.
             chain0 = True                                           # SLAM frames: the appearance kernel takes the chain path
-            lanes, per_cu = b.fused_shape()
+            lanes, per_cu = inf_shape
             lean = per_cu == 2 and N > 1024                         # (frames of up to 1024 points share a CU on the 137 KB plan's small form)
             lds_bytes, lds_clocks, by = fused_lds_model(N, dims, Vs, chain0, lean)
             row = longest_rows(pkg, pbs)
@@ -1111,10 +1118,12 @@ def main():
             "frames_per_s_end_to_end": (F * world / (run_ms * 1e-3)) if (run_ms and run_engine == 3) else F * world / ((build_ms + inf_ms) * 1e-3),
             "end_to_end": {"one_launch_ms_per_batch": run_ms, "one_launch_engine": (run_engine if run_ms else None),
                            "fallback_frames": (run_fallback if run_ms else None),
+                           "one_launch_lanes_per_frame": (run_shape[0] if run_ms else None),
+                           "one_launch_frames_per_cu": (run_shape[1] if run_ms else None),
                            "two_kernel_ms_per_batch": build_ms + inf_ms,
                            "one_launch_hbm_bytes_per_frame": (pmc_traffic(latest_profile("fused_c2"), "k_frame") / F) if ((name, F) == ("c2", DEFAULT_FRAMES) and pmc_traffic(latest_profile("fused_c2"), "k_frame")) else None,
                            "note": "per frame: both PottsPotential3D ctors (lattice + norm) + inference(n, true); one_launch = "
-                                   "lccrf_batch_run (frame_engine.hip), wall clock over back-to-back batches; two_kernel = HIP "
+                                   "lccrf_batch_run (frame_lean.hip / frame_engine.hip), wall clock over back-to-back batches; two_kernel = HIP "
                                    "events of lccrf_batch_build + lccrf_batch_inference"},
             "label_match_vs_cpu_reference": label_match,
             "max_abs_dQ_vs_cpu_reference": max_dq,

@@ -1,22 +1,25 @@
-// frame_lean.hip -- one frame's WHOLE CRF as one kernel launch (frame_engine.hip) for FULL-SIZE SLAM frames on HALF a CU:
-// 512 lanes, 3-4 points per lane, 80 KB of LDS per frame, so that two frames share a CU in every phase -- one frame's hash
-// inserts, scans and ordered row sums (latency, barriers) run under the other frame's point phases.  Per frame
+// frame_lean.hip -- one frame's WHOLE CRF as one kernel launch (frame_engine.hip) on HALF a CU: 512 lanes, 1-4 points per lane,
+// 80 KB of LDS per frame, so that two frames share a CU in every phase -- one frame's scans, barriers and ordered row sums
+// (latency) run under the other frame's point phases.  Per frame
 //     both PottsPotential3D constructors (lattice + norm)  +  DenseCRF3D::inference(n, true)      (src/Tracking.cc:1920-1929)
-// as in k_frame; what differs is where things live:
-//   build     k_frame's algorithms (keys in an LDS hash table, ids by slot order, neighbours by probing, row places by bitmap or
-//             entry lists; permutohedral_cpu.h:66-167,241-424), with the LDS scratch laid out by LIFETIME instead of carved in
-//             line: the hash table (48 KB at 2000 points) dies with phase D, and the row bitmap / the entry lists are only born
-//             there -- 78 KB at the peak instead of 96.  Each kernel's persistent tables (row starts; the appearance kernel's
-//             neighbour table) are built straight into their places in the loop's plan (fused_lean.h: lean_tables);
-//   records   what fused_lean.h's loop re-reads every iteration -- barycentric weights, norms, unary energies, the smoothness
-//             lattice's neighbour table -- goes to the batch's own arrays in HBM (KernelDev::bary / norm / nbr16, CrfDev::unary)
-//             as it is produced and comes back through L2; a lane keeps Q and its packed vertex / slot words;
+// as in k_frame; what differs:
+//   build     no hash table.  A 2-D lattice vertex is a CELL of a grid over the frame's key range (phase A below): the cells that
+//             hold a vertex are marked, a scan over the cells hands out dense ids in cell order, an entry finds its vertex by its
+//             cell's index and a vertex its blur neighbours at fixed offsets (permutohedral_cpu.h:66-167,371-377,408-421 without
+//             probing, claiming or key compares).  The id map (2 bytes per cell, ~20 KB for a 640 x 480 image's smoothness
+//             kernel) dies with phase D; the row bitmap / the entry lists that rank every entry in its vertex's row (quirk Q6:
+//             ascending point order; frame_engine.hip phases E-G) are only born there -- the scratch is laid out by LIFETIME.
+//             Each kernel's persistent tables (row starts; the appearance kernel's neighbour table) are built straight into their
+//             places in the loop's plan (fused_lean.h: lean_tables);
+//   records   what fused_lean.h's loop re-reads every iteration at 3-4 points per lane -- barycentric weights, norms, unary
+//             energies -- and the smoothness lattice's neighbour table live in ONE block per frame (kLeanRec*, the engine's
+//             `lean_rec` area) behind one buffer resource; they come back through L2;
 //   norm      one pass of the loop's own phases with Q = 1 (mean_field_lean<.., NORM>), pairwise3d.h:20-28;
 //   loop      mean_field_lean, unchanged.
-// Two 2-D kernels, L = 2, the appearance kernel with long rows (chain lanes), 1025 .. 2048 points, batches of >= 256 frames -- C2 / C3.
-// Anything else, and any frame whose lattices do not fit (it flags itself), runs on the other paths with identical results.
-// The vertex numbering is this kernel's own (ids by hash slot order), as in k_frame: the batch's lattice arrays are NOT a build a
-// later lccrf_batch_inference could iterate on (the engine marks them unbuilt).
+// Two 2-D kernels, L = 2, up to 2048 points, batches of >= 256 frames (C1 / C2 / C3).  Anything else, and any frame that does not
+// fit -- key range too wide for the id map, an appearance lattice too large for the chain lanes, coordinates near the int16 wrap --
+// flags itself and runs on the other paths with identical results.  The vertex numbering is this kernel's own (cell order): the
+// mean-field result does not depend on it (frame_engine.hip), V is reported and tested against the reference's M_.
 #include "frame_build.h"
 #include "fused_lean.h"
 
