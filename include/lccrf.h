@@ -267,10 +267,11 @@ int  lccrf_batch_device_label_bits(lccrf_batch_handle b, const uint64_t **d_bits
  *   also reports 3 = the one-launch-per-frame kernel of lccrf_batch_run.                */
 int  lccrf_batch_set_engine(lccrf_batch_handle b, int engine);
 int  lccrf_batch_get_engine(lccrf_batch_handle b, int *engine_in_use);
-/* Report only: the workgroup shape of the last fused-engine launch (engine 2) -- lanes per frame (1024, 512 or 384) and how many
- * frames share a CU (1; 2 for the half-LDS plans: frames of up to 1024 points, and -- round 5 -- full-size SLAM frames of up to
- * ~2300 points in batches of at least 256 frames, csrc/fused_lean.h).  0 / 0 if no such launch happened yet.  Same results in
- * every shape (the order of every row sum is the reference's, permutohedral_cpu.h:653-661).                                   */
+/* Report only: the workgroup shape of the last one-workgroup-per-frame launch -- lccrf_batch_inference on the fused engine (engine 2)
+ * or lccrf_batch_run's one-launch kernel (engine 3), whichever ran last -- as lanes per frame (1024 or 512) and how many frames
+ * share a CU (1; 2 for the half-LDS plans: batches of at least 256 frames of up to 2048 points, csrc/fused_lean.h and
+ * csrc/frame_lean.hip).  0 / 0 if no such launch happened yet.  Same results in every shape (the order of every row sum is the
+ * reference's, permutohedral_cpu.h:653-661).                                                                                   */
 int  lccrf_batch_get_fused_shape(lccrf_batch_handle b, int *lanes_per_frame, int *frames_per_cu);
 /* Report only: how the lattices now in HBM were built (after lccrf_batch_build) -- whether the points of a frame are processed in
  * an internal order (locality mode: frames of >= 8192 points) and whether the vertices were found by the SORTED build
