@@ -125,28 +125,21 @@ struct GridPlace {
     int scratch_b;        // the row bitmap + prefixes or the entry lists start at max(end of the former, this); born after D, they may
                           //   run over the dead id map
 };
-// Every lane of the workgroup calls it (barriers inside); false = the frame does not fit (uniform).
+// Phase A of one kernel: this lane's point records and the workgroup's key range.  No barrier: the caller runs it for every kernel of
+// the frame and then ONE barrier (one key-range reduction and one round trip of feature loads per frame instead of one per kernel).
 //   ftv          this lane's features (point tid + s * NT; loaded by the caller: every load of a phase before its stores)
-//   box, fail    LDS: four ints preset to 0x7fffffff and a flag preset to 0, a barrier ago;  wave_sum: 16 ints of scan scratch
-//   floor_lo     LDS below this is the caller's (persistent tables);  limit: end of the scratch -- the id map sits right below it
-//   place(V, GridPlace &)      the caller's plan for a lattice of V vertices (false: does not fit)
 //   emit_bary(s, i, b)         the barycentric weights of point slot s (point i)
-//   store_nbr(j, v, t, word)   (n1 + 1) | (n2 + 1) << 16 of vertex v along axis j (t = j * V + v), 0 = absent
-//   pk[s][j]     (vertex id + 1) | place in the row << 16 of every entry, as the HBM records of k_fused
-//   rowmax       LDS int that receives the longest row (atomicMax), or null
-template <int NT, int PPT, class Place, class EmitBary, class StoreNbr>
-__device__ __forceinline__ bool grid_build(unsigned char *smem, int tid, int N, const float2 (&ftv)[PPT], const float *scale, float inv_dp1,
-                                           int *box, int *fail, int *wave_sum, int floor_lo, int limit, Place place, EmitBary emit_bary,
-                                           StoreNbr store_nbr, int &V_out, unsigned (&pk)[PPT][kD1], int *rowmax, Instr &ins)
+//   pw, pf       per point: (u of its remainder-0 vertex & 0xffff) | v << 16; corner flags (point_record2_grid) -- for grid_build
+//   box, fail    LDS: four ints preset to 0x7fffffff and a flag preset to 0, a barrier ago
+// A 2-D key is (x, y) with x = y (mod 3) (permutohedral_cpu.h:274-279,373: remainder-0 point + canonical offset): u = (x - y) / 3,
+// v = y is a bijection onto Z^2, and a blur neighbour along axis j (key -+ 1, coordinate j +- 2, permutohedral_cpu.h:408-421)
+// is the cell at -+ (-1, +1), (+1, -2), (0, +1).  No hash table: a vertex is found by its cell's index, a neighbour by an offset.
+template <int NT, int PPT, class EmitBary>
+__device__ __forceinline__ void grid_records(int tid, int N, const float2 (&ftv)[PPT], const float *scale, float inv_dp1, EmitBary emit_bary,
+                                             unsigned (&pw)[PPT], unsigned (&pf)[PPT], int *box, int *fail)
 {
     constexpr int D1 = kD1;
     const int Npad = (N + 3) & ~3;                        // blocks of four, permutohedral_cpu.h:294 (quirk Q1)
-    // A: point records (elevate, round, rank, barycentric); every corner's vertex as a CELL of a grid over the frame's key range.
-    // A 2-D key is (x, y) with x = y (mod 3) (permutohedral_cpu.h:274-279,373: remainder-0 point + canonical offset): u = (x - y) / 3,
-    // v = y is a bijection onto Z^2, and a blur neighbour along axis j (key -+ 1, coordinate j +- 2, permutohedral_cpu.h:408-421)
-    // is the cell at -+ (-1, +1), (+1, -2), (0, +1).  No hash table: a vertex is found by its cell's index, a neighbour by an offset.
-    unsigned cell[PPT][D1];                           // cell index of every corner's vertex (formed behind the range's barrier)
-    unsigned pw[PPT], pf[PPT];                        // per point: (u of its remainder-0 vertex & 0xffff) | v << 16; corner flags (point_record2_grid)
     int umin = 0x7fffffff, umax = -0x7fffffff, vmin = 0x7fffffff, vmax = -0x7fffffff;
     bool bad = false;
 #pragma unroll
@@ -154,30 +147,44 @@ __device__ __forceinline__ bool grid_build(unsigned char *smem, int tid, int N, 
         const int i = tid + s * NT;
         const float2 ft = ftv[s];
         float feat[2] = {i < N ? ft.x : 0.0f, i < N ? ft.y : 0.0f};   // phantom lanes, :299
-            float b[D1];
+        float b[D1];
         int r0x, r0y;
         point_record2_grid(feat, scale, inv_dp1, b, r0x, r0y, pf[s], bad);
         emit_bary(s, i, b);
-        const int u = (r0x - r0y) / 3;               // (exact: both are multiples of 3)
-        if (i < Npad) {                               // the corners lie within u +- 1, v - 2 .. v + 2 of the remainder-0 vertex
+        const int u = (r0x - r0y) / 3;                   // (exact: both are multiples of 3)
+        if (i < Npad) {                                   // the corners lie within u +- 1, v - 2 .. v + 2 of the remainder-0 vertex
             umin = min(umin, u); umax = max(umax, u);
             vmin = min(vmin, r0y); vmax = max(vmax, r0y);
         }
         pw[s] = ((unsigned)u & 0xffffu) | ((unsigned)r0y << 16);
     }
-    {
-        // the frame's key range: wavefront minima / maxima by DPP (as wave_incl_scan), one LDS atomic per wavefront and bound
-        const int lo_u = wave_min(umin), hi_u = wave_min(-umax), lo_v = wave_min(vmin), hi_v = wave_min(-vmax);
-        if ((tid & 63) == 63) {
-            atomicMin(&box[0], lo_u);
-            atomicMin(&box[1], hi_u);
-            atomicMin(&box[2], lo_v);
-            atomicMin(&box[3], hi_v);
-        }
-        if (bad) *fail = 1;
+    // the frame's key range: wavefront minima / maxima by DPP (as wave_incl_scan), one LDS atomic per wavefront and bound
+    const int lo_u = wave_min(umin), hi_u = wave_min(-umax), lo_v = wave_min(vmin), hi_v = wave_min(-vmax);
+    if ((tid & 63) == 63) {
+        atomicMin(&box[0], lo_u);
+        atomicMin(&box[1], hi_u);
+        atomicMin(&box[2], lo_v);
+        atomicMin(&box[3], hi_v);
     }
-    __syncthreads();
-    FL_PSTAMP();
+    if (bad) *fail = 1;
+}
+
+// Phases B .. G of one kernel, a barrier behind grid_records.  Every lane of the workgroup calls it (barriers inside); false = the frame
+// does not fit (uniform).
+//   wave_sum     LDS: 16 ints of scan scratch
+//   floor_lo     LDS below this is the caller's (persistent tables);  limit: end of the scratch -- the id map sits right below it
+//   place(V, GridPlace &)      the caller's plan for a lattice of V vertices (false: does not fit)
+//   store_nbr(j, v, t, word)   (n1 + 1) | (n2 + 1) << 16 of vertex v along axis j (t = j * V + v), 0 = absent
+//   pk[s][j]     (vertex id + 1) | place in the row << 16 of every entry, as the HBM records of k_fused
+//   rowmax       LDS int that receives the longest row (atomicMax), or null
+template <int NT, int PPT, class Place, class StoreNbr>
+__device__ __forceinline__ bool grid_build(unsigned char *smem, int tid, int N, const unsigned (&pw)[PPT], const unsigned (&pf)[PPT],
+                                           const int *box, const int *fail, int *wave_sum, int floor_lo, int limit, Place place,
+                                           StoreNbr store_nbr, int &V_out, unsigned (&pk)[PPT][kD1], int *rowmax, Instr &ins)
+{
+    constexpr int D1 = kD1;
+    const int Npad = (N + 3) & ~3;
+    unsigned cell[PPT][D1];                               // cell index of every corner's vertex
     // (the corners' margin around the remainder-0 vertices, and an empty border of one neighbour step: no bounds checks)
     const int u0 = __builtin_amdgcn_readfirstlane(box[0]) - 2, v0 = __builtin_amdgcn_readfirstlane(box[2]) - 4;
     const int Wp = -__builtin_amdgcn_readfirstlane(box[1]) - u0 + 3, Hp = -__builtin_amdgcn_readfirstlane(box[3]) - v0 + 5;

@@ -114,11 +114,33 @@ __global__ void __launch_bounds__(kNTSmall, 4) k_frame_lean(CrfDev c, FrameArgs 
     unsigned pk[PPT][K][D1];              // (vertex id + 1) | place in the row << 16, as the HBM records of k_fused
 
     // ---- one kernel's lattice: false = the frame does not fit (uniform) ---------------------------------------------------
+    // A, both kernels: point records and key ranges behind ONE barrier (every load first: the record block may alias the inputs)
+    unsigned pw[K][PPT], pf[K][PPT];
+    {
+        float2 ftv[K][PPT];
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+#pragma unroll
+            for (int s = 0; s < PPT; ++s) ftv[k][s] = reinterpret_cast<const float2 *>(a.feat[k])[(size_t)f * a.maxN + min(tid + s * NT, N - 1)];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            auto emit_bary = [&](int s, int i, const float (&b)[D1]) {
+                if (!RELOAD) {
+#pragma unroll
+                    for (int j = 0; j < D1; ++j) pr.bary[s][k][j] = b[j];
+                } else if (i < N) {
+                    float *bo = reinterpret_cast<float *>(rec + kLeanRecBary + k * (kLeanRecPoints * D1 * 4)) + i * D1;
+#pragma unroll
+                    for (int j = 0; j < D1; ++j) bo[j] = b[j];
+                }
+            };
+            grid_records<NT, PPT>(tid, N, ftv[k], a.scale, a.inv_dp1, emit_bary, pw[k], pf[k], hdr->box[k], &hdr->fail);
+        }
+    }
+    __syncthreads();
+    FL_PSTAMP();
     auto build = [&](auto kc) -> bool {
         constexpr int k = decltype(kc)::value;
-        float2 ftv[PPT];                                  // (every load of the phase first, see above)
-#pragma unroll
-        for (int s = 0; s < PPT; ++s) ftv[s] = reinterpret_cast<const float2 *>(a.feat[k])[(size_t)f * a.maxN + min(tid + s * NT, N - 1)];
         const int plan_before = (int)plan;
         int lt_nbr = 0;
         // this kernel's persistent tables straight into their places in the loop's plan (fused_lean.h: lean_tables); kernel 1's scratch
@@ -132,24 +154,14 @@ __global__ void __launch_bounds__(kNTSmall, 4) k_frame_lean(CrfDev c, FrameArgs 
             gp.scratch_b = (int)plan;
             return true;
         };
-        auto emit_bary = [&](int s, int i, const float (&b)[D1]) {
-            if (!RELOAD) {
-#pragma unroll
-                for (int j = 0; j < D1; ++j) pr.bary[s][k][j] = b[j];
-            } else if (i < N) {
-                float *bo = reinterpret_cast<float *>(rec + kLeanRecBary + k * (kLeanRecPoints * D1 * 4)) + i * D1;
-#pragma unroll
-                for (int j = 0; j < D1; ++j) bo[j] = b[j];
-            }
-        };
         // the appearance lattice's table stays in LDS (the loop's plan), the smoothness lattice's goes to HBM (the loop reads it pass by pass)
         auto store_nbr = [&](int j, int v, int t, unsigned word) {
             if (k == 0) reinterpret_cast<unsigned *>(smem + lt_nbr)[t] = word;
             else reinterpret_cast<unsigned *>(rec + kLeanRecNbr)[j * (kLeanRecNbrAxis / 4) + v] = word;
         };
         unsigned pkk[PPT][D1];
-        const bool ok = grid_build<NT, PPT>(smem, tid, N, ftv, a.scale, a.inv_dp1, hdr->box[k], &hdr->fail, hdr->wave_sum, plan_before, hdr_off,
-                                            place, emit_bary, store_nbr, V[k], pkk, nullptr, ins);
+        const bool ok = grid_build<NT, PPT>(smem, tid, N, pw[k], pf[k], hdr->box[k], &hdr->fail, hdr->wave_sum, plan_before, hdr_off, place,
+                                            store_nbr, V[k], pkk, nullptr, ins);
 #pragma unroll
         for (int s = 0; s < PPT; ++s)
 #pragma unroll
