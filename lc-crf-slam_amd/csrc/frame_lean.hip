@@ -113,8 +113,7 @@ __global__ void __launch_bounds__(kNTSmall, 4) k_frame_lean(CrfDev c, FrameArgs 
     int V[K];
     unsigned pk[PPT][K][D1];              // (vertex id + 1) | place in the row << 16, as the HBM records of k_fused
 
-    // ---- one kernel's lattice: false = the frame does not fit (uniform) ---------------------------------------------------
-    // A, both kernels: point records and key ranges behind ONE barrier (every load first: the record block may alias the inputs)
+    // ---- A, both kernels: point records and key ranges behind ONE barrier (every load first: the record block may alias the inputs)
     unsigned pw[K][PPT], pf[K][PPT];
     {
         float2 ftv[K][PPT];
@@ -139,6 +138,7 @@ __global__ void __launch_bounds__(kNTSmall, 4) k_frame_lean(CrfDev c, FrameArgs 
     }
     __syncthreads();
     FL_PSTAMP();
+    // ---- B .. G, one kernel's lattice: false = the frame does not fit (uniform) ---------------------------------------------
     auto build = [&](auto kc) -> bool {
         constexpr int k = decltype(kc)::value;
         const int plan_before = (int)plan;
