@@ -742,3 +742,73 @@ np.save(sys.argv[1], np.concatenate([b.probability().ravel().view(np.uint32), np
         os.remove(path)
     assert tuple(outs[0][-2:]) == (512, 2) and tuple(outs[1][-2:]) == (1024, 1)
     assert np.array_equal(outs[0][:-2], outs[1][:-2])
+
+
+def _host_bits(b):
+    b.download_async(pkg.BatchCRF.DOWNLOAD_LABEL_BITS)
+    return b.wait_download()["bits"]
+
+
+def test_half_cu_frame_kernel_corner_calls(po, wl):
+    """frame_lean.hip at the edges of the call: zero iterations (Q = softmax(-unary), densecrf_base.h:78-80), no MAP, every points-per-lane
+    shape (1 .. 4), a handle reused with SMALLER frames (the label bits beyond a frame's points must read 0, and nothing of the previous
+    batch may leak through the kernel's record area), labels with unknown entries -- against the oracle, bit for bit."""
+    F = 256
+    for top in (400, 900, 1400, 2048):                     # 1, 2, 3, 4 points per lane
+        base = [wl.slam_problem(max(top - 37 * i, 1), seed=6400 + i) for i in range(5)]
+        for pb in base:
+            pb["label"] = pb["label"].copy()
+            pb["label"][::9] = -1
+        pbs = [base[f % 5] for f in range(F)]
+        b = _batch_of(pbs, maxN=2048)
+        refs = []
+        for pb in pbs[:5]:
+            o = cc.setup(po.OracleCRF, pb)
+            o.inference_native(0, True)
+            q0 = o.probability().copy()
+            o.inference_native(4, True)
+            refs.append((q0, o.probability().copy(), o.map().copy()))
+            o.close()
+        b.run(0, True)
+        assert b.engine() == 3 and b.fused_shape() == (512, 2)
+        Q = b.probability()
+        for f in range(F):
+            assert cc.same_bits(Q[f, :pbs[f]["N"]], refs[f % 5][0]), (top, f)
+        b.run(4, False)                                    # no MAP asked for: Q all the same
+        Q = b.probability()
+        for f in range(F):
+            assert cc.same_bits(Q[f, :pbs[f]["N"]], refs[f % 5][1]), (top, f)
+        b.run(4, True)
+        M, bits = b.map(), _host_bits(b)
+        for f in range(0, F, 17):
+            n = pbs[f]["N"]
+            assert np.array_equal(M[f, :n], refs[f % 5][2])
+            want = np.zeros(bits.shape[1] * 64, np.uint8)
+            want[:n] = refs[f % 5][2] == 1
+            assert np.array_equal(np.unpackbits(bits[f].view(np.uint8), bitorder="little"), want), (top, f)
+        b.close()
+    # one handle, a batch of large frames, then a batch of small ones
+    big = [wl.slam_problem(2000, seed=6500 + f % 3) for f in range(F)]
+    small = [wl.slam_problem(300 + f % 3, seed=6600 + f % 3) for f in range(F)]
+    b = _batch_of(big, maxN=2048)
+    b.run(3, True)
+    feats = [np.zeros((F, 2048, 2), np.float32) for _ in range(2)]
+    label = np.full((F, 2048), -1, np.int16)
+    for f, pb in enumerate(small):
+        label[f, :pb["N"]] = pb["label"]
+        for k in range(2):
+            feats[k][f, :pb["N"]] = pb["kernels"][k][0]
+    b.set_inputs_host([pb["N"] for pb in small], feats, label=label, conf=small[0].get("conf", 0.7))
+    b.run(3, True)
+    Q, bits = b.probability(), _host_bits(b)
+    for i in range(3):
+        o = cc.setup(po.OracleCRF, small[i])
+        o.inference_native(3, True)
+        n = small[i]["N"]
+        for f in range(i, F, 3):
+            assert cc.same_bits(Q[f, :n], o.probability()), f
+            want = np.zeros(bits.shape[1] * 64, np.uint8)
+            want[:n] = o.map() == 1
+            assert np.array_equal(np.unpackbits(bits[f].view(np.uint8), bitorder="little"), want), f
+        o.close()
+    b.close()
