@@ -742,7 +742,9 @@ struct Engine {
     int run_frame(int n_iter, int with_map, float relax)
     {
         *late_status = 0;
-        const bool from_label = unary_deferred && L == 2;
+        // (label-derived energies already written for lattices in locality mode sit in the INTERNAL point order: the frame kernel, which
+        //  works in the caller's order, derives them from the labels again)
+        const bool from_label = (unary_deferred || (unary_is_label && perm_on)) && L == 2;
         unsigned *dual = nullptr;
         // The tracker's case (one frame, 255 idle CUs) and small batches (a quarter as many frames as CUs, or fewer): every
         // frame gets two workgroups, one per lattice build.

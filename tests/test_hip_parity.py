@@ -1043,3 +1043,40 @@ def test_locality_mode_with_labels_and_device_inputs(po, wl):
         assert cc.same_bits(Q[i, :n], o.probability()) and np.array_equal(M[i, :n], o.map()), i
         o.close()
     b.close()
+
+
+@pytest.mark.gpu
+def test_locality_threshold_below_the_one_workgroup_build_keeps_the_callers_order(po, wl):
+    """LCCRF_PERM_MIN (instrumented library) lowers the size from which locality mode permutes the points; frames the
+    one-workgroup build still accepts (N = 2000 with two 2-D kernels) must then NOT be built by it -- that build knows nothing of the
+    internal point order, and the engine would iterate permuted unaries over lattices in the caller's order.  build() + inference()
+    with the threshold at 1500, under LCCRF_NO_FRAME as well: the oracle's bits."""
+    code = r"""
+import importlib, sys, numpy as np
+sys.path.insert(0, %r)
+pkg = importlib.import_module("lc-crf-slam_amd"); wl = importlib.import_module("lc-crf-slam_amd.workloads")
+pb = wl.slam_problem(2000, seed=77)
+F = 3
+b = pkg.BatchCRF(F, 2000, 2, [2, 2], [float(w) for _, w in pb["kernels"]])
+lab = np.repeat(pb["label"][None], F, 0)
+b.set_inputs_host([2000, 1800, 2000], [np.repeat(f[None], F, 0) for f, _ in pb["kernels"]], label=lab, conf=pb["conf"])
+b.build(); b.inference(5, True)
+q1 = b.probability().copy()
+mode = b.locality_mode()[0]
+b.run(5, True)
+np.save(sys.argv[1], np.concatenate([q1.ravel(), b.probability().ravel(), np.float32([mode])]))
+""" % ROOT
+    pb = wl.slam_problem(2000, seed=77)
+    o = cc.setup(po.OracleCRF, pb)
+    o.inference_native(5, True)
+    want = o.probability().copy()
+    o.close()
+    for extra in ({}, {"LCCRF_NO_FRAME": "1"}):
+        path = os.path.join("/tmp", "perm_min_%d.npy" % os.getpid())
+        subprocess.run([sys.executable, "-c", code, path], check=True, env=cc.switch_env(LCCRF_PERM_MIN="1500", **extra), timeout=600)
+        got = np.load(path)
+        os.remove(path)
+        q = got[:-1].reshape(2, 3, 2000, 2)
+        assert got[-1] == 1.0, extra                        # (the switch took: the lattices were built in the internal point order)
+        for which in range(2):                             # build + inference, then lccrf_batch_run
+            assert cc.same_bits(q[which, 0], want) and cc.same_bits(q[which, 2], want), (extra, which)
