@@ -952,7 +952,7 @@ struct Engine {
             g.kernels[k].dev.w = kernels[k].dev.w;
         }
         g.crf.unary = g.unary_own;
-        if (unary_deferred) {
+        if (unary_deferred || (unary_is_label && perm_on)) {   // (see run_frame: energies written in the internal point order are of no use here)
             launch_copy_frames(g.label_own, (size_t)maxN * 2, deferred_label, (size_t)maxN * 2, fb_list, n, (size_t)maxN * 2, 1, stream);
             g.unary_deferred = true;
             g.deferred_label = g.label_own;
