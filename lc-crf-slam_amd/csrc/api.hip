@@ -763,8 +763,11 @@ struct Engine {
         if (labels_armed) memset(map_host, 0xff, (size_t)activeN * sizeof(int16_t));
         // full-size frames, two per CU (frame_lean.hip): the record area its loop re-reads is allocated when a batch first wants it
         if (frame_lean_ok && !lean_rec && frame_lean_wanted(crf)) {
-            int rc = mem.alloc(reinterpret_cast<char **>(&lean_rec), frame_lean_rec_bytes(Fcap));
-            if (rc) return rc;
+            // (no memory for the area: the batch keeps the one-frame-per-CU kernel, which needs none)
+            if (mem.alloc(reinterpret_cast<char **>(&lean_rec), frame_lean_rec_bytes(Fcap), false)) {   // (written before it is read: no zeroing)
+                frame_lean_ok = false;
+                (void)hipGetLastError();
+            }
         }
         const int shape = launch_frame(crf, kdevs.data(), n_iter, with_map, relax, late_status, frame_status,
                                        from_label ? deferred_label : nullptr, deferred_tbl.v, stream, frame_small_ok, dual, dual_epoch,

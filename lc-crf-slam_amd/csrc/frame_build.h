@@ -102,6 +102,7 @@ __device__ __forceinline__ const T &late_args(int offset)
     return *(const T *)(p + offset);
 }
 constexpr int kArgOffA = (int)((sizeof(CrfDev) + alignof(FrameArgs) - 1) / alignof(FrameArgs) * alignof(FrameArgs));
+static_assert(alignof(CrfDev) == 8 && alignof(FrameArgs) == 8, "the frame kernels' arguments (CrfDev, FrameArgs) as the ABI lays them out: by value, naturally aligned, in order");
 
 constexpr int kGridMaxCells = 32768;      // cells of the id map (u16 ids; what fits beside the other scratch is checked per frame)
 
