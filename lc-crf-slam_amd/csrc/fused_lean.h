@@ -686,11 +686,11 @@ __device__ __forceinline__ void mean_field_lean(unsigned char *smem, const Fused
 #ifndef LCCRF_LEAN_EARLY_WEIGHTS
 #define LCCRF_LEAN_EARLY_WEIGHTS 0        // A/B (scripts/gpu_ab_build.sh): request the re-read records one blur phase earlier
 #endif
-            if (LCCRF_LEAN_EARLY_WEIGHTS) load_weights();
+            if (LCCRF_LEAN_EARLY_WEIGHTS && !NORM) load_weights();
             if (t >= NB) blur_small(t - NB, 0, 2);        // (two of its three dependent passes here, the third beside pass 2 below:
             else blur_big(1, t, NB, RB, wb[0]);           //  all three in one phase made that phase as long as this one wavefront)
             __syncthreads();
-            if (!LCCRF_LEAN_EARLY_WEIGHTS) load_weights();   // (requested before the last pass: they land under it)
+            if (!LCCRF_LEAN_EARLY_WEIGHTS && !NORM) load_weights();   // (requested before the last pass: they land under it; a NORM pass has no next iteration)
             if (t < NB) blur_big(2, t, NB, RB, wb[1]);
             else blur_small(t - NB, 2, D1);
             __syncthreads();
@@ -703,7 +703,7 @@ __device__ __forceinline__ void mean_field_lean(unsigned char *smem, const Fused
             __syncthreads();
             blur_pass(1, w);
             __syncthreads();
-            load_weights();                               // (requested before the last pass: they land under it)
+            if (!NORM) load_weights();                    // (requested before the last pass: they land under it)
             blur_pass(2, w);
             __syncthreads();
         }
