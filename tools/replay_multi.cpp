@@ -309,7 +309,7 @@ void rank_main(int rank, int G, int B, bool single_wg, bool serial, const std::v
 int main(int argc, char **argv)
 {
     const char *path = nullptr;
-    int G = 0, B = 64;
+    int G = 0, B = 256;                   // (from 256 frames per batch the one-launch kernel runs two frames per CU: csrc/frame_lean.hip)
     bool single_wg = false, serial = false;
     for (int i = 1; i < argc; ++i) {
         if (!strcmp(argv[i], "--gpus") && i + 1 < argc) G = atoi(argv[++i]);
