@@ -803,6 +803,18 @@ def iteration_traffic(tag):
             "profile": "profiles/%s (kernel_stats.csv, pmc_summary.csv: FETCH x2 + WRITE per launch)" % tag} if total else None
 
 
+def sq_counter(tag, kernel, counter):
+    """Mean per launch of an SQ counter of `kernel` from the committed profiles/<tag>/sq_counters.txt (scripts/pmc_sq.sh), or None."""
+    fn = os.path.join(ROOT, "profiles", tag or "", "sq_counters.txt")
+    if not tag or not os.path.exists(fn):
+        return None
+    for line in open(fn):
+        w = line.split()
+        if len(w) >= 4 and w[0] == kernel and w[1] == counter and w[2] == "mean/dispatch":
+            return float(w[3])
+    return None
+
+
 def pmc_traffic(tag, kernel="k_fused", corrected=True):
     """HBM bytes per launch of `kernel` from a committed rocprofv3 --pmc profile of THIS command line
     (profiles/<tag>/pmc_summary.csv: FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE; corrected=False:
@@ -1072,8 +1084,14 @@ def main():
             peak = lds_launch / t_floor / 1e9
             ptag = latest_profile("fused_c2") if (name, F) == ("c2", DEFAULT_FRAMES) else None
             traffic = pmc_traffic(ptag)
+            valu = sq_counter(ptag, "k_fused", "SQ_INSTS_VALU")      # wavefront-level vector instructions per launch (committed SQ counters)
+            valu_floor = (valu * 4.0 / (N_CU * 4 * CLK_HZ)) if valu else None   # a SIMD issues one wave64 vector instruction per 4 clocks
             roof = {"bound": "lds", "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": achieved / peak,
                     "traffic": traffic,
+                    "valu_issue": ({"instructions_per_launch": valu, "floor_ms": valu_floor * 1e3, "frac": valu_floor / launch_s,
+                                    "note": "with two frames per CU the vector ALU is the busiest unit: SQ_INSTS_VALU of the committed profile "
+                                            "x 4 clocks / (256 CUs x 4 SIMDs x 2.4 GHz) against the launch -- context beside the LDS roof, "
+                                            "which stays the reported bound"} if valu else None),
                     "kernel": "inference launch (start + %d mean-field iterations + map), HIP events" % n_iter,
                     "launch_ms": inf_ms, "lds_bytes_per_iteration_frame": lds_bytes, "lanes_per_frame": lanes, "frames_per_cu": per_cu,
                     "lds_floor_ms": t_floor * 1e3, "longest_row": row, "chain_floor_ms": chain_floor(row, n_iter, F, N),
