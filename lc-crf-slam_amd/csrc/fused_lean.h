@@ -519,7 +519,7 @@ __device__ __forceinline__ void mean_field_lean(unsigned char *smem, const Fused
                 float a0 = 0.0f, a1 = 0.0f;
 #pragma unroll
                 for (int u = 0; u < 8; ++u) { a0 += x[r][u].x; a1 += x[r][u].y; }   // strictly left to right
-                for (int p = p0[r] + 8; p < pe[r]; p += 8) {                         // (rows of more than eight products)
+                for (int p = p0[r] + 8; p < pe[r] && !FL_DBG(16); p += 8) {          // (rows of more than eight products; LCCRF_FUSED_DBG=16, instrumented: timing without them)
                     float2 y[8];
 #pragma unroll
                     for (int u = 0; u < 8; ++u) y[u] = *((p + u < pe[r]) ? pl + p + u : zero);
