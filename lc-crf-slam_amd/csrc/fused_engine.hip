@@ -181,7 +181,8 @@ __global__ void __launch_bounds__(NT, NT == 384 ? 3 : 4) k_fused_lean(CrfDev c, 
 {
     constexpr int D1 = kD1;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int f = blockIdx.x;
+    const int fo = blockIdx.x;                            // the frame; f: whose RECORDS are read (LEAN_SKIP(1024), timing only: the first 64 frames' --
+    const int f = LEAN_SKIP(1024) ? (fo & 63) : fo;       //   identical to this frame's in the bench's tiled batch -- so that they come out of L2, as if prefetched)
     const int tid = threadIdx.x;
     const int N = c.n_points[f];
     Instr ins{a.timing, a.timing_block, a.dbg, 0, a.timing_lane};
@@ -201,7 +202,7 @@ __global__ void __launch_bounds__(NT, NT == 384 ? 3 : 4) k_fused_lean(CrfDev c, 
         return wave_base + (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, (unsigned)z));
     };
     if (N <= 0) {
-        if (a.with_map) clear_label_bits<NT>(c, f, 0, lane_id());
+        if (a.with_map) clear_label_bits<NT>(c, fo, 0, lane_id());
         return;
     }
     const FusedLayout &lay = a.lay;
@@ -288,7 +289,7 @@ __global__ void __launch_bounds__(NT, NT == 384 ? 3 : 4) k_fused_lean(CrfDev c, 
     mean_field_lean<PPT, K, CH, NT, RELOAD>(smem, lay, V, N, t, pr, cl, alpha, wk, src, a.n_iter, a.relax, a.omr, ins);
     t = lane_id();
 
-    store_results<PPT, K, NT>(c, f, N, t, pr, a.with_map);
+    store_results<PPT, K, NT>(c, fo, N, t, pr, a.with_map);
     FL_STAMP();
     if (kInstr && a.timing && (int)blockIdx.x == a.timing_block && t == a.timing_lane) a.timing[63] = ins.n;
 }

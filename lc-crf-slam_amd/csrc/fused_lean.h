@@ -16,6 +16,16 @@
 
 #include "fused_loop.h"
 
+// Timing experiments (scripts/gpu_ab_build.sh "" "-DLCCRF_LEAN_SKIP=<bits>"; WRONG results, never in a shipped library): what a phase of
+// the loop costs in throughput, as the launch time without it.  2 no chain sums, 16 no second trips of the short-row sums, 32 no short-row
+// sums, 64 no blur passes, 128 no X (slice + softmax + products), 256 the per-point records are read once (no re-reads), 512 no
+// neighbour words, 1024 (k_fused_lean) every workgroup reads the records of one of the first 64 frames.  A compile-time constant: as a
+// run-time switch the tests alone cost the 4-points-per-lane loop 52 spilled registers.
+#ifndef LCCRF_LEAN_SKIP
+#define LCCRF_LEAN_SKIP 0
+#endif
+#define LEAN_SKIP(bit) ((LCCRF_LEAN_SKIP & (bit)) != 0)
+
 namespace lccrf {
 namespace fl {
 
@@ -472,7 +482,7 @@ __device__ __forceinline__ void mean_field_lean(unsigned char *smem, const Fused
                 // (opaque: the row's address, end and trip counts are formed HERE -- hoisted out of the loop they would sit in
                 // registers, or scratch, for the whole launch; the two words themselves ride through the ring as operands)
                 asm volatile("" : "+v"(cl.a), "+v"(cl.b));
-                if (__builtin_expect((cl.b >> 16) != 0, 1)) {
+                if (__builtin_expect((cl.b >> 16) != 0, 1) && !LEAN_SKIP(2)) {     // (LEAN_SKIP: timing experiments, see the top of the file)
                     const unsigned row_addr = cl.a & 0x3ffffu, row_end = row_addr + (cl.b & 0x1fffu) * 16u;
                     const unsigned m = (unsigned)__builtin_amdgcn_readfirstlane((int)(cl.a >> 18));       // the wavefront's longest row, quads
                     const float acc = (t >> 7) == 0 ? chain_rows_keep(row_addr, row_end, (((m + 1u) >> 1) + 3u) >> 2, cl.a, cl.b)
@@ -489,6 +499,7 @@ __device__ __forceinline__ void mean_field_lean(unsigned char *smem, const Fused
         // end of its row reads the zero block (x + 0 is exact, see chain_rows).  This lane's rows (vertices t, t + NT, ...) are walked
         // TOGETHER: every row's pointers first, then every row's first eight products -- most rows of a smoothness kernel end there --
         // so the phase waits for two rounds of LDS latency instead of two per row; each row is still added strictly left to right.
+        if (LEAN_SKIP(32)) return;
         const float2 *pl = reinterpret_cast<const float2 *>(smem + lay.prod[k]);
         const float2 *zero = reinterpret_cast<const float2 *>(smem + lay.zero);
         const unsigned short *row = reinterpret_cast<const unsigned short *>(smem + lay.row[k]);
@@ -519,7 +530,7 @@ __device__ __forceinline__ void mean_field_lean(unsigned char *smem, const Fused
                 float a0 = 0.0f, a1 = 0.0f;
 #pragma unroll
                 for (int u = 0; u < 8; ++u) { a0 += x[r][u].x; a1 += x[r][u].y; }   // strictly left to right
-                for (int p = p0[r] + 8; p < pe[r] && !FL_DBG(16); p += 8) {          // (rows of more than eight products; LCCRF_FUSED_DBG=16, instrumented: timing without them)
+                for (int p = p0[r] + 8; p < pe[r] && !LEAN_SKIP(16); p += 8) {          // (rows of more than eight products)
                     float2 y[8];
 #pragma unroll
                     for (int u = 0; u < 8; ++u) y[u] = *((p + u < pe[r]) ? pl + p + u : zero);
@@ -585,7 +596,7 @@ __device__ __forceinline__ void mean_field_lean(unsigned char *smem, const Fused
 #pragma unroll
         for (int r = 0; r < RA; ++r) {
             wa[r] = 0;
-            if (r == 0 || r * NA0 < V[K - 1])
+            if ((r == 0 || r * NA0 < V[K - 1]) && !LEAN_SKIP(512))
                 wa[r] = __builtin_amdgcn_raw_buffer_load_b32(src.nbr[K - 1], (t - 128 + r * NA0) * 4, src.off_nbr[K - 1], 0);      // (lanes < 128: out of range reads 0, unused)
         }
 #pragma unroll
@@ -593,12 +604,13 @@ __device__ __forceinline__ void mean_field_lean(unsigned char *smem, const Fused
 #pragma unroll
             for (int r = 0; r < RB; ++r) {
                 wb[j - 1][r] = 0;
-                if (r == 0 || r * NB < V[K - 1])
+                if ((r == 0 || r * NB < V[K - 1]) && !LEAN_SKIP(512))
                     wb[j - 1][r] = __builtin_amdgcn_raw_buffer_load_b32(src.nbr[K - 1], (t + r * NB) * 4, src.off_nbr[K - 1] + j * src.nbr_axis_bytes[K - 1], 0);
             }
         }
     };
     auto blur_vertex = [&](const float2 *src_v, float2 *dst, int v, unsigned n) {
+        if (LEAN_SKIP(64)) return;
         const float2 o = src_v[v + 1], x = src_v[n & 0xffffu], y = src_v[n >> 16];
         float2 u;
         u.x = o.x + 0.5f * (x.x + y.x);
@@ -686,11 +698,11 @@ __device__ __forceinline__ void mean_field_lean(unsigned char *smem, const Fused
 #ifndef LCCRF_LEAN_EARLY_WEIGHTS
 #define LCCRF_LEAN_EARLY_WEIGHTS 0        // A/B (scripts/gpu_ab_build.sh): request the re-read records one blur phase earlier
 #endif
-            if (LCCRF_LEAN_EARLY_WEIGHTS && !NORM) load_weights();
+            if (LCCRF_LEAN_EARLY_WEIGHTS && !NORM && !LEAN_SKIP(256)) load_weights();
             if (t >= NB) blur_small(t - NB, 0, 2);        // (two of its three dependent passes here, the third beside pass 2 below:
             else blur_big(1, t, NB, RB, wb[0]);           //  all three in one phase made that phase as long as this one wavefront)
             __syncthreads();
-            if (!LCCRF_LEAN_EARLY_WEIGHTS && !NORM) load_weights();   // (requested before the last pass: they land under it; a NORM pass has no next iteration)
+            if (!LCCRF_LEAN_EARLY_WEIGHTS && !NORM && !LEAN_SKIP(256)) load_weights();   // (requested before the last pass: they land under it; a NORM pass has no next iteration)
             if (t < NB) blur_big(2, t, NB, RB, wb[1]);
             else blur_small(t - NB, 2, D1);
             __syncthreads();
@@ -703,7 +715,7 @@ __device__ __forceinline__ void mean_field_lean(unsigned char *smem, const Fused
             __syncthreads();
             blur_pass(1, w);
             __syncthreads();
-            if (!NORM) load_weights();                    // (requested before the last pass: they land under it)
+            if (!NORM && !LEAN_SKIP(256)) load_weights();    // (requested before the last pass: they land under it)
             blur_pass(2, w);
             __syncthreads();
         }
@@ -713,7 +725,7 @@ __device__ __forceinline__ void mean_field_lean(unsigned char *smem, const Fused
         const bool more = it + 1 < n_iter;
 #pragma unroll
         for (int s = 0; s < PPT; ++s) {
-            if (t + s * NT < N) {
+            if (t + s * NT < N && !LEAN_SKIP(128)) {
                 point_update(s);
                 if (more) point_products_lean<PPT, K, CH>(lay, pr, s, KF);
             }
