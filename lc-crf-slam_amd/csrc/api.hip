@@ -266,6 +266,7 @@ struct Engine {
         sort.vcap = vcap;
         int vbits = 10;
         while (vbits < 21 && (1 << vbits) < 4 * vcap) ++vbits;
+        if (const char *e = ab_env("LCCRF_VBITS")) vbits = std::min(std::max(atoi(e), 10), 21);   // A/B switch (same results): buckets of the vertex sort
         sort.vbits = vbits;
         const size_t vnbk = ((size_t)1 << vbits) + 1;
         if ((rc = mem.alloc(&sort.vcode, Fz * vcap))) return rc;
