@@ -159,6 +159,45 @@ def test_a_frame_that_falls_back_is_settled_by_wait_download(po, wl):
     b.close()
 
 
+def test_pipeline_of_256_frame_batches_runs_two_frames_per_cu_and_settles_its_fallbacks(po, wl):
+    """From 256 frames per batch the one-launch kernel is csrc/frame_lean.hip (two frames per CU, records in the handle's own area): two
+    handles round-robin, batches of ragged full-size frames with one frame that the half-CU plan cannot take in every batch -- every
+    batch comes back with its own bits, the flagged frame's included, and the handles report the shape."""
+    maxN, F = 2048, 256
+    base = [wl.slam_problem(1500 + 61 * i, seed=8600 + i) for i in range(8)]
+    odd = _shaped_problem(wl, 1700, "sparse", seed=9)
+    batches = [[odd if f == 40 + i else base[(f + i) % 8] for f in range(F)] for i in range(3)]
+    refs = {}
+    for pb in base + [odd]:
+        o = cc.setup(po.OracleCRF, pb)
+        o.inference_native(5, True)
+        refs[id(pb)] = (o.probability().copy(), o.map().copy())
+        o.close()
+    handles = [_new_batch(batches[0], maxN, F) for _ in range(2)]
+    got = {}
+    for i in range(3 + 2):
+        h = handles[i % 2]
+        if i >= 2:
+            got[i - 2] = (h.wait_download(), h.fallback_frames(), h.fused_shape())
+        if i < 3:
+            npts, feats, label = _arrays(batches[i], maxN)
+            h.set_inputs_host_async(npts, feats, label=label, conf=base[0]["conf"])
+            h.run(5, True)
+            h.download_async(pkg.BatchCRF.DOWNLOAD_LABEL_BITS | pkg.BatchCRF.DOWNLOAD_PROBABILITY)
+    for i in range(3):
+        out, fb, shape = got[i]
+        assert fb == 1 and shape == (512, 2), (i, fb, shape)
+        npts = np.array([pb["N"] for pb in batches[i]], np.int32)
+        m = np.zeros((F, maxN), np.int16)
+        for f, pb in enumerate(batches[i]):
+            q, mm = refs[id(pb)]
+            assert cc.same_bits(out["prob"][f, :pb["N"]], q), (i, f)
+            m[f, :pb["N"]] = mm
+        assert np.array_equal(out["bits"], _bits_of(m, npts)), i
+    for h in handles:
+        h.close()
+
+
 def test_async_path_refuses_what_it_cannot_do(wl):
     pbs = [wl.slam_problem(100, seed=1)]
     b = _new_batch(pbs, 100)
