@@ -179,6 +179,10 @@ struct Engine {
     UnaryTable deferred_tbl{};
     bool late_ok = false;              // set by the object API: single frame, automatic engine choice
     bool late_pending = false;
+    // Called by resolve_late() right behind a re-run of flagged frames (before its final synchronisation): the owner of host-side
+    // copies of the results (the batch's download pipe) re-queues them, whichever entry point happened to settle the run.
+    int (*after_rerun)(void *) = nullptr;
+    void *after_rerun_ctx = nullptr;
     // Per-frame fallback of the one-launch kernel: k_frame leaves 1 in frame_status[f] for a frame whose lattices do not
     // fit its LDS plan; resolve_late() gathers exactly those frames into the sub-engine `fb`, runs the two-kernel path
     // there and scatters Q / labels / V back.
@@ -914,6 +918,7 @@ struct Engine {
         }
         if (rc) return rc;
         if (timed_inf) HIP_TRY(hipEventRecord(ev[3], stream));   // the timed region now ends behind the re-run
+        if (after_rerun && (rc = after_rerun(after_rerun_ctx))) return rc;
         HIP_TRY(hipStreamSynchronize(stream));             // callers read borrowed device buffers right behind a synchronisation point
         return LCCRF_OK;
     }
@@ -1085,7 +1090,32 @@ int apply_option(Engine &e, int option, int value)
 class CopyPool {
 public:
     struct Job { char *dst; const char *src; size_t bytes; };
-    void run(const std::vector<Job> &arrays, int max_threads)
+    // Never throws (it sits under an extern "C" entry point): if a worker thread or the chunk list cannot be created
+    // (std::system_error, std::bad_alloc) the calling thread copies the arrays itself.
+    void run(const std::vector<Job> &arrays, int max_threads) noexcept
+    {
+        try {
+            run_pooled(arrays, max_threads);
+        } catch (...) {
+            {
+                std::lock_guard<std::mutex> g(m_);         // (nothing was published: the throwing statements come before jobs_ is set)
+                jobs_ = nullptr;
+            }
+            for (const Job &j : arrays) memcpy(j.dst, j.src, j.bytes);
+        }
+    }
+    ~CopyPool()
+    {
+        {
+            std::lock_guard<std::mutex> g(m_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        for (auto &t : workers_) t.join();
+    }
+
+private:
+    void run_pooled(const std::vector<Job> &arrays, int max_threads)
     {
         constexpr size_t kChunk = (size_t)512 << 10;
         std::vector<Job> chunks;
@@ -1114,17 +1144,6 @@ public:
         done_.wait(lk, [this] { return left_ == 0 && busy_ == 0; });
         jobs_ = nullptr;
     }
-    ~CopyPool()
-    {
-        {
-            std::lock_guard<std::mutex> g(m_);
-            stop_ = true;
-        }
-        cv_.notify_all();
-        for (auto &t : workers_) t.join();
-    }
-
-private:
     void take()
     {
         for (;;) {
@@ -1162,8 +1181,11 @@ private:
     unsigned long epoch_ = 0;
     bool stop_ = false;
 };
-CopyPool g_copy_pool;
-std::mutex g_copy_pool_user;                               // (one batch stages at a time; handles on other threads queue up)
+// One pool (and one staging lock) per DEVICE: a host with one thread per GPU (tools/replay_multi.cpp) stages its ranks' batches side by
+// side instead of queueing all of them behind one pool's workers; handles of one device still stage one at a time.
+constexpr int kCopyPools = 16;
+CopyPool g_copy_pool[kCopyPools];
+std::mutex g_copy_pool_user[kCopyPools];
 
 template <typename T>
 int pinned_plain(Arena &mem, T **out, size_t count)      // ordinary (cached, DMA-friendly) pinned memory owned by the arena
@@ -1784,17 +1806,20 @@ int lccrf_batch_set_inputs_host(lccrf_batch_handle b, int n_frames, const int32_
     return LCCRF_OK;
 }
 
+static int pipe_refresh_after_rerun(void *ctx);
+
 static int pipe_init(lccrf_batch *b)
 {
     HostPipe &p = b->pipe;
     if (p.up) return LCCRF_OK;
     Engine &e = b->eng;
+    e.after_rerun = pipe_refresh_after_rerun;
+    e.after_rerun_ctx = b;
     HIP_TRY(hipStreamCreateWithFlags(&p.up, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&p.down, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&p.ev_up, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&p.ev_down, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&p.ev_q, hipEventDisableTiming));
-    (void)e;
     return LCCRF_OK;
 }
 
@@ -1848,8 +1873,9 @@ int lccrf_batch_set_inputs_host_async(lccrf_batch_handle b, int n_frames, const 
             jobs.push_back({(char *)p.feat[k], (const char *)features[k], sizeof(float) * Fz * per * d});
             src_ft[k] = p.feat[k];
         }
-        std::lock_guard<std::mutex> g(g_copy_pool_user);
-        g_copy_pool.run(jobs, p.copy_threads);
+        const int pool = (e.device >= 0 ? e.device : 0) % kCopyPools;
+        std::lock_guard<std::mutex> g(g_copy_pool_user[pool]);
+        g_copy_pool[pool].run(jobs, p.copy_threads);
     }
     // the upload waits for everything queued on the batch's stream so far (a kernel of the previous batch may still read the
     // device copies), and whatever is queued from here on waits for the upload
@@ -1905,6 +1931,21 @@ static int pipe_queue_download(lccrf_batch *b, hipStream_t on)
     return LCCRF_OK;
 }
 
+// Engine::after_rerun of a batch with a download pipe: a queued download copied the results BEFORE the flagged frames were re-run
+// (whoever settled them -- lccrf_batch_get_fallback_frames, _synchronize, the next batch's inputs, ...): queue the copies again behind
+// the re-run on the batch's stream and move the "download landed" event there, so lccrf_batch_wait_download waits for the fresh ones.
+static int pipe_refresh_after_rerun(void *ctx)
+{
+    lccrf_batch *b = static_cast<lccrf_batch *>(ctx);
+    HostPipe &p = b->pipe;
+    if (!p.down_pending) return LCCRF_OK;
+    HIP_TRY(hipEventSynchronize(p.ev_down));           // (the first copies still own the pinned arrays)
+    int rc = pipe_queue_download(b, b->eng.stream);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(p.ev_down, b->eng.stream));
+    return LCCRF_OK;
+}
+
 int lccrf_batch_download_async(lccrf_batch_handle b, int what)
 {
     CHECK_H(b);
@@ -1944,15 +1985,12 @@ int lccrf_batch_wait_download(lccrf_batch_handle b, const uint64_t **label_bits,
     HostPipe &p = b->pipe;
     if (!p.down_pending) return fail(LCCRF_E_STATE, "no download queued (lccrf_batch_download_async)");
     HIP_TRY(hipEventSynchronize(p.ev_down));
-    p.down_pending = false;
-    // a one-launch run may have flagged frames that did not fit: they are re-run here (resolve_late), and then the copies are stale
-    const bool was_late = e.late_pending;
+    // a one-launch run may have flagged frames that did not fit: they are re-run at the first synchronisation point behind the launch
+    // -- here, or in any call made since lccrf_batch_download_async -- and the re-run queues the copies again (pipe_refresh_after_rerun)
     int rc = e.resolve_late();
-    if (rc) return rc;
-    if (was_late && e.fallback_frames > 0) {
-        if ((rc = pipe_queue_download(b, e.stream))) return rc;
-        HIP_TRY(hipStreamSynchronize(e.stream));
-    }
+    if (rc) { p.down_pending = false; return rc; }
+    HIP_TRY(hipEventSynchronize(p.ev_down));           // (re-recorded behind a re-run; otherwise already complete)
+    p.down_pending = false;
     if (label_bits) *label_bits = (p.down_what & LCCRF_DOWNLOAD_LABEL_BITS) ? p.bits : nullptr;
     if (words_per_frame) *words_per_frame = e.crf.bits_stride;
     if (map) *map = (p.down_what & LCCRF_DOWNLOAD_MAP) ? p.map : nullptr;
@@ -2082,8 +2120,12 @@ int lccrf_batch_run(lccrf_batch_handle b, int n_iterations, int with_map, float 
 int lccrf_batch_synchronize(lccrf_batch_handle b)
 {
     CHECK_H(b);
+    // Scoped to THIS batch: its stream (calls made on a caller's stream are ordered into it before they return) and its two copy
+    // streams.  Not hipDeviceSynchronize: a host that keeps several batches in flight (tools/replay_multi.cpp, tools/host_pipeline.cpp)
+    // settles one of them while the others' uploads and kernels keep running.
     HIP_TRY(hipStreamSynchronize(b->eng.stream));
-    HIP_TRY(hipDeviceSynchronize());
+    if (b->pipe.up) HIP_TRY(hipStreamSynchronize(b->pipe.up));
+    if (b->pipe.down) HIP_TRY(hipStreamSynchronize(b->pipe.down));
     return b->eng.resolve_late();
 }
 

@@ -43,7 +43,7 @@ constexpr size_t kLdsHalf = kLdsLimit / 2;
 #ifndef LCCRF_FUSE_XP
 #define LCCRF_FUSE_XP 1
 #endif
-constexpr bool kFuseXP = LCCRF_FUSE_XP != 0;     // A/B switch (scripts/gpu_ab.sh): products written right behind each point's softmax
+constexpr bool kFuseXP = LCCRF_FUSE_XP != 0;     // A/B switch (scripts/gpu_ab_build.sh): products written right behind each point's softmax
 #ifndef LCCRF_INSTRUMENT
 #define LCCRF_INSTRUMENT 0
 #endif

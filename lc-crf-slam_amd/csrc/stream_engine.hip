@@ -51,7 +51,7 @@ __device__ __forceinline__ FrameBlock frame_block(XcdMap m)
 }
 // lanes per workgroup of the iteration kernels: 256; with one or two frames in flight a pass is a chain of latencies and smaller
 // workgroups drain sooner (scripts/ubench/phasecost.hip: 256 -> 64 lanes 6.8 -> 6.4 us per pass of one C5 frame; in the engine,
-// `FRAMES=1 scripts/gpu_c5_env_ab.sh LCCRF_SMALL_F_BLOCK=256 ""`: one frame 41.0 -> 40.2 us per iteration, two 32.8 -> 32.1, four +-0)
+// `FRAMES=1 WORKLOAD=c5 scripts/gpu_env_ab.sh LCCRF_SMALL_F_BLOCK=256 ""`: one frame 41.0 -> 40.2 us per iteration, two 32.8 -> 32.1, four +-0)
 inline int iter_block(int F)
 {
     static const char *e = ab_env("LCCRF_SMALL_F_BLOCK");             // A/B switch: same results
@@ -1893,8 +1893,8 @@ __global__ void __launch_bounds__(kBlock) k_blur2x2t(KernelDev kd, const float *
     d[v] = make_float2(tv.x + 0.5f * (ta.x + tbv.x), tv.y + 0.5f * (ta.y + tbv.y));
 }
 
-constexpr int kSliceBlurMaxFrames = 1;       // the last blur pass inside the slice (k_slice2<D1, true>) when passes go one per launch, up to this many frames in flight (with the sorted build: two frames +2 % without it, four and eight +-0: `FRAMES=2 scripts/gpu_c5_env_ab.sh LCCRF_SLICE_BLUR_MAX=8 ""`)
-constexpr int kPairFuseMaxFrames = 1;        // (measured, `FRAMES=1 scripts/gpu_c5_env_ab.sh LCCRF_NO_PAIR_FUSE=1 ""`: one C5 frame 52.5 -> 45.2 us per iteration; two or four frames in flight: +-0)
+constexpr int kSliceBlurMaxFrames = 1;       // the last blur pass inside the slice (k_slice2<D1, true>) when passes go one per launch, up to this many frames in flight (with the sorted build: two frames +2 % without it, four and eight +-0: `FRAMES=2 WORKLOAD=c5 scripts/gpu_env_ab.sh LCCRF_SLICE_BLUR_MAX=8 ""`)
+constexpr int kPairFuseMaxFrames = 1;        // (measured, `FRAMES=1 WORKLOAD=c5 scripts/gpu_env_ab.sh LCCRF_NO_PAIR_FUSE=1 ""`: one C5 frame 52.5 -> 45.2 us per iteration; two or four frames in flight: +-0)
 // ... or, whatever the number of frames, when the launch is SMALL: up to ~0.7 M vertices over all frames (one C5 frame: 0.59 M; two: +-0)
 // the passes are launch- and latency-bound, e.g. 8 frames of 5000 points (30 000 vertices each): 9 launches of ~3.8 us per iteration
 constexpr long kPairFuseMaxVertices = 700000;

@@ -609,7 +609,7 @@ def test_streaming_engine_xcd_chunked_grid_below_eight_frames(po, wl, F):
     """Any number of frames in flight (round 4): the launch's blocks -- frame after frame -- are cut into eight contiguous parts,
     one per XCD, so with fewer than 8 frames an XCD holds a contiguous chunk of a frame's vertex / row / point range and with 3, 6,
     12, 13 frames a part spans a frame boundary.  Ragged frames, an empty one, on engine 1 against the oracle -- and the plain grid
-    (LCCRF_NO_XCD_CHUNK is read once per process, so the A/B itself is `FRAMES=1 scripts/gpu_c5_env_ab.sh LCCRF_NO_XCD_CHUNK=1 ""`;
+    (LCCRF_NO_XCD_CHUNK is read once per process, so the A/B itself is `FRAMES=1 WORKLOAD=c5 scripts/gpu_env_ab.sh LCCRF_NO_XCD_CHUNK=1 ""`;
     here the results must simply be the oracle's)."""
     sizes = [700, 333, 0, 699, 5, 512, 257, 700, 1, 650, 0, 300, 699][:F]
     maxN = 700

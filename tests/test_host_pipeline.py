@@ -159,6 +159,39 @@ def test_a_frame_that_falls_back_is_settled_by_wait_download(po, wl):
     b.close()
 
 
+@pytest.mark.parametrize("settler", ["fallback_frames", "synchronize", "engine", "next_inputs"])
+def test_a_fallback_settled_before_wait_download_still_refreshes_the_host_copies(po, wl, settler):
+    """any call between download_async and wait_download that settles the flagged frames (and clears the pending state)
+    used to leave the pinned copies at their pre-re-run bits.  The re-run itself now queues the copies again."""
+    pbs = [wl.slam_problem(900, seed=8300 + i) for i in range(40)]
+    pbs[17] = _shaped_problem(wl, 900, "sparse", seed=5)
+    maxN = 900
+    npts, feats, label = _arrays(pbs, maxN)
+    b = _new_batch(pbs, maxN)
+    b.set_inputs_host_async(npts, feats, label=label, conf=pbs[0]["conf"])
+    b.run(5, True)
+    b.download_async(pkg.BatchCRF.DOWNLOAD_LABEL_BITS | pkg.BatchCRF.DOWNLOAD_MAP | pkg.BatchCRF.DOWNLOAD_PROBABILITY)
+    if settler == "fallback_frames":
+        assert b.fallback_frames() == 1
+    elif settler == "synchronize":
+        b.synchronize()
+    elif settler == "engine":
+        assert b.engine() == 3
+    else:                                                   # the next batch's inputs arrive before the caller collects this one
+        pbs2 = [wl.slam_problem(900, seed=8400 + i) for i in range(40)]
+        n2, f2, l2 = _arrays(pbs2, maxN)
+        b.set_inputs_host_async(n2, f2, label=l2, conf=pbs[0]["conf"])
+    out = b.wait_download()
+    for f in (0, 16, 17, 18, 39):
+        o = cc.setup(po.OracleCRF, pbs[f])
+        o.inference_native(5, True)
+        assert cc.same_bits(out["prob"][f, :900], o.probability()), (settler, f)
+        assert np.array_equal(out["map"][f, :900], o.map()), (settler, f)
+        o.close()
+    assert np.array_equal(out["bits"], _bits_of(out["map"], npts))
+    b.close()
+
+
 def test_pipeline_of_256_frame_batches_runs_two_frames_per_cu_and_settles_its_fallbacks(po, wl):
     """From 256 frames per batch the one-launch kernel is csrc/frame_lean.hip (two frames per CU, records in the handle's own area): two
     handles round-robin, batches of ragged full-size frames with one frame that the half-CU plan cannot take in every batch -- every

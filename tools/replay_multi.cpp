@@ -144,9 +144,10 @@ struct Totals {
 //
 // Three rounds are in flight per rank, each on a batch handle and a stream of its own (slot = round mod 3):
 //     iteration t:   stage + upload + launch round t        lccrf_batch_set_inputs_host_async -> lccrf_batch_run
-//                    settle + gather round t-1              lccrf_batch_synchronize (frames the one-launch kernel could not take),
-//                                                           ncclAllGather of the label bits, its copy to the host and the
-//                                                           probabilities' download -- all queued, nothing waited for
+//                    settle + gather round t-1              lccrf_batch_synchronize: the host waits for round t-1's OWN streams (its kernel
+//                                                           has been running under the staging of round t) and re-runs the frames the
+//                                                           one-launch kernel could not take; then ncclAllGather of the label bits, its
+//                                                           copy to the host and the probabilities' download are queued, not waited for
 //                    check round t-2                        wait for ITS copies only, compare on the host
 // so round t's kernels run under round t-1's gather and round t+1's staging and upload: what an 8-GPU run then measures is the
 // split, not a serialised upload -> launch -> synchronise -> gather -> download per batch.
@@ -227,7 +228,7 @@ void rank_main(int rank, int G, int B, bool single_wg, bool serial, const std::v
             TRY_LCCRF(lccrf_batch_set_inputs_host_async(sl.b, B, npts.data(), nullptr, label.data(), conf, feats, 0));
             TRY_LCCRF(lccrf_batch_run(sl.b, (int)f0.h.n_iterations, 1, 1.0f, sl.stream));
         };
-        auto gather = [&](size_t t) {                       // settle + gather round t: queued, not waited for
+        auto gather = [&](size_t t) {                       // settle round t (a wait on ITS streams only), then gather: queued, not waited for
             Slot &sl = slots[t % kSlots];
             TRY_LCCRF(lccrf_batch_synchronize(sl.b));       // (settles frames the one-launch kernel could not take: the bits are complete behind this)
             // the path's one collective: every rank's bit-packed labels to every rank
