@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define LCCRF_ABI_VERSION 2   /* 2: lccrf_batch_get_fused_shape, the asynchronous host path of the batch API, lccrf_set_option's option 3 (LCCRF_OPT_COPY_THREADS) */
+#define LCCRF_ABI_VERSION 3   /* 3: lccrf_batch_last_prepare, lccrf_batch_synchronize scoped to the batch's streams; 2: lccrf_batch_get_fused_shape, the asynchronous host path of the batch API, lccrf_set_option's option 3 (LCCRF_OPT_COPY_THREADS) */
 #define LCCRF_MAX_KERNELS 8      /* pairwise terms per CRF                        */
 #define LCCRF_MAX_DIMS    8      /* feature dimensions per kernel (reference uses <= 6) */
 #define LCCRF_MAX_LABELS  64
@@ -287,6 +287,14 @@ int  lccrf_batch_get_locality_mode(lccrf_batch_handle b, int *internal_point_ord
  * on its stream, the number of launches of the dominant kernel and their summed
  * duration as seen by events around them (0 if not instrumented).                       */
 int  lccrf_batch_last_timing(lccrf_batch_handle b, float *inference_ms, float *build_ms);
+/* Batches of >= 256 two-kernel frames of 513 .. 2048 points run their inference two frames per CU from PREPARED launch records: what
+ * the kernel's prologue would derive from the lattices in every launch (the ranking and placement of the appearance kernel's rows,
+ * every point's vertex addresses and product slots, the row and neighbour tables in their on-chip form) is written once, by the
+ * FIRST lccrf_batch_inference behind a build, into one block per frame (<= 64 KB; allocated on that call, kept with the handle), and
+ * every later inference on those lattices starts from it.  It is part of the lattice construction (the PottsPotential3D ctor,
+ * pairwise3d.h:20-28), not of inference(): prepare_ms = HIP-event time of the last such launch (0 if none), runs = how many there
+ * were on this handle.  Results are identical with and without the records.                                                         */
+int  lccrf_batch_last_prepare(lccrf_batch_handle b, float *prepare_ms, int *runs);
 /* Measurement support: average HIP-event duration of `reps` launches of the streaming engine's dominant kernel (one
  * Jacobi blur pass of `kernel` over every frame of the batch, permutohedral_cpu.h:663-679) and the number of lattice
  * vertices one launch processes.  Needs lccrf_batch_build; leaves the CRF state (Q, labels) untouched.            */

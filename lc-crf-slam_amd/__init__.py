@@ -129,6 +129,7 @@ def lib():
     L.lccrf_batch_get_locality_mode.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.lccrf_batch_pose_set_crf_counts.argtypes = [vp, vp]
     L.lccrf_batch_last_timing.argtypes = [vp, _f32p, _f32p]
+    L.lccrf_batch_last_prepare.argtypes = [vp, _f32p, C.POINTER(C.c_int)]
     L.lccrf_batch_time_blur_pass.argtypes = [vp, C.c_int, C.c_int, _f32p, C.POINTER(C.c_int64)]
     L.lccrf_bf_match.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_double, _i32p, _i32p]
     L.lccrf_pose_optimization.argtypes = [C.c_int, C.c_int, _f32p, _f32p, _f32p, _f32p, C.c_void_p, _i16p, _f32p, C.c_float,
@@ -498,6 +499,12 @@ class BatchCRF:
         a, b = C.c_float(0), C.c_float(0)
         _check(lib().lccrf_batch_last_timing(self.h, C.byref(a), C.byref(b)))
         return dict(inference_ms=a.value, build_ms=b.value)
+
+    def last_prepare(self):
+        """(prepare_ms, runs) of the two-frames-per-CU kernel's prepared launch records (include/lccrf.h: lccrf_batch_last_prepare)."""
+        ms, n = C.c_float(0), C.c_int(0)
+        _check(lib().lccrf_batch_last_prepare(self.h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
 
 
 def lattice_filter(features, x, device=0):

@@ -152,6 +152,7 @@ struct Engine {
     int last_with_map = 0;             // did the last inference produce MAP labels?
     size_t fused_lds = 0;
     int fused_shape = 0;               // report only: what the last fused inference launched (launch_inference_fused)
+    LeanPrep lean_prep;                // prepared launch records of the two-frames-per-CU inference kernel (engine.h)
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   // build begin/end, inference begin/end
     hipEvent_t ev_order = nullptr;     // orders a caller-supplied stream against the engine's own (StreamScope)
     int *npoints_bad = nullptr;        // pinned: set by the validation kernel when a bound n_points[f] is outside [0, maxN]
@@ -343,6 +344,9 @@ struct Engine {
         for (auto &e : ev)
             if (e) (void)hipEventDestroy(e);
         if (ev_order) (void)hipEventDestroy(ev_order);
+        if (lean_prep.ev0) (void)hipEventDestroy(lean_prep.ev0);
+        if (lean_prep.ev1) (void)hipEventDestroy(lean_prep.ev1);
+        lean_prep = LeanPrep{};
         if (stream) (void)hipStreamDestroy(stream);
         stream = nullptr;
     }
@@ -674,6 +678,7 @@ struct Engine {
         }
         sync_views();
         sizes_known = true;
+        lean_prep.valid = false;                           // (every path that changes a lattice clears sizes_known and so comes through here)
         sized_engine = 1;
         if (engine_pref != 1 && !perm_on && fused_supported(crf, kdevs.data(), maxV.data(), maxRow.data(), &fused_lds)) sized_engine = 2;
         if (engine_pref == 2 && sized_engine != 2)
@@ -858,7 +863,27 @@ struct Engine {
             if (with_map) launch_map(crf, stream);
             started = true;
         } else if (sized_engine == 2) {
-            fused_shape = launch_inference_fused(crf, kdevs.data(), maxV.data(), maxRow.data(), n_iter, with_map, relax, stream);
+            // the two-frames-per-CU kernel runs from prepared launch records (fused_lean.h: LeanPrepPlan): one block per frame, owned
+            // here, (re)written by the first inference behind a build -- learn_sizes() clears `valid` whenever a lattice has changed
+            const size_t prep_need = lean_prep_bytes(crf, kdevs.data(), maxV.data(), maxRow.data());
+            if (prep_need > lean_prep.bytes) {
+                lean_prep.valid = false;
+                lean_prep.buf = nullptr;                       // (an outgrown block stays with the arena until the handle goes)
+                lean_prep.bytes = 0;
+                unsigned char *p = nullptr;
+                if (mem.alloc(&p, prep_need, false) == LCCRF_OK) {
+                    lean_prep.buf = p;
+                    lean_prep.bytes = prep_need;
+                } else {
+                    (void)hipGetLastError();                   // no room: the self-contained kernel runs instead, same results
+                }
+                if (!lean_prep.ev0) {
+                    (void)hipEventCreate(&lean_prep.ev0);
+                    (void)hipEventCreate(&lean_prep.ev1);
+                }
+            }
+            fused_shape = launch_inference_fused(crf, kdevs.data(), maxV.data(), maxRow.data(), n_iter, with_map, relax, stream,
+                                                 prep_need ? &lean_prep : nullptr);
             started = true;
         } else {
             if ((rc = start())) return rc;
@@ -2433,6 +2458,22 @@ int lccrf_batch_last_timing(lccrf_batch_handle b, float *inference_ms, float *bu
         *inference_ms = 0.0f;
         if (e.timed_inf) HIP_TRY(hipEventElapsedTime(inference_ms, e.ev[2], e.ev[3]));
     }
+    return LCCRF_OK;
+}
+
+int lccrf_batch_last_prepare(lccrf_batch_handle b, float *prepare_ms, int *runs)
+{
+    CHECK_H(b);
+    Engine &e = b->eng;
+    { int rl = e.resolve_late(); if (rl) return rl; }
+    if (prepare_ms) {
+        *prepare_ms = 0.0f;
+        if (e.lean_prep.timed) {
+            HIP_TRY(hipEventSynchronize(e.lean_prep.ev1));
+            HIP_TRY(hipEventElapsedTime(prepare_ms, e.lean_prep.ev0, e.lean_prep.ev1));
+        }
+    }
+    if (runs) *runs = (int)e.lean_prep.runs;
     return LCCRF_OK;
 }
 

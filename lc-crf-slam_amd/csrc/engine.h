@@ -204,8 +204,20 @@ void launch_build_small(const KernelDev *kds, int n, int max_points, const CrfDe
 bool fused_supported(const CrfDev &c, const KernelDev *kds, const int *maxV, const int *maxRow,
                      size_t *lds_bytes);
 // returns the shape it launched: lanes per workgroup (= per frame) | workgroups per CU << 16 (0: nothing launched)
+// prep (optional): the batch's prepared launch records of the two-frames-per-CU kernel (fused_lean.h: LeanPrepPlan) -- `buf` of
+// `bytes` bytes owned by the caller (lean_prep_bytes(): what the current batch needs, 0 when the plan does not apply); the call
+// fills them when !valid (the caller clears `valid` whenever a lattice changes) and records ev0 / ev1 around that launch.
+struct LeanPrep {
+    unsigned char *buf = nullptr;
+    size_t bytes = 0;
+    bool valid = false, timed = false;
+    unsigned long long key = 0;
+    unsigned runs = 0;                    // how many times the blocks were (re)written: tests
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+size_t lean_prep_bytes(const CrfDev &c, const KernelDev *kds, const int *maxV, const int *maxRow);
 int launch_inference_fused(const CrfDev &c, const KernelDev *kds, const int *maxV, const int *maxRow,
-                           int n_iter, int with_map, float relax, hipStream_t s);
+                           int n_iter, int with_map, float relax, hipStream_t s, LeanPrep *prep = nullptr);
 
 // ---- frame engine (SLAM sizes; lattice build + normalisation + inference of a frame in ONE launch) ---------
 bool frame_supported(const CrfDev &c, const KernelDev *kds);

@@ -41,6 +41,9 @@ struct FusedArgs {
     long long *timing;                    // instrumented builds: shader-clock stamps of one workgroup (LCCRF_FUSED_TIMING=<block index + 1>)
     int timing_block, timing_lane;
     int dbg;                              // instrumented builds: LCCRF_FUSED_DBG (see fused_loop.h)
+    unsigned char *prep;                  // lean plan: the frames' prepared launch records (fused_lean.h: LeanPrepPlan), prep_stride bytes each
+    int prep_stride;
+    int Vcap[kMaxFusedK];                 // the vertex counts the LDS plan was sized for (maxima over the batch)
 };
 
 // One workgroup per frame.  Lane t owns points t, t+NT, ... (PPT of them); the per-frame records a build
@@ -176,7 +179,10 @@ __global__ void __launch_bounds__(NT, 4) k_fused(CrfDev c, FusedArgs a)
 // The same inference on HALF a CU's LDS (fused_lean.h): frames of 1025 .. ~2300 keypoints, two workgroups per CU.
 //   NT = 512 (8 wavefronts, 4 per SIMD with both workgroups resident: 128 registers per lane), 3 or 4 points per lane;
 //   RELOAD: unary energies, barycentric weights and norms are re-read every iteration instead of kept in registers
-template <int NT, int PPT, int K, int CH, bool RELOAD>
+//   MODE  0: the prologue derives everything from the build's records (ranking, placement, table conversion) in every launch;
+//         1: that prologue ONLY -- its results go to the frame's prepared block (fused_lean.h: LeanPrepPlan), once per build;
+//         2: the prologue is a handful of coalesced loads of that block (what an inference runs from the second launch on)
+template <int NT, int PPT, int K, int CH, bool RELOAD, int MODE>
 __global__ void __launch_bounds__(NT, NT == 384 ? 3 : 4) k_fused_lean(CrfDev c, FusedArgs a)
 {
     constexpr int D1 = kD1;
@@ -206,6 +212,78 @@ __global__ void __launch_bounds__(NT, NT == 384 ? 3 : 4) k_fused_lean(CrfDev c, 
         return;
     }
     const FusedLayout &lay = a.lay;
+
+    if constexpr (MODE == 2) {
+        // ---- prologue from the prepared block: every load below depends on the frame index only ------------------------------------
+        float wk[K];
+        LeanSrc src;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const KernelDev &kd = a.kd[k];
+            wk[k] = kd.w;
+            src.nbr[k] = lean_rsrc(kd.nbr16 + (size_t)f * D1 * kd.Epad, (size_t)D1 * kd.Epad * 4);
+            src.bary[k] = lean_rsrc(kd.bary + (size_t)f * kd.Epad, (size_t)kd.Epad * 4);
+            src.norm[k] = lean_rsrc(kd.norm + (size_t)f * kd.maxN, (size_t)kd.maxN * 4);
+            src.nbr_axis_bytes[k] = kd.Epad * 4;
+            src.off_nbr[k] = src.off_bary[k] = src.off_norm[k] = 0;
+        }
+        src.unary = lean_rsrc(c.unary + (size_t)f * c.maxN * 2, (size_t)c.maxN * 8);
+        src.off_unary = 0;
+        const LeanPrepPlan pp = lean_prep_plan(lay, K, a.Vcap, NT, PPT);
+        const __amdgpu_buffer_rsrc_t rp = lean_rsrc(a.prep + (size_t)f * a.prep_stride, (size_t)a.prep_stride);
+        typedef unsigned lean_u2 __attribute__((ext_vector_type(2)));
+        typedef unsigned lean_u4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+        for (int s = 0; s < PPT; ++s) {
+            const lean_u2 u = __builtin_amdgcn_raw_buffer_load_b64(src.unary, (tid + s * NT) * 8, 0, 0);   // (a lane past the frame reads 0 or a spare row: unused)
+            pr.un[s] = make_float2(__uint_as_float(u.x), __uint_as_float(u.y));
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const lean_u3 w = __builtin_amdgcn_raw_buffer_load_b96(rp, tid * 12, ((s * K + k) * NT) * 12, 0);
+                pr.ix[s][k][0] = w.x;
+                pr.ix[s][k][1] = w.y;
+                pr.ix[s][k][2] = w.z;
+                if (!RELOAD) {
+                    const lean_u3 b = __builtin_amdgcn_raw_buffer_load_b96(src.bary[k], (tid + s * NT) * (D1 * 4), 0, 0);
+                    pr.bary[s][k][0] = __uint_as_float(b.x);
+                    pr.bary[s][k][1] = __uint_as_float(b.y);
+                    pr.bary[s][k][2] = __uint_as_float(b.z);
+                    pr.wn[s][k] = wk[k] * __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(src.norm[k], (tid + s * NT) * 4, 0, 0));   // pairwise3d.h:77
+                }
+            }
+        }
+        const lean_u2 clw = __builtin_amdgcn_raw_buffer_load_b64(rp, tid * 8, pp.cl_off, 0);
+#pragma unroll
+        for (int k = 0; k < K; ++k) {                     // the LDS tables, 16 bytes per lane and trip
+            for (int b = tid * 16; b < pp.row_bytes[k]; b += NT * 16)
+                *reinterpret_cast<lean_u4 *>(smem + lay.row[k] + b) = __builtin_amdgcn_raw_buffer_load_b128(rp, b, pp.row_off[k], 0);
+            for (int b = tid * 16; b < pp.nbr_bytes[k]; b += NT * 16)
+                *reinterpret_cast<lean_u4 *>(smem + lay.nbr[k] + b) = __builtin_amdgcn_raw_buffer_load_b128(rp, b, pp.nbr_off[k], 0);
+        }
+        if (tid < 32) reinterpret_cast<float *>(smem + lay.zero)[tid] = 0.0f;
+        if (tid == 0) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                reinterpret_cast<float2 *>(smem + lay.val[k][0])[0] = make_float2(0.f, 0.f);
+                reinterpret_cast<float2 *>(smem + lay.val[k][1])[0] = make_float2(0.f, 0.f);
+            }
+        }
+        __syncthreads();
+        FL_PSTAMP();
+        ChainLane cl{clw.x, clw.y};
+        start_inference<PPT, K, NT>(pr, N, tid);
+        FL_STAMP();
+        float alpha[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) alpha[k] = a.kd[k].alpha;
+        int t = lane_id();
+        mean_field_lean<PPT, K, CH, NT, RELOAD>(smem, lay, V, N, t, pr, cl, alpha, wk, src, a.n_iter, a.relax, a.omr, ins);
+        t = lane_id();
+        store_results<PPT, K, NT>(c, fo, N, t, pr, a.with_map);
+        FL_STAMP();
+        if (kInstr && a.timing && (int)blockIdx.x == a.timing_block && t == a.timing_lane) a.timing[63] = ins.n;
+        return;
+    }
 
     // per-point records first (the long pole of the prologue), then the lattice tables
     unsigned pk[PPT][K][D1];              // (vertex id + 1) | place in the row << 16
@@ -239,12 +317,12 @@ __global__ void __launch_bounds__(NT, NT == 384 ? 3 : 4) k_fused_lean(CrfDev c, 
 #pragma unroll
             for (int j = 0; j < D1; ++j) {
                 pk[s][k][j] = kd.pk[e0 + j];
-                if (!RELOAD) pr.bary[s][k][j] = gbary[k][(size_t)ic * D1 + j];
+                if (!RELOAD && MODE != 1) pr.bary[s][k][j] = gbary[k][(size_t)ic * D1 + j];
             }
-            if (!RELOAD) pr.wn[s][k] = gnorm[k][ic];
+            if (!RELOAD && MODE != 1) pr.wn[s][k] = gnorm[k][ic];
         }
     }
-    if (!RELOAD) {
+    if (!RELOAD && MODE != 1) {
 #pragma unroll
         for (int s = 0; s < PPT; ++s)
 #pragma unroll
@@ -278,9 +356,32 @@ __global__ void __launch_bounds__(NT, NT == 384 ? 3 : 4) k_fused_lean(CrfDev c, 
     ChainLane cl{0u, 0u};
     if (CH != 0 && chain_k<CH>(lay, 0)) cl = chain_setup_lean<NT>(smem, lay, V[0], tid);
     FL_PSTAMP();
-    start_inference<PPT, K, NT>(pr, N, tid);
+    if (MODE != 1) start_inference<PPT, K, NT>(pr, N, tid);
     place_products_lean<PPT, K, CH, NT>(smem, lay, N, tid, pk, pr);
     FL_STAMP();
+    if constexpr (MODE == 1) {
+        // ---- the prepared block of this frame: ix words, chain lanes, LDS tables (LeanPrepPlan) ---------------------------------------
+        const LeanPrepPlan pp = lean_prep_plan(lay, K, a.Vcap, NT, PPT);
+        unsigned char *pf = a.prep + (size_t)fo * a.prep_stride;
+#pragma unroll
+        for (int s = 0; s < PPT; ++s)
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                unsigned *w = reinterpret_cast<unsigned *>(pf) + ((size_t)(s * K + k) * NT + tid) * 3;
+                w[0] = pr.ix[s][k][0];
+                w[1] = pr.ix[s][k][1];
+                w[2] = pr.ix[s][k][2];
+            }
+        reinterpret_cast<uint2 *>(pf + pp.cl_off)[tid] = make_uint2(cl.a, cl.b);
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            for (int b = tid * 16; b < pp.row_bytes[k]; b += NT * 16)
+                *reinterpret_cast<uint4 *>(pf + pp.row_off[k] + b) = *reinterpret_cast<const uint4 *>(smem + lay.row[k] + b);
+            for (int b = tid * 16; b < pp.nbr_bytes[k]; b += NT * 16)
+                *reinterpret_cast<uint4 *>(pf + pp.nbr_off[k] + b) = *reinterpret_cast<const uint4 *>(smem + lay.nbr[k] + b);
+        }
+        return;
+    }
 
     float alpha[K];
 #pragma unroll
@@ -355,24 +456,41 @@ bool lean_layout(const CrfDev &c, const KernelDev *kds, const int *maxV, const i
 // buffer in fused_loop.h's loop as well: 2.04e7 against 2.42e7 iterations/s.  With nobody else on the CU the re-reads' latency and the
 // seven barriers are all exposed; the plan pays through co-residency, not through its schedule alone.)
 
-template <int NT, int PPT, int K, int CH, bool RELOAD>
-void launch_lean(const CrfDev &c, const FusedArgs &a, hipStream_t s)
+template <int NT, int PPT, int K, int CH, bool RELOAD, int MODE>
+void launch_lean_mode(const CrfDev &c, const FusedArgs &a, hipStream_t s)
 {
-    auto fn = k_fused_lean<NT, PPT, K, CH, RELOAD>;
+    auto fn = k_fused_lean<NT, PPT, K, CH, RELOAD, MODE>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit);
     fn<<<dim3(c.F), dim3(NT), a.lay.total, s>>>(c, a);
 }
 
+// mode: 0 the self-contained kernel, 1 prepare, 2 run from the prepared blocks
+template <int NT, int PPT, int K, int CH, bool RELOAD>
+void launch_lean(const CrfDev &c, const FusedArgs &a, hipStream_t s, int mode)
+{
+    if (mode == 2) launch_lean_mode<NT, PPT, K, CH, RELOAD, 2>(c, a, s);
+    else if (mode == 1) launch_lean_mode<NT, PPT, K, CH, RELOAD, 1>(c, a, s);
+    else launch_lean_mode<NT, PPT, K, CH, RELOAD, 0>(c, a, s);
+}
+
 template <int NT, int PPT, bool RELOAD>
-void launch_lean_ppt(const CrfDev &c, const FusedArgs &a, hipStream_t s)
+void launch_lean_ppt(const CrfDev &c, const FusedArgs &a, hipStream_t s, int mode)
 {
     if (c.K == 1) {
-        if (a.lay.chain0) launch_lean<NT, PPT, 1, 1, RELOAD>(c, a, s);
-        else launch_lean<NT, PPT, 1, 0, RELOAD>(c, a, s);
+        if (a.lay.chain0) launch_lean<NT, PPT, 1, 1, RELOAD>(c, a, s, mode);
+        else launch_lean<NT, PPT, 1, 0, RELOAD>(c, a, s, mode);
     } else {
-        if (a.lay.chain0) launch_lean<NT, PPT, 2, 1, RELOAD>(c, a, s);
-        else launch_lean<NT, PPT, 2, 0, RELOAD>(c, a, s);
+        if (a.lay.chain0) launch_lean<NT, PPT, 2, 1, RELOAD>(c, a, s, mode);
+        else launch_lean<NT, PPT, 2, 0, RELOAD>(c, a, s, mode);
     }
+}
+
+void launch_lean_any(const CrfDev &c, const FusedArgs &a, hipStream_t s, int mode, int NAp)
+{
+    if (NAp <= 512) launch_lean_ppt<512, 1, false>(c, a, s, mode);
+    else if (NAp <= 2 * 512) launch_lean_ppt<512, 2, false>(c, a, s, mode);
+    else if (NAp <= 3 * 512) launch_lean_ppt<512, 3, true>(c, a, s, mode);
+    else launch_lean_ppt<512, 4, true>(c, a, s, mode);
 }
 
 template <int NT, int PPT, int K, int CH>
@@ -407,8 +525,21 @@ bool fused_supported(const CrfDev &c, const KernelDev *kds, const int *maxV, con
     return ok;
 }
 
+size_t lean_prep_bytes(const CrfDev &c, const KernelDev *kds, const int *maxV, const int *maxRow)
+{
+    // (the shape decision of launch_inference_fused)
+    FusedLayout lay, other;
+    int nt = 0;
+    const int NAp = c.activeN > 0 ? c.activeN : c.maxN;
+    const bool lean_first = NAp <= 2 * kNTSmall && lean_layout(c, kds, maxV, maxRow, &lay, &nt);
+    const bool small = !lean_first && small_layout(c, kds, maxV, maxRow, &other);
+    if (!(lean_first || (!small && lean_layout(c, kds, maxV, maxRow, &lay, &nt)))) return 0;
+    const LeanPrepPlan pp = lean_prep_plan(lay, c.K, maxV, 512, NAp <= 512 ? 1 : (NAp + 511) / 512);
+    return (size_t)pp.total * (size_t)c.F;
+}
+
 int launch_inference_fused(const CrfDev &c, const KernelDev *kds, const int *maxV, const int *maxRow, int n_iter,
-                           int with_map, float relax, hipStream_t s)
+                           int with_map, float relax, hipStream_t s, LeanPrep *prep)
 {
     FusedArgs a{};
     int lean_nt = 0;
@@ -438,10 +569,34 @@ int launch_inference_fused(const CrfDev &c, const KernelDev *kds, const int *max
         if (NAp <= kNTSmall) launch_fused_ppt<kNTSmall, 1>(c, a, s);
         else launch_fused_ppt<kNTSmall, 2>(c, a, s);
     } else if (lean) {
-        if (NAp <= 512) launch_lean_ppt<512, 1, false>(c, a, s);
-        else if (NAp <= 2 * 512) launch_lean_ppt<512, 2, false>(c, a, s);
-        else if (NAp <= 3 * 512) launch_lean_ppt<512, 3, true>(c, a, s);
-        else launch_lean_ppt<512, 4, true>(c, a, s);
+        // prepared launch records (fused_lean.h: LeanPrepPlan): written by the first inference behind a build, read by every one after it
+        const int ppt = NAp <= 512 ? 1 : (NAp + 511) / 512;
+        for (int k = 0; k < c.K; ++k) a.Vcap[k] = maxV[k];
+        const LeanPrepPlan pp = lean_prep_plan(a.lay, c.K, a.Vcap, 512, ppt);
+        static const bool no_prep = ab_env("LCCRF_NO_LEAN_PREP") != nullptr;    // A/B switch (instrumented library): same results either way
+        int mode = 0;
+        if (prep && prep->buf && !no_prep && (size_t)pp.total <= kLeanPrepMaxBytes && (size_t)pp.total * (size_t)c.F <= prep->bytes) {
+            // what the blocks depend on besides the lattices themselves: the plan, the shape, the frame count
+            unsigned long long key = 1469598103934665603ull;
+            auto mix = [&](const void *p, size_t n) { for (size_t i = 0; i < n; ++i) key = (key ^ static_cast<const unsigned char *>(p)[i]) * 1099511628211ull; };
+            mix(&a.lay, sizeof(a.lay));
+            mix(a.Vcap, sizeof(int) * c.K);
+            const int shape[4] = {c.F, c.K, ppt, NAp};
+            mix(shape, sizeof(shape));
+            a.prep = prep->buf;
+            a.prep_stride = pp.total;
+            if (!prep->valid || prep->key != key) {
+                if (prep->ev0) (void)hipEventRecord(prep->ev0, s);
+                launch_lean_any(c, a, s, 1, NAp);
+                if (prep->ev1) (void)hipEventRecord(prep->ev1, s);
+                prep->timed = prep->ev0 && prep->ev1;
+                prep->valid = true;
+                prep->key = key;
+                ++prep->runs;
+            }
+            mode = 2;
+        }
+        launch_lean_any(c, a, s, mode, NAp);
     } else {
         switch ((NAp + kNT - 1) / kNT) {
         case 1: launch_fused_ppt<kNT, 1>(c, a, s); break;

@@ -405,6 +405,42 @@ __device__ __forceinline__ void opaque_ids(PointRegs<PPT, K> &pr)
     }
 }
 
+// ---- prepared launch records (round 6) -----------------------------------------------------------------------------------------
+// What the prologue of k_fused_lean derives from a frame's lattice and the batch's LDS plan -- the ranking of the chain rows and
+// their placement (chain_setup_lean: six barriers, LDS atomics, two scans), every point's vertex addresses and product slots
+// (place_products_lean), the u16 row table and the chain kernel's neighbour table -- is the same in every inference on that lattice.
+// It is computed ONCE behind a build (k_fused_lean<.., MODE 1>, the first inference after lccrf_batch_build) into one block per frame:
+//     [ix   : (s, k, lane) x 3 words]   the final PointRegs::ix, 12 bytes per (point slot, kernel, lane), lane-contiguous
+//     [cl   : lane x 2 words]           the lane's ChainLane
+//     [row k, nbr k for every kernel]   the bytes of the LDS tables, each padded to 16
+// and an inference (MODE 2) starts with coalesced loads that depend on nothing but the frame index: no load waits for the frame's
+// point count, nothing is ranked, placed or converted.  Stamps of one steady-state C2 workgroup (profiles/r6_fused_c2/stamps.txt):
+// first barrier 16.5k -> see there, ranking 4.9k -> 0, placement 3.0k -> 0 of a workgroup's ~135k cycles.
+struct LeanPrepPlan {
+    int cl_off;
+    int row_off[kMaxFusedK], row_bytes[kMaxFusedK];
+    int nbr_off[kMaxFusedK], nbr_bytes[kMaxFusedK];     // nbr_bytes = 0: the kernel's table is not in LDS
+    int total;                                           // multiple of 256
+};
+__host__ __device__ inline LeanPrepPlan lean_prep_plan(const FusedLayout &lay, int K, const int *Vcap, int nt, int ppt)
+{
+    LeanPrepPlan p{};
+    int o = K * ppt * nt * 12;
+    p.cl_off = o;
+    o += nt * 8;
+    for (int k = 0; k < K; ++k) {
+        p.row_off[k] = o;
+        p.row_bytes[k] = ((Vcap[k] + 2) * 2 + 15) & ~15;
+        o += p.row_bytes[k];
+        p.nbr_off[k] = o;
+        p.nbr_bytes[k] = lay.nbr[k] >= 0 ? ((kD1 * Vcap[k] * 4 + 15) & ~15) : 0;
+        o += p.nbr_bytes[k];
+    }
+    p.total = (o + 255) & ~255;
+    return p;
+}
+constexpr size_t kLeanPrepMaxBytes = 64 * 1024;        // per frame, whatever the plan: 2 kernels x 4 slots x 512 lanes x 12 + 4 KB + tables < 8 KB
+
 // n_iter x stepInference on the lean plan.  Per iteration, between workgroup barriers:
 //   [X: slice + apply + softmax of every point, its products for kernel K-1 right behind]  |  S(K-1)  |  P(k) | S(k) for k = K-2 .. 0  |
 //   blur pass 0 | 1 | 2 (every kernel)

@@ -36,7 +36,7 @@ def test_header_declares_the_reference_operator_surface():
 def test_library_exports_every_declared_symbol(lib):
     missing = [n for n in declared_symbols() if not hasattr(lib, n)]
     assert not missing, missing
-    assert lib.lccrf_abi_version() == 2
+    assert lib.lccrf_abi_version() == 3
 
 
 def test_python_binding_covers_every_declared_symbol(lib):

@@ -592,9 +592,10 @@ def test_two_label_softmax_dense_sweep(po, wl, N):
     b.close()
 
 
-@pytest.mark.parametrize("shape", ["", "2"])
+@pytest.mark.parametrize("shape", ["", "2", "2-noprep"])
 def test_full_size_frames_share_a_cu_and_give_the_same_bits(po, wl, shape):
-    """shape "" = the RELEASE library (liblccrf_hip.so, environment untouched: the default shape is the lean one), "2" = the same
+    """"2-noprep" = the self-contained kernel (no prepared launch records, round 6: LCCRF_NO_LEAN_PREP) in the instrumented twin;
+    shape "" = the RELEASE library (liblccrf_hip.so, environment untouched: the default shape is the lean one), "2" = the same
     shape selected by switch in the instrumented twin (the sweep has to hit the shipped object too).
     Round 5: frames of 1025 .. ~2300 points run TWO per CU as well when a batch has at least 256 frames -- the lean plan of
     csrc/fused_lean.h (one shared product buffer, the large lattice's neighbour table read from HBM/L2, chain rows placed by a scan;
@@ -606,7 +607,7 @@ sys.path.insert(0, %r); sys.path.insert(0, %r); sys.path.insert(0, %r)
 import crf_cases as cc, pyoracle as po
 from test_frame_engine import _batch_of
 wl = importlib.import_module("lc-crf-slam_amd.workloads")
-lanes = 512 if %r in ("", "2") else 384
+lanes = 512 if %r in ("", "2", "2-noprep") else 384
 top = 2048 if lanes == 512 else 2304
 sizes = [2000, 1025, 1536, 1537, 1999, top, 1100, 1920, 1921, top - 1, 0, 700, 1152, 1153, 3, 2001]
 base = [wl.slam_problem(n, seed=5100 + i) for i, n in enumerate(sizes)]
@@ -660,11 +661,72 @@ for pick in ((0,), (1,), (1, 1)):
         o.close()
 print("ok")
 """ % (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle"), shape)
-    env = cc.switch_env(LCCRF_LEAN_SHAPE=shape) if shape else dict(os.environ)
+    env = dict(os.environ)
+    if shape == "2-noprep":
+        env = cc.switch_env(LCCRF_LEAN_SHAPE="2", LCCRF_NO_LEAN_PREP="1")
+    elif shape:
+        env = cc.switch_env(LCCRF_LEAN_SHAPE=shape)
     if not shape:
         assert "LCCRF_LIB" not in env and "LCCRF_LEAN_SHAPE" not in env
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_prepared_launch_records_follow_the_lattices_and_not_the_unaries(po, wl):
+    """Round 6 (fused_lean.h: LeanPrepPlan): the two-frames-per-CU inference kernel starts from per-frame blocks the FIRST inference
+    behind a build writes (ranking / placement of the chain rows, vertex addresses, product slots, the LDS tables).  They must be
+    rewritten when -- and only when -- a lattice changes; unary energies are inputs of every launch, not of the blocks."""
+    F, maxN = 264, 2048
+    def batch(seed0):
+        sizes = [2000, 1300, 1999, 1100, 2048, 1537, 3, 0]
+        return [wl.slam_problem(sizes[f % 8], seed=seed0 + f % 8) for f in range(F)]
+
+    def check(b, pbs, n_iter, tag, conf=None):
+        Q, M = b.probability(), b.map()
+        for f in list(range(8)) + [F - 8 + i for i in range(8)]:
+            pb = dict(pbs[f])
+            if conf is not None:
+                pb["conf"] = conf
+            o = cc.setup(po.OracleCRF, pb)
+            o.inference_native(n_iter, True)
+            assert cc.same_bits(Q[f, :pb["N"]], o.probability()), (tag, f)
+            assert np.array_equal(M[f, :pb["N"]], o.map()), (tag, f)
+            o.close()
+
+    pbs = batch(9100)
+    b = _batch_of(pbs, maxN=maxN)
+    assert b.last_prepare()[1] == 0
+    b.build()
+    b.inference(5, True)
+    assert b.engine() == 2 and b.fused_shape() == (512, 2)
+    ms, runs = b.last_prepare()
+    assert runs == 1 and ms > 0
+    check(b, pbs, 5, "first")
+    b.inference(3, True)                                     # same lattices: the blocks are reused
+    assert b.last_prepare()[1] == 1
+    check(b, pbs, 3, "second")
+    # other unaries (another confidence) on the SAME lattices: no rebuild, no new blocks, new results
+    feats = [np.stack([np.pad(pb["kernels"][k][0], ((0, maxN - pb["N"]), (0, 0))) for pb in pbs]) for k in range(2)]
+    label = np.stack([np.pad(pb["label"], (0, maxN - pb["N"]), constant_values=-1) for pb in pbs]).astype(np.int16)
+    # (new inputs through the host path invalidate the lattices: build again, then compare the run counter)
+    b.set_inputs_host([pb["N"] for pb in pbs], feats, label=label, conf=0.9)
+    b.build()
+    b.inference(5, True)
+    assert b.last_prepare()[1] == 2
+    check(b, pbs, 5, "conf 0.9", conf=np.float32(0.9))
+    # other frames: the lattices change, the blocks are rewritten
+    pbs2 = batch(9200)
+    feats2 = [np.stack([np.pad(pb["kernels"][k][0], ((0, maxN - pb["N"]), (0, 0))) for pb in pbs2]) for k in range(2)]
+    label2 = np.stack([np.pad(pb["label"], (0, maxN - pb["N"]), constant_values=-1) for pb in pbs2]).astype(np.int16)
+    b.set_inputs_host([pb["N"] for pb in pbs2], feats2, label=label2, conf=pbs2[0]["conf"])
+    b.build()
+    b.inference(5, True)
+    assert b.last_prepare()[1] == 3
+    check(b, pbs2, 5, "other frames")
+    b.inference(5, True)
+    assert b.last_prepare()[1] == 3
+    check(b, pbs2, 5, "other frames, again")
+    b.close()
 
 
 def test_full_size_frames_share_a_cu_in_the_one_launch_kernel(po, wl):

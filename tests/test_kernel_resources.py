@@ -55,10 +55,12 @@ def test_two_full_size_frames_per_cu_fit_the_register_file_without_scratch():
     The rings of the ordered row sums clobber v96..v127; what must survive them passes through the asm statements as operands."""
     use = resource_usage("fused_engine.hip")
     lean = {k: v for k, v in use.items() if "k_fused_leanI" in k}
-    assert len(lean) == 16                                    # PPT 1..4 x K 1..2 x {short rows, chain} (PPT <= 2: everything in registers)
+    # PPT 1..4 x K 1..2 x {short rows, chain} (PPT <= 2: everything in registers) x MODE {0 self-contained, 1 prepare, 2 from the
+    # prepared launch records (round 6)}
+    assert len(lean) == 48
     for name, r in lean.items():
-        nt, ppt = (int(x) for x in re.search(r"k_fused_leanILi(\d+)ELi(\d)E", name).groups())
-        assert nt == 512 and ppt in (1, 2, 3, 4)
+        nt, ppt, mode = (int(x) for x in re.search(r"k_fused_leanILi(\d+)ELi(\d)ELi\dELi\dELb\dELi(\d)E", name).groups())
+        assert nt == 512 and ppt in (1, 2, 3, 4) and mode in (0, 1, 2)
         assert r["VGPRs"] + r.get("AGPRs", 0) <= 128, name
         assert r["ScratchSize [bytes/lane]"] == 0 and r["VGPRs Spill"] == 0, (name, r)
 
