@@ -207,14 +207,12 @@ __global__ void __launch_bounds__(NT, NT == 384 ? 3 : 4) k_fused_lean(CrfDev c, 
         asm volatile("" : "+v"(z));
         return wave_base + (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, (unsigned)z));
     };
-    if (N <= 0) {
-        if (a.with_map) clear_label_bits<NT>(c, fo, 0, lane_id());
-        return;
-    }
     const FusedLayout &lay = a.lay;
-
     if constexpr (MODE == 2) {
-        // ---- prologue from the prepared block: every load below depends on the frame index only ------------------------------------
+        // ---- prologue from the prepared block: every load below depends on the frame index only, so all of them -- the words, the
+        // chain lane, the tables, the unary energies and the FIRST iteration's weights and norms -- are in flight at once: one round
+        // trip to HBM / L2 between the kernel's start and its first barrier (the self-contained prologue pays four or five: the point
+        // count, the records, the table conversion loops one after the other, then the loop's first re-read)
         float wk[K];
         LeanSrc src;
 #pragma unroll
@@ -235,30 +233,44 @@ __global__ void __launch_bounds__(NT, NT == 384 ? 3 : 4) k_fused_lean(CrfDev c, 
         typedef unsigned lean_u4 __attribute__((ext_vector_type(4)));
 #pragma unroll
         for (int s = 0; s < PPT; ++s) {
-            const lean_u2 u = __builtin_amdgcn_raw_buffer_load_b64(src.unary, (tid + s * NT) * 8, 0, 0);   // (a lane past the frame reads 0 or a spare row: unused)
+            const lean_u2 u = __builtin_amdgcn_raw_buffer_load_b64(src.unary, (tid + s * NT) * 8, 0, LEAN_AUX(1));   // (a lane past the frame reads 0 or a spare row: unused)
             pr.un[s] = make_float2(__uint_as_float(u.x), __uint_as_float(u.y));
 #pragma unroll
             for (int k = 0; k < K; ++k) {
-                const lean_u3 w = __builtin_amdgcn_raw_buffer_load_b96(rp, tid * 12, ((s * K + k) * NT) * 12, 0);
+                const lean_u3 w = __builtin_amdgcn_raw_buffer_load_b96(rp, tid * 12, ((s * K + k) * NT) * 12, LEAN_AUX(1));
                 pr.ix[s][k][0] = w.x;
                 pr.ix[s][k][1] = w.y;
                 pr.ix[s][k][2] = w.z;
-                if (!RELOAD) {
-                    const lean_u3 b = __builtin_amdgcn_raw_buffer_load_b96(src.bary[k], (tid + s * NT) * (D1 * 4), 0, 0);
-                    pr.bary[s][k][0] = __uint_as_float(b.x);
-                    pr.bary[s][k][1] = __uint_as_float(b.y);
-                    pr.bary[s][k][2] = __uint_as_float(b.z);
-                    pr.wn[s][k] = wk[k] * __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(src.norm[k], (tid + s * NT) * 4, 0, 0));   // pairwise3d.h:77
-                }
+                // (RELOAD: these are the first iteration's; mean_field_lean re-reads them from the second on)
+                const lean_u3 b = __builtin_amdgcn_raw_buffer_load_b96(src.bary[k], (tid + s * NT) * (D1 * 4), 0, LEAN_AUX(16));
+                pr.bary[s][k][0] = __uint_as_float(b.x);
+                pr.bary[s][k][1] = __uint_as_float(b.y);
+                pr.bary[s][k][2] = __uint_as_float(b.z);
+                pr.wn[s][k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(src.norm[k], (tid + s * NT) * 4, 0, LEAN_AUX(4)));
             }
         }
-        const lean_u2 clw = __builtin_amdgcn_raw_buffer_load_b64(rp, tid * 8, pp.cl_off, 0);
+        const lean_u2 clw = __builtin_amdgcn_raw_buffer_load_b64(rp, tid * 8, pp.cl_off, LEAN_AUX(1));
+        // the LDS tables: every piece is at most 16 bytes per lane (launch_inference_fused checks the plan), all requested before any is stored
+        lean_u4 trow[K], tnbr[K];
 #pragma unroll
-        for (int k = 0; k < K; ++k) {                     // the LDS tables, 16 bytes per lane and trip
-            for (int b = tid * 16; b < pp.row_bytes[k]; b += NT * 16)
-                *reinterpret_cast<lean_u4 *>(smem + lay.row[k] + b) = __builtin_amdgcn_raw_buffer_load_b128(rp, b, pp.row_off[k], 0);
-            for (int b = tid * 16; b < pp.nbr_bytes[k]; b += NT * 16)
-                *reinterpret_cast<lean_u4 *>(smem + lay.nbr[k] + b) = __builtin_amdgcn_raw_buffer_load_b128(rp, b, pp.nbr_off[k], 0);
+        for (int k = 0; k < K; ++k) {
+            trow[k] = tnbr[k] = lean_u4{0u, 0u, 0u, 0u};
+            if (tid * 16 < pp.row_bytes[k]) trow[k] = __builtin_amdgcn_raw_buffer_load_b128(rp, tid * 16, pp.row_off[k], LEAN_AUX(1));
+            if (tid * 16 < pp.nbr_bytes[k]) tnbr[k] = __builtin_amdgcn_raw_buffer_load_b128(rp, tid * 16, pp.nbr_off[k], LEAN_AUX(1));
+        }
+        FL_PSTAMP();                                      // (everything requested)
+        if (N <= 0) {                                     // (the point count was requested first and is only needed here)
+            if (a.with_map) clear_label_bits<NT>(c, fo, 0, lane_id());
+            return;
+        }
+        if (FL_DBG(8)) {                                  // (fine stamps only: ... landed)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            FL_STAMP();
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            if (tid * 16 < pp.row_bytes[k]) *reinterpret_cast<lean_u4 *>(smem + lay.row[k] + tid * 16) = trow[k];
+            if (tid * 16 < pp.nbr_bytes[k]) *reinterpret_cast<lean_u4 *>(smem + lay.nbr[k] + tid * 16) = tnbr[k];
         }
         if (tid < 32) reinterpret_cast<float *>(smem + lay.zero)[tid] = 0.0f;
         if (tid == 0) {
@@ -268,6 +280,11 @@ __global__ void __launch_bounds__(NT, NT == 384 ? 3 : 4) k_fused_lean(CrfDev c, 
                 reinterpret_cast<float2 *>(smem + lay.val[k][1])[0] = make_float2(0.f, 0.f);
             }
         }
+#pragma unroll
+        for (int s = 0; s < PPT; ++s)
+#pragma unroll
+            for (int k = 0; k < K; ++k) pr.wn[s][k] = wk[k] * pr.wn[s][k];                    // pairwise3d.h:77 (w_*norm_[i])
+        FL_PSTAMP();                                      // (this wavefront's tables stored)
         __syncthreads();
         FL_PSTAMP();
         ChainLane cl{clw.x, clw.y};
@@ -277,13 +294,18 @@ __global__ void __launch_bounds__(NT, NT == 384 ? 3 : 4) k_fused_lean(CrfDev c, 
 #pragma unroll
         for (int k = 0; k < K; ++k) alpha[k] = a.kd[k].alpha;
         int t = lane_id();
-        mean_field_lean<PPT, K, CH, NT, RELOAD>(smem, lay, V, N, t, pr, cl, alpha, wk, src, a.n_iter, a.relax, a.omr, ins);
+        mean_field_lean<PPT, K, CH, NT, RELOAD, false, true>(smem, lay, V, N, t, pr, cl, alpha, wk, src, a.n_iter, a.relax, a.omr, ins);
         t = lane_id();
-        store_results<PPT, K, NT>(c, fo, N, t, pr, a.with_map);
+        store_results<PPT, K, NT, (LCCRF_LEAN_NT & 8) != 0>(c, fo, N, t, pr, a.with_map);
         FL_STAMP();
         if (kInstr && a.timing && (int)blockIdx.x == a.timing_block && t == a.timing_lane) a.timing[63] = ins.n;
         return;
     }
+    if (N <= 0) {
+        if (a.with_map) clear_label_bits<NT>(c, fo, 0, lane_id());
+        return;
+    }
+
 
     // per-point records first (the long pole of the prologue), then the lattice tables
     unsigned pk[PPT][K][D1];              // (vertex id + 1) | place in the row << 16
@@ -575,7 +597,9 @@ int launch_inference_fused(const CrfDev &c, const KernelDev *kds, const int *max
         const LeanPrepPlan pp = lean_prep_plan(a.lay, c.K, a.Vcap, 512, ppt);
         static const bool no_prep = ab_env("LCCRF_NO_LEAN_PREP") != nullptr;    // A/B switch (instrumented library): same results either way
         int mode = 0;
-        if (prep && prep->buf && !no_prep && (size_t)pp.total <= kLeanPrepMaxBytes && (size_t)pp.total * (size_t)c.F <= prep->bytes) {
+        bool pieces_ok = true;                                 // (the run kernel moves every table with one 16-byte load per lane)
+        for (int k = 0; k < c.K; ++k) pieces_ok = pieces_ok && pp.row_bytes[k] <= 512 * 16 && pp.nbr_bytes[k] <= 512 * 16;
+        if (prep && prep->buf && !no_prep && pieces_ok && (size_t)pp.total <= kLeanPrepMaxBytes && (size_t)pp.total * (size_t)c.F <= prep->bytes) {
             // what the blocks depend on besides the lattices themselves: the plan, the shape, the frame count
             unsigned long long key = 1469598103934665603ull;
             auto mix = [&](const void *p, size_t n) { for (size_t i = 0; i < n; ++i) key = (key ^ static_cast<const unsigned char *>(p)[i]) * 1099511628211ull; };

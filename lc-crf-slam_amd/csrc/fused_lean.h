@@ -25,6 +25,14 @@
 #define LCCRF_LEAN_SKIP 0
 #endif
 #define LEAN_SKIP(bit) ((LCCRF_LEAN_SKIP & (bit)) != 0)
+// Cache policy of the loop's HBM / L2 accesses (bit set = non-temporal, aux = 2): 1 the prologue's once-per-launch records, 2 the
+// large lattice's neighbour words, 4 norms + unary energies, 8 the results, 16 the barycentric weights.  What every iteration re-reads
+// is ~94 KB per frame, 64 frames per XCD: 6 MB cycling through a 4 MB L2 misses every time (FETCH_SIZE: profiles/r5_fused_c2); the
+// point of the hints is to keep a subset that FITS (the weights: 48 KB per frame) resident and stream the rest past it.
+#ifndef LCCRF_LEAN_NT
+#define LCCRF_LEAN_NT 0
+#endif
+#define LEAN_AUX(bit) ((LCCRF_LEAN_NT & (bit)) ? 2 : 0)
 
 namespace lccrf {
 namespace fl {
@@ -448,7 +456,8 @@ constexpr size_t kLeanPrepMaxBytes = 64 * 1024;        // per frame, whatever th
 // lane's (L2-resident) records; what a lane holds between iterations is Q and the packed ids / slots (8 registers per point).
 // NORM (the one-launch frame kernel): ONE pass that leaves every kernel's norm = 1 / (K * 1 + 1e-20) (pairwise3d.h:20-28) in src.norm
 // (RELOAD; else w * norm in pr.wn) instead of updating Q -- the caller sets Q = 1; the same splat / row sums / blur / slice as an iteration's, phase by phase.
-template <int PPT, int K, int CH, int NT, bool RELOAD, bool NORM = false>
+// PRELOADED: the caller has the first iteration's records in pr already (k_fused_lean from prepared blocks requests them with everything else).
+template <int PPT, int K, int CH, int NT, bool RELOAD, bool NORM = false, bool PRELOADED = false>
 __device__ __forceinline__ void mean_field_lean(unsigned char *smem, const FusedLayout &lay, const int (&V)[K], int N, int &t,
                                                 PointRegs<PPT, K> &pr, ChainLane &cl, const float (&alpha)[K],
                                                 const float (&wk)[K], const LeanSrc &src, int n_iter, float relax, float omr, Instr &ins)
@@ -482,16 +491,16 @@ __device__ __forceinline__ void mean_field_lean(unsigned char *smem, const Fused
             const int i = t + s * NT;                   // (a lane without a point in this slot reads the slice's spare rows or 0: unused)
             if (!NORM) {
                 typedef unsigned lean_u2 __attribute__((ext_vector_type(2)));
-                const lean_u2 u = __builtin_amdgcn_raw_buffer_load_b64(src.unary, i * 8, src.off_unary, 0);
+                const lean_u2 u = __builtin_amdgcn_raw_buffer_load_b64(src.unary, i * 8, src.off_unary, LEAN_AUX(4));
                 pr.un[s] = make_float2(__uint_as_float(u.x), __uint_as_float(u.y));
             }
 #pragma unroll
             for (int k = 0; k < K; ++k) {
-                const lean_u3 b = __builtin_amdgcn_raw_buffer_load_b96(src.bary[k], i * (D1 * 4), src.off_bary[k], 0);
+                const lean_u3 b = __builtin_amdgcn_raw_buffer_load_b96(src.bary[k], i * (D1 * 4), src.off_bary[k], LEAN_AUX(16));
                 pr.bary[s][k][0] = __uint_as_float(b.x);
                 pr.bary[s][k][1] = __uint_as_float(b.y);
                 pr.bary[s][k][2] = __uint_as_float(b.z);
-                if (!NORM) pr.wn[s][k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(src.norm[k], i * 4, src.off_norm[k], 0));
+                if (!NORM) pr.wn[s][k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(src.norm[k], i * 4, src.off_norm[k], LEAN_AUX(4)));
             }
         }
         if (NORM) return;
@@ -592,7 +601,7 @@ __device__ __forceinline__ void mean_field_lean(unsigned char *smem, const Fused
                 for (int r = 0; r < R; ++r) {
                     w[k][j][r] = 0;
                     if (!(CH == 1 && k == 0) && (r == 0 || r * NT < V[k]))      // (uniform; v >= V: an unused word of the table)
-                        w[k][j][r] = __builtin_amdgcn_raw_buffer_load_b32(src.nbr[k], (t + r * NT) * 4, src.off_nbr[k] + j * src.nbr_axis_bytes[k], 0);
+                        w[k][j][r] = __builtin_amdgcn_raw_buffer_load_b32(src.nbr[k], (t + r * NT) * 4, src.off_nbr[k] + j * src.nbr_axis_bytes[k], LEAN_AUX(2));
                 }
             }
         }
@@ -633,7 +642,7 @@ __device__ __forceinline__ void mean_field_lean(unsigned char *smem, const Fused
         for (int r = 0; r < RA; ++r) {
             wa[r] = 0;
             if ((r == 0 || r * NA0 < V[K - 1]) && !LEAN_SKIP(512))
-                wa[r] = __builtin_amdgcn_raw_buffer_load_b32(src.nbr[K - 1], (t - 128 + r * NA0) * 4, src.off_nbr[K - 1], 0);      // (lanes < 128: out of range reads 0, unused)
+                wa[r] = __builtin_amdgcn_raw_buffer_load_b32(src.nbr[K - 1], (t - 128 + r * NA0) * 4, src.off_nbr[K - 1], LEAN_AUX(2));      // (lanes < 128: out of range reads 0, unused)
         }
 #pragma unroll
         for (int j = 1; j < D1; ++j) {
@@ -641,7 +650,7 @@ __device__ __forceinline__ void mean_field_lean(unsigned char *smem, const Fused
             for (int r = 0; r < RB; ++r) {
                 wb[j - 1][r] = 0;
                 if ((r == 0 || r * NB < V[K - 1]) && !LEAN_SKIP(512))
-                    wb[j - 1][r] = __builtin_amdgcn_raw_buffer_load_b32(src.nbr[K - 1], (t + r * NB) * 4, src.off_nbr[K - 1] + j * src.nbr_axis_bytes[K - 1], 0);
+                    wb[j - 1][r] = __builtin_amdgcn_raw_buffer_load_b32(src.nbr[K - 1], (t + r * NB) * 4, src.off_nbr[K - 1] + j * src.nbr_axis_bytes[K - 1], LEAN_AUX(2));
             }
         }
     };
@@ -701,7 +710,7 @@ __device__ __forceinline__ void mean_field_lean(unsigned char *smem, const Fused
     };
 
     if (n_iter <= 0) return;
-    load_weights();
+    if (!PRELOADED) load_weights();
 #pragma unroll
     for (int s = 0; s < PPT; ++s)
         if (t + s * NT < N) point_products_lean<PPT, K, CH>(lay, pr, s, KF);

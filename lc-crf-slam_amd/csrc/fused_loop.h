@@ -593,15 +593,25 @@ __device__ __forceinline__ void clear_label_bits(const CrfDev &c, int f, int fir
 }
 
 // Q and the MAP labels (densecrf3d.h:136-151: first maximum wins, ties -> label 0) of this lane's points.
-template <int PPT, int K, int NT = kNT>
+// NTS: non-temporal stores (the results leave the XCD's L2 working set alone: fused_lean.h, LCCRF_LEAN_NT)
+template <int PPT, int K, int NT = kNT, bool NTS = false>
 __device__ __forceinline__ void store_results(const CrfDev &c, int f, int N, int tid, const PointRegs<PPT, K> &pr, int with_map)
 {
 #pragma unroll
     for (int s = 0; s < PPT; ++s) {
         const int i = tid + s * NT;
         if (i < N) {
-            reinterpret_cast<float2 *>(c.Q)[(size_t)f * c.maxN + i] = pr.q[s];
-            if (with_map) c.map[(size_t)f * c.maxN + i] = (pr.q[s].x < pr.q[s].y) ? 1 : 0;   // densecrf3d.h:145
+            if (NTS) {
+                typedef float nts_f2 __attribute__((ext_vector_type(2)));
+                nts_f2 q;
+                q.x = pr.q[s].x;
+                q.y = pr.q[s].y;
+                __builtin_nontemporal_store(q, reinterpret_cast<nts_f2 *>(c.Q) + (size_t)f * c.maxN + i);
+                if (with_map) __builtin_nontemporal_store((int16_t)((pr.q[s].x < pr.q[s].y) ? 1 : 0), c.map + (size_t)f * c.maxN + i);
+            } else {
+                reinterpret_cast<float2 *>(c.Q)[(size_t)f * c.maxN + i] = pr.q[s];
+                if (with_map) c.map[(size_t)f * c.maxN + i] = (pr.q[s].x < pr.q[s].y) ? 1 : 0;   // densecrf3d.h:145
+            }
         }
         if (with_map && c.map_bits && (i & ~63) < N) {                   // the same labels, one bit each (label gather payload)
             const unsigned long long m = __ballot(i < N && pr.q[s].x < pr.q[s].y);
