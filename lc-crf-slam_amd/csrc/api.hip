@@ -679,6 +679,7 @@ struct Engine {
         sync_views();
         sizes_known = true;
         lean_prep.valid = false;                           // (every path that changes a lattice clears sizes_known and so comes through here)
+        lean_prep.seen_key = 0;
         sized_engine = 1;
         if (engine_pref != 1 && !perm_on && fused_supported(crf, kdevs.data(), maxV.data(), maxRow.data(), &fused_lds)) sized_engine = 2;
         if (engine_pref == 2 && sized_engine != 2)

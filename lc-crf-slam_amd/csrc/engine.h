@@ -211,7 +211,7 @@ struct LeanPrep {
     unsigned char *buf = nullptr;
     size_t bytes = 0;
     bool valid = false, timed = false;
-    unsigned long long key = 0;
+    unsigned long long key = 0, seen_key = 0;   // the plan / shape the blocks were written for; ... the last inference ran with (blocks are written by the second)
     unsigned runs = 0;                    // how many times the blocks were (re)written: tests
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };

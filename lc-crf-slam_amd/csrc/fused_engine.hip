@@ -33,6 +33,8 @@ namespace {
 
 using namespace fl;
 
+constexpr int kPrepMinFrames = 64;        // prepared launch records pay for batches that fill the chip; a handful of frames keeps the self-contained kernel
+
 struct FusedArgs {
     KernelDev kd[kMaxFusedK];
     FusedLayout lay;
@@ -52,7 +54,10 @@ struct FusedArgs {
 //   CH = 0 / 1: kernel 0 short-row / chain, decided by the host
 // (second launch bound: four wavefronts per SIMD = 128 registers per lane in both shapes -- what lets two 512-lane
 // workgroups be co-resident)
-template <int NT, int PPT, int K, int CH>
+//   MODE  0 / 1 / 2: the self-contained kernel / its prologue only, into the frame's prepared block / the run from that block
+//         (fused_lean.h: LeanPrepPlan -- the same blocks as k_fused_lean's: what chain_setup and place_products derive from the
+//         lattices is written once behind a build)
+template <int NT, int PPT, int K, int CH, int MODE>
 __global__ void __launch_bounds__(NT, 4) k_fused(CrfDev c, FusedArgs a)
 {
     constexpr int D1 = kD1;
@@ -67,12 +72,91 @@ __global__ void __launch_bounds__(NT, 4) k_fused(CrfDev c, FusedArgs a)
     int V[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) V[k] = a.kd[k].V[f];
+    const FusedLayout &lay = a.lay;
 
-    if (N <= 0) {                         // nothing to infer (and nothing below may index an empty frame)
-        if (a.with_map) clear_label_bits<NT>(c, f, 0, tid);
+    if constexpr (MODE == 2) {
+        // every load depends on the frame index only: one round trip between the kernel's start and its first barrier
+        typedef unsigned pf_u2 __attribute__((ext_vector_type(2)));
+        typedef unsigned pf_u4 __attribute__((ext_vector_type(4)));
+        const LeanPrepPlan pp = lean_prep_plan(lay, K, a.Vcap, NT, PPT);
+        const __amdgpu_buffer_rsrc_t rp = lean_rsrc(a.prep + (size_t)f * a.prep_stride, (size_t)a.prep_stride);
+        const __amdgpu_buffer_rsrc_t ru = lean_rsrc(c.unary + (size_t)f * c.maxN * 2, (size_t)c.maxN * 8);
+#pragma unroll
+        for (int s = 0; s < PPT; ++s) {
+            const pf_u2 u = __builtin_amdgcn_raw_buffer_load_b64(ru, (tid + s * NT) * 8, 0, 0);   // (a lane past the frame reads 0 or a spare row: unused)
+            pr.un[s] = make_float2(__uint_as_float(u.x), __uint_as_float(u.y));
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const KernelDev &kd = a.kd[k];
+                const __amdgpu_buffer_rsrc_t rb = lean_rsrc(kd.bary + (size_t)f * kd.Epad, (size_t)kd.Epad * 4);
+                const __amdgpu_buffer_rsrc_t rn = lean_rsrc(kd.norm + (size_t)f * kd.maxN, (size_t)kd.maxN * 4);
+                const lean_u3 w = __builtin_amdgcn_raw_buffer_load_b96(rp, tid * 12, ((s * K + k) * NT) * 12, 0);
+                pr.ix[s][k][0] = w.x;
+                pr.ix[s][k][1] = w.y;
+                pr.ix[s][k][2] = w.z;
+                const lean_u3 b = __builtin_amdgcn_raw_buffer_load_b96(rb, (tid + s * NT) * (D1 * 4), 0, 0);
+                pr.bary[s][k][0] = __uint_as_float(b.x);
+                pr.bary[s][k][1] = __uint_as_float(b.y);
+                pr.bary[s][k][2] = __uint_as_float(b.z);
+                pr.wn[s][k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rn, (tid + s * NT) * 4, 0, 0));
+            }
+        }
+        const pf_u2 clw = __builtin_amdgcn_raw_buffer_load_b64(rp, tid * 8, pp.cl_off, 0);
+        // the LDS tables: at most two 16-byte pieces per lane and table (launch_inference_fused checks the plan), all requested before any is stored
+        pf_u4 trow[K][2], tnbr[K][2];
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                trow[k][r] = tnbr[k][r] = pf_u4{0u, 0u, 0u, 0u};
+                const int b = (tid + r * NT) * 16;
+                if (b < pp.row_bytes[k]) trow[k][r] = __builtin_amdgcn_raw_buffer_load_b128(rp, b, pp.row_off[k], 0);
+                if (b < pp.nbr_bytes[k]) tnbr[k][r] = __builtin_amdgcn_raw_buffer_load_b128(rp, b, pp.nbr_off[k], 0);
+            }
+        FL_PSTAMP();
+        if (N <= 0) {
+            if (a.with_map) clear_label_bits<NT>(c, f, 0, tid);
+            return;
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int b = (tid + r * NT) * 16;
+                if (b < pp.row_bytes[k]) *reinterpret_cast<pf_u4 *>(smem + lay.row[k] + b) = trow[k][r];
+                if (b < pp.nbr_bytes[k]) *reinterpret_cast<pf_u4 *>(smem + lay.nbr[k] + b) = tnbr[k][r];
+            }
+        if (tid < 16) reinterpret_cast<float *>(smem + lay.zero)[tid] = 0.0f;
+        if (tid == 0) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                reinterpret_cast<float2 *>(smem + lay.val[k][0])[0] = make_float2(0.f, 0.f);
+                reinterpret_cast<float2 *>(smem + lay.val[k][1])[0] = make_float2(0.f, 0.f);
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < PPT; ++s)
+#pragma unroll
+            for (int k = 0; k < K; ++k) pr.wn[s][k] = a.kd[k].w * pr.wn[s][k];   // pairwise3d.h:77 (w_*norm_[i])
+        __syncthreads();
+        FL_PSTAMP();
+        const ChainLane cl{clw.x, clw.y};
+        start_inference<PPT, K, NT>(pr, N, tid);
+        FL_STAMP();
+        float alpha[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) alpha[k] = a.kd[k].alpha;
+        mean_field<PPT, K, CH, NT, true>(smem, lay, V, N, tid, pr, cl, alpha, a.n_iter, a.relax, ins);
+        store_results<PPT, K, NT>(c, f, N, tid, pr, a.with_map);
+        FL_STAMP();
+        if (kInstr && a.timing && (int)blockIdx.x == a.timing_block && tid == a.timing_lane) a.timing[63] = ins.n;
         return;
     }
-    const FusedLayout &lay = a.lay;
+
+    if (N <= 0) {                         // nothing to infer (and nothing below may index an empty frame)
+        if (a.with_map && MODE != 1) clear_label_bits<NT>(c, f, 0, tid);
+        return;
+    }
     if (FL_DBG(4)) {                      // debugging aid: NaN-poison the LDS so that reads of unwritten LDS show up
         for (int i = tid; i < lay.total / 4; i += NT) reinterpret_cast<unsigned *>(smem)[i] = 0x7fc00000u + (unsigned)i;
         __syncthreads();
@@ -161,9 +245,32 @@ __global__ void __launch_bounds__(NT, 4) k_fused(CrfDev c, FusedArgs a)
     ChainLane cl{0u, 0u};
     if (CH != 0 && chain_k<CH>(lay, 0)) cl = chain_setup(smem, lay, V[0], tid);
     FL_PSTAMP();
-    start_inference<PPT, K, NT>(pr, N, tid);
+    if (MODE != 1) start_inference<PPT, K, NT>(pr, N, tid);
     place_products<PPT, K, CH, NT>(smem, lay, N, tid, pk, pr);
     FL_STAMP();
+    if constexpr (MODE == 1) {
+        // ---- the prepared block of this frame: ix words, chain lanes, LDS tables (LeanPrepPlan) ---------------------------------------
+        const LeanPrepPlan pp = lean_prep_plan(lay, K, a.Vcap, NT, PPT);
+        unsigned char *pf = a.prep + (size_t)f * a.prep_stride;
+#pragma unroll
+        for (int s = 0; s < PPT; ++s)
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                unsigned *w = reinterpret_cast<unsigned *>(pf) + ((size_t)(s * K + k) * NT + tid) * 3;
+                w[0] = pr.ix[s][k][0];
+                w[1] = pr.ix[s][k][1];
+                w[2] = pr.ix[s][k][2];
+            }
+        reinterpret_cast<uint2 *>(pf + pp.cl_off)[tid] = make_uint2(cl.a, cl.b);
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            for (int b = tid * 16; b < pp.row_bytes[k]; b += NT * 16)
+                *reinterpret_cast<uint4 *>(pf + pp.row_off[k] + b) = *reinterpret_cast<const uint4 *>(smem + lay.row[k] + b);
+            for (int b = tid * 16; b < pp.nbr_bytes[k]; b += NT * 16)
+                *reinterpret_cast<uint4 *>(pf + pp.nbr_off[k] + b) = *reinterpret_cast<const uint4 *>(smem + lay.nbr[k] + b);
+        }
+        return;
+    }
 
     float alpha[K];
 #pragma unroll
@@ -515,25 +622,52 @@ void launch_lean_any(const CrfDev &c, const FusedArgs &a, hipStream_t s, int mod
     else launch_lean_ppt<512, 4, true>(c, a, s, mode);
 }
 
-template <int NT, int PPT, int K, int CH>
-void launch_fused(const CrfDev &c, const FusedArgs &a, hipStream_t s)
+template <int NT, int PPT, int K, int CH, int MODE>
+void launch_fused_mode(const CrfDev &c, const FusedArgs &a, hipStream_t s)
 {
-    auto fn = k_fused<NT, PPT, K, CH>;
+    auto fn = k_fused<NT, PPT, K, CH, MODE>;
     // per (function, device); cheap enough to repeat and safe with several devices in one process
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)kLdsLimit);
     fn<<<dim3(c.F), dim3(NT), a.lay.total, s>>>(c, a);
 }
 
+template <int NT, int PPT, int K, int CH>
+void launch_fused(const CrfDev &c, const FusedArgs &a, hipStream_t s, int mode)
+{
+    if (mode == 2) launch_fused_mode<NT, PPT, K, CH, 2>(c, a, s);
+    else if (mode == 1) launch_fused_mode<NT, PPT, K, CH, 1>(c, a, s);
+    else launch_fused_mode<NT, PPT, K, CH, 0>(c, a, s);
+}
+
 template <int NT, int PPT>
-void launch_fused_ppt(const CrfDev &c, const FusedArgs &a, hipStream_t s)
+void launch_fused_ppt(const CrfDev &c, const FusedArgs &a, hipStream_t s, int mode)
 {
     if (c.K == 1) {
-        if (a.lay.chain0) launch_fused<NT, PPT, 1, 1>(c, a, s);
-        else launch_fused<NT, PPT, 1, 0>(c, a, s);
+        if (a.lay.chain0) launch_fused<NT, PPT, 1, 1>(c, a, s, mode);
+        else launch_fused<NT, PPT, 1, 0>(c, a, s, mode);
     } else {
-        if (a.lay.chain0) launch_fused<NT, PPT, 2, 1>(c, a, s);
-        else launch_fused<NT, PPT, 2, 0>(c, a, s);
+        if (a.lay.chain0) launch_fused<NT, PPT, 2, 1>(c, a, s, mode);
+        else launch_fused<NT, PPT, 2, 0>(c, a, s, mode);
+    }
+}
+
+// the shape launch_inference_fused has chosen, in one of the three modes
+void launch_shape(const CrfDev &c, const FusedArgs &a, hipStream_t s, int mode, int NAp, bool small, bool lean)
+{
+    if (small) {
+        if (NAp <= kNTSmall) launch_fused_ppt<kNTSmall, 1>(c, a, s, mode);
+        else launch_fused_ppt<kNTSmall, 2>(c, a, s, mode);
+    } else if (lean) {
+        launch_lean_any(c, a, s, mode, NAp);
+    } else {
+        switch ((NAp + kNT - 1) / kNT) {
+        case 1: launch_fused_ppt<kNT, 1>(c, a, s, mode); break;
+        case 2: launch_fused_ppt<kNT, 2>(c, a, s, mode); break;
+        case 3: launch_fused_ppt<kNT, 3>(c, a, s, mode); break;
+        case 4: launch_fused_ppt<kNT, 4>(c, a, s, mode); break;
+        default: break;
+        }
     }
 }
 
@@ -547,16 +681,32 @@ bool fused_supported(const CrfDev &c, const KernelDev *kds, const int *maxV, con
     return ok;
 }
 
+// the shape decision of launch_inference_fused
+struct FusedShape {
+    bool ok, small, lean;
+    int nt, ppt;
+};
+static FusedShape choose_shape(const CrfDev &c, const KernelDev *kds, const int *maxV, const int *maxRow, FusedLayout *lay)
+{
+    FusedShape sh{false, false, false, kNT, 1};
+    int lean_nt = 0;
+    const int NAp = c.activeN > 0 ? c.activeN : c.maxN;
+    const bool lean_first = NAp <= 2 * kNTSmall && lean_layout(c, kds, maxV, maxRow, lay, &lean_nt);      // (LCCRF_LEAN_SMALL experiment)
+    sh.small = !lean_first && small_layout(c, kds, maxV, maxRow, lay);
+    sh.lean = lean_first || (!sh.small && lean_layout(c, kds, maxV, maxRow, lay, &lean_nt));
+    if (!sh.small && !sh.lean && !make_layout(c, kds, maxV, maxRow, lay)) return sh;
+    sh.ok = true;
+    sh.nt = (sh.small || sh.lean) ? kNTSmall : kNT;
+    sh.ppt = std::max((NAp + sh.nt - 1) / sh.nt, 1);
+    return sh;
+}
+
 size_t lean_prep_bytes(const CrfDev &c, const KernelDev *kds, const int *maxV, const int *maxRow)
 {
-    // (the shape decision of launch_inference_fused)
-    FusedLayout lay, other;
-    int nt = 0;
-    const int NAp = c.activeN > 0 ? c.activeN : c.maxN;
-    const bool lean_first = NAp <= 2 * kNTSmall && lean_layout(c, kds, maxV, maxRow, &lay, &nt);
-    const bool small = !lean_first && small_layout(c, kds, maxV, maxRow, &other);
-    if (!(lean_first || (!small && lean_layout(c, kds, maxV, maxRow, &lay, &nt)))) return 0;
-    const LeanPrepPlan pp = lean_prep_plan(lay, c.K, maxV, 512, NAp <= 512 ? 1 : (NAp + 511) / 512);
+    FusedLayout lay;
+    const FusedShape sh = choose_shape(c, kds, maxV, maxRow, &lay);
+    if (!sh.ok || c.F < kPrepMinFrames) return 0;
+    const LeanPrepPlan pp = lean_prep_plan(lay, c.K, maxV, sh.nt, sh.ppt);
     return (size_t)pp.total * (size_t)c.F;
 }
 
@@ -564,12 +714,9 @@ int launch_inference_fused(const CrfDev &c, const KernelDev *kds, const int *max
                            int with_map, float relax, hipStream_t s, LeanPrep *prep)
 {
     FusedArgs a{};
-    int lean_nt = 0;
-    const int NAp0 = c.activeN > 0 ? c.activeN : c.maxN;
-    const bool lean_first = NAp0 <= 2 * kNTSmall && lean_layout(c, kds, maxV, maxRow, &a.lay, &lean_nt);      // (LCCRF_LEAN_SMALL experiment)
-    const bool small = !lean_first && small_layout(c, kds, maxV, maxRow, &a.lay);
-    const bool lean = lean_first || (!small && lean_layout(c, kds, maxV, maxRow, &a.lay, &lean_nt));
-    if (!small && !lean && !make_layout(c, kds, maxV, maxRow, &a.lay)) return 0;
+    const FusedShape sh = choose_shape(c, kds, maxV, maxRow, &a.lay);
+    if (!sh.ok) return 0;
+    const bool small = sh.small, lean = sh.lean;
     static const bool no_chain = ab_env("LCCRF_NO_CHAIN") != nullptr;     // debugging aid: compiler-scheduled S phase
     if (no_chain) a.lay.chain0 = 0;                                        // (the padded plane size is harmless)
     for (int k = 0; k < c.K; ++k) a.kd[k] = kds[k];
@@ -587,49 +734,42 @@ int launch_inference_fused(const CrfDev &c, const KernelDev *kds, const int *max
     static const int dbg = (kInstr && ab_env("LCCRF_FUSED_DBG")) ? atoi(ab_env("LCCRF_FUSED_DBG")) : 0;
     a.dbg = dbg;
     const int NAp = c.activeN > 0 ? c.activeN : c.maxN;
-    if (small) {
-        if (NAp <= kNTSmall) launch_fused_ppt<kNTSmall, 1>(c, a, s);
-        else launch_fused_ppt<kNTSmall, 2>(c, a, s);
-    } else if (lean) {
-        // prepared launch records (fused_lean.h: LeanPrepPlan): written by the first inference behind a build, read by every one after it
-        const int ppt = NAp <= 512 ? 1 : (NAp + 511) / 512;
-        for (int k = 0; k < c.K; ++k) a.Vcap[k] = maxV[k];
-        const LeanPrepPlan pp = lean_prep_plan(a.lay, c.K, a.Vcap, 512, ppt);
-        static const bool no_prep = ab_env("LCCRF_NO_LEAN_PREP") != nullptr;    // A/B switch (instrumented library): same results either way
-        int mode = 0;
-        bool pieces_ok = true;                                 // (the run kernel moves every table with one 16-byte load per lane)
-        for (int k = 0; k < c.K; ++k) pieces_ok = pieces_ok && pp.row_bytes[k] <= 512 * 16 && pp.nbr_bytes[k] <= 512 * 16;
-        if (prep && prep->buf && !no_prep && pieces_ok && (size_t)pp.total <= kLeanPrepMaxBytes && (size_t)pp.total * (size_t)c.F <= prep->bytes) {
-            // what the blocks depend on besides the lattices themselves: the plan, the shape, the frame count
-            unsigned long long key = 1469598103934665603ull;
-            auto mix = [&](const void *p, size_t n) { for (size_t i = 0; i < n; ++i) key = (key ^ static_cast<const unsigned char *>(p)[i]) * 1099511628211ull; };
-            mix(&a.lay, sizeof(a.lay));
-            mix(a.Vcap, sizeof(int) * c.K);
-            const int shape[4] = {c.F, c.K, ppt, NAp};
-            mix(shape, sizeof(shape));
-            a.prep = prep->buf;
-            a.prep_stride = pp.total;
-            if (!prep->valid || prep->key != key) {
-                if (prep->ev0) (void)hipEventRecord(prep->ev0, s);
-                launch_lean_any(c, a, s, 1, NAp);
-                if (prep->ev1) (void)hipEventRecord(prep->ev1, s);
-                prep->timed = prep->ev0 && prep->ev1;
-                prep->valid = true;
-                prep->key = key;
-                ++prep->runs;
-            }
+    // Prepared launch records (fused_lean.h: LeanPrepPlan): what the prologue derives from the lattices and the plan alone.  The FIRST
+    // inference behind a build runs the self-contained kernel (a caller with one inference per lattice pays nothing); the second one
+    // writes the blocks (MODE 1) and every inference from then on starts from them (MODE 2).
+    for (int k = 0; k < c.K; ++k) a.Vcap[k] = maxV[k];
+    const LeanPrepPlan pp = lean_prep_plan(a.lay, c.K, a.Vcap, sh.nt, sh.ppt);
+    static const bool no_prep = ab_env("LCCRF_NO_LEAN_PREP") != nullptr;    // A/B switches (instrumented library): same results either way
+    static const bool prep_now = ab_env("LCCRF_LEAN_PREP_NOW") != nullptr;  //   ... the blocks already in the first inference
+    int mode = 0;
+    bool pieces_ok = !no_chain;                           // (the run kernels move every table with one (lean) / two 16-byte loads per lane)
+    for (int k = 0; k < c.K; ++k) pieces_ok = pieces_ok && pp.row_bytes[k] <= (lean ? 1 : 2) * sh.nt * 16 && pp.nbr_bytes[k] <= (lean ? 1 : 2) * sh.nt * 16;
+    if (prep && prep->buf && !no_prep && pieces_ok && c.F >= kPrepMinFrames && (size_t)pp.total * (size_t)c.F <= prep->bytes) {
+        // what the blocks depend on besides the lattices themselves: the plan, the shape, the frame count
+        unsigned long long key = 1469598103934665603ull;
+        auto mix = [&](const void *p, size_t n) { for (size_t i = 0; i < n; ++i) key = (key ^ static_cast<const unsigned char *>(p)[i]) * 1099511628211ull; };
+        mix(&a.lay, sizeof(a.lay));
+        mix(a.Vcap, sizeof(int) * c.K);
+        const int shape[6] = {c.F, c.K, sh.ppt, NAp, sh.nt, lean ? 2 : small ? 1 : 0};
+        mix(shape, sizeof(shape));
+        a.prep = prep->buf;
+        a.prep_stride = pp.total;
+        if (prep->valid && prep->key == key) {
             mode = 2;
-        }
-        launch_lean_any(c, a, s, mode, NAp);
-    } else {
-        switch ((NAp + kNT - 1) / kNT) {
-        case 1: launch_fused_ppt<kNT, 1>(c, a, s); break;
-        case 2: launch_fused_ppt<kNT, 2>(c, a, s); break;
-        case 3: launch_fused_ppt<kNT, 3>(c, a, s); break;
-        case 4: launch_fused_ppt<kNT, 4>(c, a, s); break;
-        default: break;
+        } else if (prep->seen_key == key || prep_now) {      // the second inference on these lattices: write the blocks, then run from them
+            if (prep->ev0) (void)hipEventRecord(prep->ev0, s);
+            launch_shape(c, a, s, 1, NAp, small, lean);
+            if (prep->ev1) (void)hipEventRecord(prep->ev1, s);
+            prep->timed = prep->ev0 && prep->ev1;
+            prep->valid = true;
+            prep->key = key;
+            ++prep->runs;
+            mode = 2;
+        } else {
+            prep->seen_key = key;                            // the first one
         }
     }
+    launch_shape(c, a, s, mode, NAp, small, lean);
     if (a.timing) {                       // debug only: synchronous read-back of workgroup 0's phase stamps
         long long h[64];
         (void)hipStreamSynchronize(s);
@@ -638,7 +778,7 @@ int launch_inference_fused(const CrfDev &c, const KernelDev *kds, const int *max
         for (int i = 1; i < h[63] && i < 63; ++i) fprintf(stderr, " %lld", h[i] - h[i - 1]);
         fprintf(stderr, "\n");
     }
-    return small ? (kNTSmall | 2 << 16) : lean ? (lean_nt | 2 << 16) : (kNT | 1 << 16);
+    return small ? (kNTSmall | 2 << 16) : lean ? (kNTSmall | 2 << 16) : (kNT | 1 << 16);
 }
 
 }  // namespace lccrf

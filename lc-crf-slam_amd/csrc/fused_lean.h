@@ -417,7 +417,8 @@ __device__ __forceinline__ void opaque_ids(PointRegs<PPT, K> &pr)
 // What the prologue of k_fused_lean derives from a frame's lattice and the batch's LDS plan -- the ranking of the chain rows and
 // their placement (chain_setup_lean: six barriers, LDS atomics, two scans), every point's vertex addresses and product slots
 // (place_products_lean), the u16 row table and the chain kernel's neighbour table -- is the same in every inference on that lattice.
-// It is computed ONCE behind a build (k_fused_lean<.., MODE 1>, the first inference after lccrf_batch_build) into one block per frame:
+// It is computed ONCE behind a build (k_fused_lean / k_fused <.., MODE 1>, by the SECOND inference on the same lattices: a caller
+// with one inference per lattice never pays for it) into one block per frame:
 //     [ix   : (s, k, lane) x 3 words]   the final PointRegs::ix, 12 bytes per (point slot, kernel, lane), lane-contiguous
 //     [cl   : lane x 2 words]           the lane's ChainLane
 //     [row k, nbr k for every kernel]   the bytes of the LDS tables, each padded to 16
@@ -447,7 +448,6 @@ __host__ __device__ inline LeanPrepPlan lean_prep_plan(const FusedLayout &lay, i
     p.total = (o + 255) & ~255;
     return p;
 }
-constexpr size_t kLeanPrepMaxBytes = 64 * 1024;        // per frame, whatever the plan: 2 kernels x 4 slots x 512 lanes x 12 + 4 KB + tables < 8 KB
 
 // n_iter x stepInference on the lean plan.  Per iteration, between workgroup barriers:
 //   [X: slice + apply + softmax of every point, its products for kernel K-1 right behind]  |  S(K-1)  |  P(k) | S(k) for k = K-2 .. 0  |

@@ -607,7 +607,9 @@ sys.path.insert(0, %r); sys.path.insert(0, %r); sys.path.insert(0, %r)
 import crf_cases as cc, pyoracle as po
 from test_frame_engine import _batch_of
 wl = importlib.import_module("lc-crf-slam_amd.workloads")
-lanes = 512 if %r in ("", "2", "2-noprep") else 384
+shape = %r
+noprep = shape == "2-noprep"
+lanes = 512 if shape in ("", "2", "2-noprep") else 384
 top = 2048 if lanes == 512 else 2304
 sizes = [2000, 1025, 1536, 1537, 1999, top, 1100, 1920, 1921, top - 1, 0, 700, 1152, 1153, 3, 2001]
 base = [wl.slam_problem(n, seed=5100 + i) for i, n in enumerate(sizes)]
@@ -619,6 +621,11 @@ for n_iter, relax in ((5, 1.0), (3, 0.5)):
     b.build(); b.inference(n_iter, True, relax=relax)
     Q, M = b.probability(), b.map()
     assert b.engine() == 2 and b.fused_shape() == (lanes, 2), (b.engine(), b.fused_shape())
+    # the second inference on the same lattices writes the prepared launch records and runs from them, the third reuses them (round 6)
+    for again in range(2):
+        b.inference(n_iter, True, relax=relax)
+        assert cc.same_bits(b.probability(), Q) and np.array_equal(b.map(), M), ("prepared", n_iter, again)
+    assert b.last_prepare()[1] == (0 if noprep else 1)
     b.close()
     for i, pb in enumerate(base):
         o = cc.setup(po.OracleCRF, pb)
@@ -635,6 +642,9 @@ b = _batch_of(pbs2, maxN=1024)
 b.build(); b.inference(5, True)
 Q, M = b.probability(), b.map()
 assert b.engine() == 2 and b.fused_shape() == (512, 2), (b.engine(), b.fused_shape())
+for again in range(2):
+    b.inference(5, True)
+    assert cc.same_bits(b.probability(), Q) and np.array_equal(b.map(), M), ("prepared small", again)
 b.close()
 for i, pb in enumerate(small):
     o = cc.setup(po.OracleCRF, pb)
@@ -651,6 +661,9 @@ for pick in ((0,), (1,), (1, 1)):
     b = _batch_of(pbs1, maxN=top)
     b.build(); b.inference(4, True)
     Q = b.probability()
+    for again in range(2):
+        b.inference(4, True)
+        assert cc.same_bits(b.probability(), Q), ("prepared", pick, again)
     # (two large lattices do not fit half a CU's LDS: that batch keeps the 1024-lane shape)
     assert b.engine() == 2 and b.fused_shape() == ((lanes, 2) if len(pick) == 1 else (1024, 1)), (pick, b.engine(), b.fused_shape())
     b.close()
@@ -674,8 +687,8 @@ print("ok")
 
 def test_prepared_launch_records_follow_the_lattices_and_not_the_unaries(po, wl):
     """Round 6 (fused_lean.h: LeanPrepPlan): the two-frames-per-CU inference kernel starts from per-frame blocks the FIRST inference
-    behind a build writes (ranking / placement of the chain rows, vertex addresses, product slots, the LDS tables).  They must be
-    rewritten when -- and only when -- a lattice changes; unary energies are inputs of every launch, not of the blocks."""
+    behind a build writes (ranking / placement of the chain rows, vertex addresses, product slots, the LDS tables) -- the SECOND one, so
+    that one inference per lattice pays nothing.  They must be rewritten when -- and only when -- a lattice changes."""
     F, maxN = 264, 2048
     def batch(seed0):
         sizes = [2000, 1300, 1999, 1100, 2048, 1537, 3, 0]
@@ -697,36 +710,87 @@ def test_prepared_launch_records_follow_the_lattices_and_not_the_unaries(po, wl)
     b = _batch_of(pbs, maxN=maxN)
     assert b.last_prepare()[1] == 0
     b.build()
-    b.inference(5, True)
+    b.inference(5, True)                                     # the first inference behind a build: the self-contained kernel
     assert b.engine() == 2 and b.fused_shape() == (512, 2)
+    assert b.last_prepare() == (0.0, 0)
+    check(b, pbs, 5, "first")
+    b.inference(3, True)                                     # the second one writes the blocks and runs from them
     ms, runs = b.last_prepare()
     assert runs == 1 and ms > 0
-    check(b, pbs, 5, "first")
-    b.inference(3, True)                                     # same lattices: the blocks are reused
-    assert b.last_prepare()[1] == 1
     check(b, pbs, 3, "second")
-    # other unaries (another confidence) on the SAME lattices: no rebuild, no new blocks, new results
+    b.inference(5, True)                                     # ... and the third reuses them
+    assert b.last_prepare()[1] == 1
+    check(b, pbs, 5, "third")
+    # other unaries (another confidence): new inputs through the host path invalidate the lattices -- build again; the blocks follow
     feats = [np.stack([np.pad(pb["kernels"][k][0], ((0, maxN - pb["N"]), (0, 0))) for pb in pbs]) for k in range(2)]
     label = np.stack([np.pad(pb["label"], (0, maxN - pb["N"]), constant_values=-1) for pb in pbs]).astype(np.int16)
-    # (new inputs through the host path invalidate the lattices: build again, then compare the run counter)
     b.set_inputs_host([pb["N"] for pb in pbs], feats, label=label, conf=0.9)
     b.build()
     b.inference(5, True)
+    assert b.last_prepare()[1] == 1                          # (first inference on the new lattices)
+    check(b, pbs, 5, "conf 0.9, first", conf=np.float32(0.9))
+    b.inference(5, True)
     assert b.last_prepare()[1] == 2
-    check(b, pbs, 5, "conf 0.9", conf=np.float32(0.9))
+    check(b, pbs, 5, "conf 0.9, second", conf=np.float32(0.9))
     # other frames: the lattices change, the blocks are rewritten
     pbs2 = batch(9200)
     feats2 = [np.stack([np.pad(pb["kernels"][k][0], ((0, maxN - pb["N"]), (0, 0))) for pb in pbs2]) for k in range(2)]
     label2 = np.stack([np.pad(pb["label"], (0, maxN - pb["N"]), constant_values=-1) for pb in pbs2]).astype(np.int16)
     b.set_inputs_host([pb["N"] for pb in pbs2], feats2, label=label2, conf=pbs2[0]["conf"])
     b.build()
-    b.inference(5, True)
-    assert b.last_prepare()[1] == 3
-    check(b, pbs2, 5, "other frames")
-    b.inference(5, True)
-    assert b.last_prepare()[1] == 3
-    check(b, pbs2, 5, "other frames, again")
+    for rep in range(3):
+        b.inference(5, True)
+        assert b.last_prepare()[1] == (2 if rep == 0 else 3)
+        check(b, pbs2, 5, "other frames, inference %d" % rep)
     b.close()
+
+
+@pytest.mark.parametrize("case", ["c4", "n500", "sparse", "k1_chain", "k1_short", "short_rows", "few_frames"])
+def test_repeated_inference_runs_from_prepared_records_in_every_fused_shape(po, wl, case):
+    """Round 6: k_fused (1024 lanes, one frame per CU: 3000 keypoints; 512 lanes: frames of up to 512 points) takes the prepared launch
+    records as well.  Inference three times on the same lattices -- self-contained, prepare + run, run -- gives the same bits, and
+    they are the oracle's; a handful of frames (< 64) never prepares."""
+    F = 72
+    if case == "c4":
+        sizes, top, shape = [3000, 2500, 2049, 2999, 3, 0, 2700, 3072], 3072, (1024, 1)
+        base = [wl.slam_problem(n, seed=9400 + i) for i, n in enumerate(sizes)]
+    elif case == "n500":
+        sizes, top, shape, F = [500, 512, 1, 0, 333, 257, 400, 64], 512, (512, 2), 264
+        base = [wl.slam_problem(n, seed=9500 + i) for i, n in enumerate(sizes)]
+    elif case == "sparse":                                   # large lattices: the tables take two 16-byte pieces per lane
+        top, shape = 1800, (1024, 1)
+        base = [_shaped_problem(wl, 1500 + 40 * i, "sparse", seed=20 + i) for i in range(4)] + [wl.slam_problem(1800, seed=9600)]
+    elif case in ("k1_chain", "k1_short"):
+        top, shape = 3000, (1024, 1)
+        base = []
+        for i, n in enumerate([3000, 2600, 2100]):
+            q = dict(wl.slam_problem(n, seed=9700 + i)); q["kernels"] = [q["kernels"][0 if case == "k1_chain" else 1]]; base.append(q)
+    elif case == "short_rows":                               # no chain kernel: a frame whose appearance features spread out
+        top, shape = 2500, (1024, 1)
+        base = []
+        for i, n in enumerate([2500, 2100, 2300]):
+            q = dict(wl.slam_problem(n, seed=9800 + i)); q["kernels"] = [q["kernels"][1], q["kernels"][1]]; base.append(q)
+    else:
+        sizes, top, shape, F = [3000, 2500, 2800], 3000, (1024, 1), 8
+        base = [wl.slam_problem(n, seed=9900 + i) for i, n in enumerate(sizes)]
+    pbs = [base[f % len(base)] for f in range(F)]
+    b = _batch_of(pbs, maxN=top)
+    b.build()
+    b.inference(5, True)
+    assert b.engine() == 2 and b.fused_shape() == shape, (case, b.engine(), b.fused_shape())
+    Q, M = b.probability().copy(), b.map().copy()
+    for again in range(2):
+        b.inference(5, True)
+        assert cc.same_bits(b.probability(), Q) and np.array_equal(b.map(), M), (case, again)
+    assert b.last_prepare()[1] == (0 if case == "few_frames" else 1), case
+    b.close()
+    for i, pb in enumerate(base):
+        o = cc.setup(po.OracleCRF, pb)
+        o.inference_native(5, True)
+        for f in (i, i + len(base) * ((F - 1 - i) // len(base))):
+            assert cc.same_bits(Q[f, :pb["N"]], o.probability()), (case, f)
+            assert np.array_equal(M[f, :pb["N"]], o.map()), (case, f)
+        o.close()
 
 
 def test_full_size_frames_share_a_cu_in_the_one_launch_kernel(po, wl):

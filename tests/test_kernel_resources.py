@@ -38,10 +38,12 @@ def test_fused_slam_variants_do_not_spill():
     config C4) -- runs without scratch memory."""
     use = resource_usage("fused_engine.hip")
     fused = {k: v for k, v in use.items() if "k_fusedI" in k}
-    assert len(fused) == 24                                   # 1024 lanes: PPT 1..4 x K 1..2 x {short rows, chain}; 512 lanes: PPT 1..2 x ...
+    # 1024 lanes: PPT 1..4 x K 1..2 x {short rows, chain}; 512 lanes: PPT 1..2 x ...; each x MODE {0 self-contained, 1 prepare, 2 from
+    # the prepared launch records (round 6)}
+    assert len(fused) == 72
     for name, r in fused.items():
-        nt, ppt = (int(x) for x in re.search(r"k_fusedILi(\d+)ELi(\d)E", name).groups())
-        assert nt in (512, 1024)
+        nt, ppt, mode = (int(x) for x in re.search(r"k_fusedILi(\d+)ELi(\d)ELi\dELi\dELi(\d)E", name).groups())
+        assert nt in (512, 1024) and mode in (0, 1, 2)
         # 128 registers per lane: 1024 lanes fill the CU's register file; two 512-lane workgroups (small frames) share it
         assert r["VGPRs"] + r.get("AGPRs", 0) <= 128, name
         if ppt <= 3:
