@@ -141,7 +141,7 @@ def compact_line(full):
         if cb.get("all_cores"):
             line["cpu_baseline"]["all_cores_value"] = g("cpu_baseline", "all_cores", "value")
     for k in ("label_match_vs_cpu_reference", "max_abs_dQ_vs_cpu_reference", "frames_checked", "tiles_identical",
-              "build_ms_per_batch", "frames_per_s_end_to_end", "scaling_measured", "label_gather_ok", "device", "lib_sha16"):
+              "build_ms_per_batch", "prepare_ms_per_batch", "frames_per_s_end_to_end", "scaling_measured", "label_gather_ok", "device", "lib_sha16"):
         if k in full:
             line[k] = _r(full[k])
     if full.get("end_to_end"):
@@ -514,6 +514,7 @@ def slam_subrecord(pkg, wl, torch, dev, name, steps=10, warmup=3, distinct=32):
         ms.append(b.last_timing()["inference_ms"])
     inf_ms = float(np.median(ms))
     lanes, per_cu = b.fused_shape()
+    prepare_ms, _ = b.last_prepare()
     M, Q = b.map(), b.probability()
     frames_checked, label_match, max_dq = check_distinct_frames(pbs, idx, M, Q, n_iter)
     tiles_ok = tiles_identical(torch, b, dev, F, N, idx)
@@ -541,11 +542,11 @@ def slam_subrecord(pkg, wl, torch, dev, name, steps=10, warmup=3, distinct=32):
                         "lanes_per_frame": lanes, "frames_per_cu": per_cu,
                         "lds_floor_ms": t_floor * 1e3, "longest_row": row, "chain_floor_ms": chain_floor(row, n_iter, F, N),
                         "algorithmic_hbm_bytes_per_iteration_frame": algorithmic_bytes_per_iter(N, 2, dims, Vs)},
-           "build_ms_per_batch": build_ms,
+           "build_ms_per_batch": build_ms, "prepare_ms_per_batch": prepare_ms,
            "end_to_end": {"one_launch_ms_per_batch": run_ms, "one_launch_engine": run_engine, "fallback_frames": fb,
                           "one_launch_lanes_per_frame": run_lanes, "one_launch_frames_per_cu": run_per_cu,
                           "one_launch_label_match_vs_cpu_reference": run_match, "one_launch_max_abs_dQ_vs_cpu_reference": run_dq,
-                          "frames_per_s": F / (run_ms * 1e-3), "two_kernel_ms_per_batch": build_ms + inf_ms},
+                          "frames_per_s": F / (run_ms * 1e-3), "two_kernel_ms_per_batch": build_ms + prepare_ms + inf_ms},
            "label_match_vs_cpu_reference": label_match, "max_abs_dQ_vs_cpu_reference": max_dq,
            "frames_checked": frames_checked, "tiles_identical": tiles_ok}
     ptag = latest_profile({"c1": "small_c1", "c4": "fused_c4"}.get(name, "none"))      # committed rocprofv3 summary of `bench.py --workload <name>`
@@ -1170,6 +1171,9 @@ def main():
         kernel_ms.append(b.last_timing()["inference_ms"])
     inf_ms = float(np.median(kernel_ms))
     inf_shape = b.fused_shape()            # (lanes per frame, frames per CU) of the inference kernel just timed
+    # the fused engine's prepared launch records (include/lccrf.h: lccrf_batch_last_prepare): written once behind the build, by the
+    # second inference on its lattices (inside the warm-up here) -- part of the lattice construction, reported beside build_ms
+    prepare_ms, prepare_runs = b.last_prepare()
 
     # end to end per frame = PottsPotential ctors + inference, as the reference pays per frame: ONE launch per frame
     run_ms = None
@@ -1264,12 +1268,14 @@ def main():
                                    "labels per step (%d bytes per rank), %s" % (F * words * 8, "serial" if args.serial_gather else "overlapped with the next step's launch (double-buffered)")},
             "roofline": roof,
             "build_ms_per_batch": build_ms,
-            "frames_per_s_end_to_end": (F * world / (run_ms * 1e-3)) if (run_ms and run_engine == 3) else F * world / ((build_ms + inf_ms) * 1e-3),
+            "prepare_ms_per_batch": prepare_ms,      # once per build: the launch records every later inference on these lattices starts from
+            "prepare_runs": prepare_runs,
+            "frames_per_s_end_to_end": (F * world / (run_ms * 1e-3)) if (run_ms and run_engine == 3) else F * world / ((build_ms + prepare_ms + inf_ms) * 1e-3),
             "end_to_end": {"one_launch_ms_per_batch": run_ms, "one_launch_engine": (run_engine if run_ms else None),
                            "fallback_frames": (run_fallback if run_ms else None),
                            "one_launch_lanes_per_frame": (run_shape[0] if run_ms else None),
                            "one_launch_frames_per_cu": (run_shape[1] if run_ms else None),
-                           "two_kernel_ms_per_batch": build_ms + inf_ms,
+                           "two_kernel_ms_per_batch": build_ms + prepare_ms + inf_ms,
                            "one_launch_hbm_bytes_per_frame": (pmc_traffic(latest_profile("fused_c2"), "k_frame") / F) if ((name, F) == ("c2", DEFAULT_FRAMES) and pmc_traffic(latest_profile("fused_c2"), "k_frame")) else None,
                            "note": "per frame: both PottsPotential3D ctors (lattice + norm) + inference(n, true); one_launch = "
                                    "lccrf_batch_run (frame_lean.hip / frame_engine.hip), wall clock over back-to-back batches; two_kernel = HIP "

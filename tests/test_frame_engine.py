@@ -758,8 +758,8 @@ def test_repeated_inference_runs_from_prepared_records_in_every_fused_shape(po, 
         sizes, top, shape, F = [500, 512, 1, 0, 333, 257, 400, 64], 512, (512, 2), 264
         base = [wl.slam_problem(n, seed=9500 + i) for i, n in enumerate(sizes)]
     elif case == "sparse":                                   # large lattices: the tables take two 16-byte pieces per lane
-        top, shape = 1800, (1024, 1)
-        base = [_shaped_problem(wl, 1500 + 40 * i, "sparse", seed=20 + i) for i in range(4)] + [wl.slam_problem(1800, seed=9600)]
+        top, shape = 850, (1024, 1)                          # (V = 3 N for the first kernel: ~30 KB of neighbour words at 820 points)
+        base = [_shaped_problem(wl, n, "sparse", seed=20 + i) for i, n in enumerate([700, 760, 820, 640])] + [wl.slam_problem(850, seed=9600)]
     elif case in ("k1_chain", "k1_short"):
         top, shape = 3000, (1024, 1)
         base = []
