@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define LCCRF_ABI_VERSION 3   /* 3: lccrf_batch_last_prepare, lccrf_batch_synchronize scoped to the batch's streams; 2: lccrf_batch_get_fused_shape, the asynchronous host path of the batch API, lccrf_set_option's option 3 (LCCRF_OPT_COPY_THREADS) */
+#define LCCRF_ABI_VERSION 3   /* 3: lccrf_batch_last_prepare, LCCRF_OPT_EVENT_TIMING, lccrf_batch_synchronize scoped to the batch's streams; 2: lccrf_batch_get_fused_shape, the asynchronous host path of the batch API, lccrf_set_option's option 3 (LCCRF_OPT_COPY_THREADS) */
 #define LCCRF_MAX_KERNELS 8      /* pairwise terms per CRF                        */
 #define LCCRF_MAX_DIMS    8      /* feature dimensions per kernel (reference uses <= 6) */
 #define LCCRF_MAX_LABELS  64
@@ -83,13 +83,17 @@ int  lccrf_trim_cache(void);
  *       Z-order curve of the points).  Results never depend on how vertices are found or numbered.
  *   LCCRF_OPT_COPY_THREADS   (batches; 1 .. 64, default 8) host threads that copy the caller's arrays into the batch's pinned
  *       staging in lccrf_batch_set_inputs_host_async (one core copies ~10 GB/s, the PCIe link takes ~50).
+ *   LCCRF_OPT_EVENT_TIMING   (batches; default 1) value 0: lccrf_batch_build / _inference / _run record no HIP events around their
+ *       work and lccrf_batch_last_timing reads 0.  An event record is a packet of its own between two launches: ~20 us per call on a
+ *       stream that is kept busy, 1-2 % of a 1.7 ms batch -- a replay loop that does not read the timings turns them off.
  * lccrf_set_option applies to one handle (set it after lccrf_create: a handle taken from the cache starts from the defaults) and is
  * per handle only for LCCRF_OPT_VERTEX_ORDER and LCCRF_OPT_COPY_THREADS; lccrf_set_default_option applies LCCRF_OPT_SINGLE_WORKGROUP
  * to every handle and batch created afterwards in this process.                                                              */
 typedef enum lccrf_option {
     LCCRF_OPT_SINGLE_WORKGROUP = 1,
     LCCRF_OPT_VERTEX_ORDER     = 2,
-    LCCRF_OPT_COPY_THREADS     = 3
+    LCCRF_OPT_COPY_THREADS     = 3,
+    LCCRF_OPT_EVENT_TIMING     = 4
 } lccrf_option;
 int  lccrf_set_option(lccrf_handle h, int option, int value);
 int  lccrf_set_default_option(int option, int value);

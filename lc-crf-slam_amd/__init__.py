@@ -343,6 +343,7 @@ class BatchCRF:
     HOST_PINNED = 1
     DOWNLOAD_LABEL_BITS, DOWNLOAD_MAP, DOWNLOAD_PROBABILITY = 1, 2, 4
     OPT_COPY_THREADS = 3
+    OPT_EVENT_TIMING = 4
 
     def set_inputs_host_async(self, n_points, features, unary=None, label=None, conf=None, pinned=False):
         """lccrf_batch_set_inputs_host_async: the arrays are staged and uploaded without a host wait.  The arrays must already be

@@ -222,6 +222,7 @@ struct Engine {
     int late_iter = 0, late_map = 0;
     float late_relax = 1.0f;
     bool timed_build = false, timed_inf = false;
+    bool event_timing = true;          // LCCRF_OPT_EVENT_TIMING: HIP events around every build / inference / run of the batch API
     // Locality mode (batch engines, frames of >= kPermMinPoints points on the streaming engine): the lattices are built
     // with the points in an internal Z-order of their lattice cells (stream_engine.hip: launch_sort_points); Q, next and
     // the unaries of the iteration live in that order (Qp, unary_p / unary_own) and Q is un-permuted on the way out.
@@ -1342,6 +1343,11 @@ int lccrf_batch_set_option(lccrf_batch_handle b, int option, int value)
         b->pipe.copy_threads = value;
         return LCCRF_OK;
     }
+    if (option == LCCRF_OPT_EVENT_TIMING) {
+        b->eng.event_timing = value != 0;
+        if (!value) b->eng.timed_build = b->eng.timed_inf = false;
+        return LCCRF_OK;
+    }
     return apply_option(b->eng, option, value);
 }
 
@@ -2093,14 +2099,14 @@ int lccrf_batch_build(lccrf_batch_handle b, void *stream)
     StreamScope scope(e, stream);
     int rc = scope.enter();
     if (rc) return rc;
-    HIP_TRY(hipEventRecord(e.ev[0], e.stream));
+    if (e.event_timing) HIP_TRY(hipEventRecord(e.ev[0], e.stream));
     if (!e.kernels.empty()) rc = e.build_kernels(0, (int)e.kernels.size());
     e.built_upto = (int)e.kernels.size();
-    if (!rc) {
+    if (!rc && e.event_timing) {
         hipError_t er = hipEventRecord(e.ev[1], e.stream);
         if (er != hipSuccess) rc = fail(LCCRF_E_HIP, "hipEventRecord: %s", hipGetErrorString(er));
     }
-    e.timed_build = !rc;
+    e.timed_build = !rc && e.event_timing;
     e.built = !rc;
     return rc;                                        // (learn_sizes() waits on the own stream, which ~StreamScope orders behind this one)
 }
@@ -2114,13 +2120,13 @@ int lccrf_batch_inference(lccrf_batch_handle b, int n_iterations, int with_map, 
     if (rc) return rc;
     StreamScope scope(e, stream);
     if ((rc = scope.enter())) return rc;
-    HIP_TRY(hipEventRecord(e.ev[2], e.stream));
+    if (e.event_timing) HIP_TRY(hipEventRecord(e.ev[2], e.stream));
     rc = e.inference(n_iterations, with_map, relax);
-    if (!rc) {
+    if (!rc && e.event_timing) {
         hipError_t er = hipEventRecord(e.ev[3], e.stream);
         if (er != hipSuccess) rc = fail(LCCRF_E_HIP, "hipEventRecord: %s", hipGetErrorString(er));
     }
-    e.timed_inf = !rc;
+    e.timed_inf = !rc && e.event_timing;
     return rc;
 }
 
@@ -2132,13 +2138,13 @@ int lccrf_batch_run(lccrf_batch_handle b, int n_iterations, int with_map, float 
     StreamScope scope(e, stream);
     int rc = scope.enter();
     if (rc) return rc;
-    HIP_TRY(hipEventRecord(e.ev[2], e.stream));
+    if (e.event_timing) HIP_TRY(hipEventRecord(e.ev[2], e.stream));
     rc = e.run(n_iterations, with_map, relax);
-    if (!rc) {
+    if (!rc && e.event_timing) {
         hipError_t er = hipEventRecord(e.ev[3], e.stream);
         if (er != hipSuccess) rc = fail(LCCRF_E_HIP, "hipEventRecord: %s", hipGetErrorString(er));
     }
-    e.timed_inf = !rc;
+    e.timed_inf = !rc && e.event_timing;
     e.built = e.built_upto == (int)e.kernels.size() && !e.kernels.empty();
     return rc;
 }

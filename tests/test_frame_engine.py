@@ -793,6 +793,26 @@ def test_repeated_inference_runs_from_prepared_records_in_every_fused_shape(po, 
         o.close()
 
 
+def test_event_timing_option_only_switches_the_events_off(po, wl):
+    """LCCRF_OPT_EVENT_TIMING = 0: no HIP events around build / inference / run (a packet less between two launches), timings read 0,
+    results unchanged; 1 brings them back."""
+    pbs = [wl.slam_problem(700, seed=9950 + i) for i in range(4)]
+    b = _batch_of(pbs)
+    b.build(); b.inference(5, True)
+    Q = b.probability().copy()
+    assert b.last_timing()["inference_ms"] > 0 and b.last_timing()["build_ms"] > 0
+    b.set_option(pkg.BatchCRF.OPT_EVENT_TIMING, 0)
+    b.build(); b.inference(5, True)
+    assert b.last_timing() == dict(inference_ms=0.0, build_ms=0.0)
+    assert cc.same_bits(b.probability(), Q)
+    b.run(5, True)
+    assert b.last_timing()["inference_ms"] == 0.0 and cc.same_bits(b.probability(), Q)
+    b.set_option(pkg.BatchCRF.OPT_EVENT_TIMING, 1)
+    b.run(5, True)
+    assert b.last_timing()["inference_ms"] > 0 and cc.same_bits(b.probability(), Q)
+    b.close()
+
+
 def test_full_size_frames_share_a_cu_in_the_one_launch_kernel(po, wl):
     """Round 5: lccrf_batch_run on batches of >= 256 full-size two-kernel frames (1025 .. 2048 points) runs the WHOLE frame -- both
     lattice builds, normalisation, inference -- in 512-lane workgroups on half a CU (csrc/frame_lean.hip: LDS scratch laid out by
