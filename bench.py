@@ -955,11 +955,17 @@ def pmc_traffic(tag, kernel="k_fused", corrected=True):
     fn = os.path.join(ROOT, "profiles", tag or "", "pmc_summary.csv")
     if not tag or not os.path.exists(fn):
         return None
-    tot = 0.0
+    # (several instances of a kernel template may match -- the self-contained first inference, the once-per-build prepare launch, the
+    # steady-state kernel: the instance with the most dispatches is the one the timed region runs)
+    by_name = {}
     for r in csv.DictReader(open(fn)):
         if kernel in r["kernel"]:
-            tot += float(r["bytes_corrected" if corrected else "bytes_per_dispatch"])
-    return tot or None
+            e = by_name.setdefault(r["kernel"], [0, 0.0])
+            e[0] = max(e[0], int(r["dispatches"]))
+            e[1] += float(r["bytes_corrected" if corrected else "bytes_per_dispatch"])
+    if not by_name:
+        return None
+    return max(by_name.values(), key=lambda e: e[0])[1] or None
 
 
 # ---------------------------------------------------------------------------------------------

@@ -13,12 +13,21 @@ run p3 "TCC_EA0_RDREQ_LEVEL_sum TCC_EA0_RDREQ_DRAM_CREDIT_STALL_sum TCC_EA0_WRRE
 python3 - <<'PY'
 import csv, collections, glob, os
 kerns = os.environ.get("KERNELS", "k_fused k_frame").split()
-agg = collections.defaultdict(list)
+raw = collections.defaultdict(list)
 for fn in glob.glob("gpurun_out/prof/tcc/p*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(fn)):
         for k in kerns:
-            if k in r["Kernel_Name"] and "ELi1EEEv" not in r["Kernel_Name"]:      # (not the once-per-build prepare launch)
-                agg[(k, r["Counter_Name"])].append(float(r["Counter_Value"]))
+            if k in r["Kernel_Name"]:
+                raw[(k, r["Kernel_Name"], r["Counter_Name"])].append(float(r["Counter_Value"]))
+# several instances of a template may match (the self-contained first inference, the once-per-build prepare launch, the steady-state
+# kernel): the instance with the most dispatches is reported
+best = {}
+for (k, name, c), v in raw.items():
+    if k not in best or len(v) > best[k][1]:
+        best[k] = (name, len(v))
+agg = {(k, c): v for (k, name, c), v in raw.items() if best[k][0] == name}
+for k, (name, n) in sorted(best.items()):
+    print("# %s = %s" % (k, name[:150]))
 m = {k: sum(v) / len(v) for k, v in agg.items()}
 for (kern, c), v in sorted(m.items()):
     print("%-9s %-40s mean/dispatch %.5g  (n=%d)" % (kern, c, v, len(agg[(kern, c)])))
