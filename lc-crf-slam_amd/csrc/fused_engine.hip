@@ -146,7 +146,7 @@ __global__ void __launch_bounds__(NT, 4) k_fused(CrfDev c, FusedArgs a)
         float alpha[K];
 #pragma unroll
         for (int k = 0; k < K; ++k) alpha[k] = a.kd[k].alpha;
-        mean_field<PPT, K, CH, NT, true, true>(smem, lay, V, N, tid, pr, cl, alpha, a.n_iter, a.relax, ins);
+        mean_field<PPT, K, CH, NT, true>(smem, lay, V, N, tid, pr, cl, alpha, a.n_iter, a.relax, ins);
         store_results<PPT, K, NT>(c, f, N, tid, pr, a.with_map);
         FL_STAMP();
         if (kInstr && a.timing && (int)blockIdx.x == a.timing_block && tid == a.timing_lane) a.timing[63] = ins.n;
@@ -275,7 +275,7 @@ __global__ void __launch_bounds__(NT, 4) k_fused(CrfDev c, FusedArgs a)
     float alpha[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) alpha[k] = a.kd[k].alpha;
-    mean_field<PPT, K, CH, NT, true, true>(smem, lay, V, N, tid, pr, cl, alpha, a.n_iter, a.relax, ins);
+    mean_field<PPT, K, CH, NT, true>(smem, lay, V, N, tid, pr, cl, alpha, a.n_iter, a.relax, ins);
 
     store_results<PPT, K, NT>(c, f, N, tid, pr, a.with_map);
     FL_STAMP();

@@ -47,10 +47,6 @@ constexpr bool kFuseXP = LCCRF_FUSE_XP != 0;     // A/B switch (scripts/gpu_ab_b
 #ifndef LCCRF_INSTRUMENT
 #define LCCRF_INSTRUMENT 0
 #endif
-#ifndef LCCRF_OVL_SHARED
-#define LCCRF_OVL_SHARED 1
-#endif
-constexpr bool kOvlShared = LCCRF_OVL_SHARED != 0;   // A/B switch (scripts/gpu_ab_build.sh): shared product buffer, kernel 1's first blur pass beside kernel 0's chain
 constexpr bool kInstr = LCCRF_INSTRUMENT != 0;   // `make INSTRUMENT=1`; the release library has no stamps and no phase-skipping switches
 
 struct FusedLayout {                      // byte offsets into dynamic LDS
@@ -369,9 +365,7 @@ __device__ __forceinline__ void chain_pads(unsigned char *smem, const ChainLane 
 // KMASK: the kernels that take part (bit k) -- all of them in the loop; the frame kernel's two-workgroup form normalises
 // its kernels one at a time (frame_engine.hip).
 // REV: see the blur passes.
-// OVLS: the shared-buffer schedule with kernel 1's first blur pass beside kernel 0's chain (k_fused; the frame kernel's 3-points-per-lane
-// variants do not have the registers for the second pass body: 64 bytes of scratch per lane)
-template <int PPT, int K, int CH, bool WITH_P = true, int NT = kNT, int KMASK = (1 << K) - 1, bool REV = false, bool OVLS = false>
+template <int PPT, int K, int CH, bool WITH_P = true, int NT = kNT, int KMASK = (1 << K) - 1, bool REV = false>
 __device__ __forceinline__ void splat_blur(unsigned char *smem, const FusedLayout &lay, const int (&V)[K], int N, int tid,
                                            const PointRegs<PPT, K> &pr, const ChainLane &cl, Instr &ins)
 {
@@ -423,7 +417,6 @@ __device__ __forceinline__ void splat_blur(unsigned char *smem, const FusedLayou
         }
     };
     constexpr auto on = [](int k) { return ((KMASK >> k) & 1) != 0; };
-    bool ovl_done = false;
     if (lay.prod_all) {
         if (WITH_P) {
 #pragma unroll
@@ -438,36 +431,6 @@ __device__ __forceinline__ void splat_blur(unsigned char *smem, const FusedLayou
             if (on(k)) phase_S(k, s_lo);                               // the chain kernel is kernel 0: it starts first
         __syncthreads();
         FL_STAMP();
-    } else if (OVLS && kOvlShared && K == 2 && KMASK == 3 && chain_k<CH>(lay, 0)) {
-        // One shared product buffer and a chain kernel (3000-point frames: BASELINE config 4): the kernels take the buffer one after the
-        // other, and while kernel 0's longest rows are added -- three wavefront pairs at most, ~6.8k cycles at 3000 points -- the other
-        // wavefronts used to wait.  Kernel 1 goes FIRST now, so that its row sums are complete two barriers before the chain starts and
-        // the wavefronts without chain rows run its first blur pass beside the chain (round 6; the same operations on the same values).
-        phase_P(1);
-        __syncthreads();
-        phase_S(1, 0);
-        __syncthreads();
-        phase_P(0);
-        __syncthreads();
-        phase_S(0, 0);
-        {
-            const int lo = 128 * (1 + ((max(V[0] - kChainTop, 0) + 63) >> 6));       // the first lane behind the chain pairs (whole wavefronts)
-            if (tid >= lo) {
-                const float2 *src = reinterpret_cast<const float2 *>(smem + lay.val[1][0]);
-                float2 *dst = reinterpret_cast<float2 *>(smem + lay.val[1][1]);
-                const unsigned *nbr = reinterpret_cast<const unsigned *>(smem + lay.nbr[1]);
-                for (int v = tid - lo; v < V[1]; v += NT - lo) {
-                    const unsigned n = nbr[v];
-                    const float2 o = src[v + 1], x = src[n & 0xffffu], y = src[n >> 16];
-                    float2 r;
-                    r.x = o.x + 0.5f * (x.x + y.x);
-                    r.y = o.y + 0.5f * (x.y + y.y);
-                    dst[v + 1] = r;
-                }
-            }
-        }
-        __syncthreads();
-        ovl_done = true;
     } else {
 #pragma unroll
         for (int k = 0; k < K; ++k) {
@@ -485,7 +448,6 @@ __device__ __forceinline__ void splat_blur(unsigned char *smem, const FusedLayou
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             if (!on(k)) continue;
-            if (j == 0 && k == 1 && ovl_done) continue;   // (ran beside the chain)
             const float2 *src = reinterpret_cast<const float2 *>(smem + lay.val[k][j & 1]);
             float2 *dst = reinterpret_cast<float2 *>(smem + lay.val[k][(j & 1) ^ 1]);
             const unsigned *nbr = reinterpret_cast<const unsigned *>(smem + lay.nbr[k]) + j * V[k];
@@ -562,7 +524,7 @@ __device__ __forceinline__ void start_inference(PointRegs<PPT, K> &pr, int N, in
 // already put kernel k's in place (the frame kernel's two-workgroup form, while it waits for the other lattice) clears bit k.
 // No barrier is needed behind X: the next P only writes the product buffers, whose readers finished
 // two barriers ago.
-template <int PPT, int K, int CH, int NT = kNT, bool REV = false, bool OVLS = false>
+template <int PPT, int K, int CH, int NT = kNT, bool REV = false>
 __device__ __forceinline__ void mean_field(unsigned char *smem, const FusedLayout &lay, const int (&V)[K], int N, int tid,
                                            PointRegs<PPT, K> &pr, const ChainLane &cl, const float (&alpha)[K], int n_iter,
                                            float relax, Instr &ins, int first_p = -1)
@@ -595,7 +557,7 @@ __device__ __forceinline__ void mean_field(unsigned char *smem, const FusedLayou
         }
         for (int it = 0; it < n_iter; ++it) {
             opaque(pr);
-            splat_blur<PPT, K, CH, false, NT, (1 << K) - 1, REV, OVLS>(smem, lay, V, N, tid, pr, cl, ins);
+            splat_blur<PPT, K, CH, false, NT, (1 << K) - 1, REV>(smem, lay, V, N, tid, pr, cl, ins);
             const bool more = it + 1 < n_iter;
 #pragma unroll
             for (int s = 0; s < PPT; ++s) {
@@ -613,7 +575,7 @@ __device__ __forceinline__ void mean_field(unsigned char *smem, const FusedLayou
     }
     for (int it = 0; it < n_iter; ++it) {
         opaque(pr);
-        splat_blur<PPT, K, CH, true, NT, (1 << K) - 1, REV, OVLS>(smem, lay, V, N, tid, pr, cl, ins);
+        splat_blur<PPT, K, CH, true, NT, (1 << K) - 1, REV>(smem, lay, V, N, tid, pr, cl, ins);
 #pragma unroll
         for (int s = 0; s < PPT; ++s)
             if (tid + s * NT < N) point_update(s);
