@@ -126,10 +126,10 @@ def compact_line(full):
     line = {k: _r(full.get(k)) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
                                          "scaling", "vs_baseline", "dtype", "data")}
     cfg = full.get("config") or {}
-    line["config"] = {k: _r(cfg.get(k)) for k in ("workload", "frames_in_flight_per_gpu", "distinct_frames", "n_points", "n_iters",
+    line["config"] = {k: _r(cfg.get(k)) for k in ("workload", "frames_in_flight_per_gpu", "handles", "distinct_frames", "n_points", "n_iters",
                                                   "n_labels", "kernel_dims", "mean_lattice_vertices", "engine") if k in cfg}
     line["roofline"] = {k: _r(roof.get(k)) for k in ("bound", "achieved", "peak", "unit", "frac", "launch_ms", "traffic",
-                                                     "hbm_counter_frac", "lanes_per_frame", "frames_per_cu",
+                                                     "hbm_counter_frac", "frames_per_launch", "lanes_per_frame", "frames_per_cu",
                                                      "algorithmic_hbm_bytes_per_launch", "algorithmic_bytes_per_launch") if k in roof}
     if _pick(roof, "valu_issue", "frac") is not None:
         line["roofline"]["valu_issue_frac"] = g("roofline", "valu_issue", "frac")
@@ -479,7 +479,7 @@ def cpp_caller_latency(pbs, reps):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
-def slam_subrecord(pkg, wl, torch, dev, name, steps=10, warmup=3, distinct=32):
+def slam_subrecord(pkg, wl, torch, dev, name, steps=10, warmup=3, distinct=32, handles=2):
     """One more SLAM-shaped configuration, timed exactly like the headline (lccrf_batch_inference over F frames resident
     in HBM, wall clock over `steps` back-to-back batches, HIP events for the launch) -- the default line's C1 / C3 / C4 /
     N500 sub-records, so that every configuration of BASELINE.json is driver-timed."""
@@ -493,20 +493,32 @@ def slam_subrecord(pkg, wl, torch, dev, name, steps=10, warmup=3, distinct=32):
     d_label = torch.from_numpy(label).to(dev)
     d_np = torch.full((F,), N, dtype=torch.int32, device=dev)
     torch.cuda.synchronize()
-    b = pkg.BatchCRF(F, N, 2, dims, weights, device=dev.index)
-    b.bind_inputs_device(F, d_np.data_ptr(), [t.data_ptr() for t in d_feats], d_label=d_label.data_ptr(), conf=pbs[0]["conf"])
-    b.build(); b.synchronize(); b.build(); b.synchronize()
-    build_ms = b.last_timing()["build_ms"]
+    H = handles                                          # (as the main record: handles of F / H frames, a stream each)
+    Fh = F // H
+    bs, streams, build_ms = [], [], 0.0
+    for h in range(H):
+        lo, hi = h * Fh, (h + 1) * Fh
+        bh = pkg.BatchCRF(Fh, N, 2, dims, weights, device=dev.index)
+        bh.bind_inputs_device(Fh, d_np[lo:hi].data_ptr(), [t[lo:hi].data_ptr() for t in d_feats], d_label=d_label[lo:hi].data_ptr(), conf=pbs[0]["conf"])
+        bh.build(); bh.synchronize(); bh.build(); bh.synchronize()
+        build_ms += bh.last_timing()["build_ms"]
+        bh.set_option(pkg.BatchCRF.OPT_EVENT_TIMING, 0)
+        bs.append(bh)
+        streams.append(torch.cuda.Stream(dev))
+    b = bs[0]
     engine = b.engine()
-    Vs = [float(b.lattice_sizes(k).astype(np.float64).mean()) for k in range(len(dims))]
-    b.set_option(pkg.BatchCRF.OPT_EVENT_TIMING, 0)
+    Vs = [float(np.concatenate([bh.lattice_sizes(k) for bh in bs]).astype(np.float64).mean()) for k in range(len(dims))]
+
+    def all_of(what):
+        for bh, st in zip(bs, streams):
+            (bh.inference if what == "inference" else bh.run)(n_iter, True, stream=st.cuda_stream)
     for _ in range(warmup):
-        b.inference(n_iter, True)
-    b.synchronize()
+        all_of("inference")
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
-        b.inference(n_iter, True)
-    b.synchronize()
+        all_of("inference")
+    torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     b.set_option(pkg.BatchCRF.OPT_EVENT_TIMING, 1)
     ms = []
@@ -514,35 +526,36 @@ def slam_subrecord(pkg, wl, torch, dev, name, steps=10, warmup=3, distinct=32):
         b.inference(n_iter, True)                       # (two back to back, the SECOND one event-timed: a launch that starts on a busy GPU,
         b.inference(n_iter, True)                       #  not on one that has just idled through a host-side synchronisation)
         ms.append(b.last_timing()["inference_ms"])
-    inf_ms = float(np.median(ms))
+    inf_ms = float(np.median(ms))                       # ONE handle's launch: Fh frames
     lanes, per_cu = b.fused_shape()
-    prepare_ms, _ = b.last_prepare()
-    M, Q = b.map(), b.probability()
+    prepare_ms = sum(bh.last_prepare()[0] for bh in bs)
+    M = np.concatenate([bh.map() for bh in bs])
+    Q = np.concatenate([bh.probability() for bh in bs])
     frames_checked, label_match, max_dq = check_distinct_frames(pbs, idx, M, Q, n_iter)
-    tiles_ok = tiles_identical(torch, b, dev, F, N, idx)
+    tiles_ok = all(tiles_identical(torch, bh, dev, Fh, N, idx[h * Fh:(h + 1) * Fh]) for h, bh in enumerate(bs))
     for _ in range(2):
-        b.run(n_iter, True)
-    b.synchronize()
+        all_of("run")
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(max(steps // 2, 3)):
-        b.run(n_iter, True)
-    b.synchronize()
+        all_of("run")
+    torch.cuda.synchronize()
     run_ms = (time.perf_counter() - t0) / max(steps // 2, 3) * 1e3
-    run_engine, fb = b.engine(), b.fallback_frames()
+    run_engine, fb = b.engine(), sum(bh.fallback_frames() for bh in bs)
     run_lanes, run_per_cu = b.fused_shape()
     # (the one-launch results through the same gate: every distinct frame against the CPU checker)
-    _, run_match, run_dq = check_distinct_frames(pbs, idx, b.map(), b.probability(), n_iter)
+    _, run_match, run_dq = check_distinct_frames(pbs, idx, np.concatenate([bh.map() for bh in bs]), np.concatenate([bh.probability() for bh in bs]), n_iter)
     lds_bytes, lds_clocks, _ = fused_lds_model(N, dims, Vs, True, per_cu == 2 and N > 1024)
     row = longest_rows(pkg, pbs)
-    t_floor = lds_clocks * n_iter * F / N_CU / CLK_HZ
-    achieved = lds_bytes * n_iter * F / (inf_ms * 1e-3) / 1e9
-    peak = lds_bytes * n_iter * F / t_floor / 1e9
-    rec = {"workload": desc, "frames_in_flight": F, "value": F * n_iter / dt, "unit": "iters/s", "ms_per_step": dt * 1e3,
+    t_floor = lds_clocks * n_iter * Fh / N_CU / CLK_HZ
+    achieved = lds_bytes * n_iter * Fh / (inf_ms * 1e-3) / 1e9
+    peak = lds_bytes * n_iter * Fh / t_floor / 1e9
+    rec = {"workload": desc, "frames_in_flight": F, "handles": H, "value": F * n_iter / dt, "unit": "iters/s", "ms_per_step": dt * 1e3,
            "engine": {1: "streaming", 2: "fused"}.get(engine, str(engine)), "mean_lattice_vertices": Vs,
            "roofline": {"bound": "lds" if engine == 2 else "hbm", "achieved": achieved, "peak": peak, "unit": "GB/s",
                         "frac": achieved / peak, "launch_ms": inf_ms, "lds_bytes_per_iteration_frame": lds_bytes,
                         "lanes_per_frame": lanes, "frames_per_cu": per_cu,
-                        "lds_floor_ms": t_floor * 1e3, "longest_row": row, "chain_floor_ms": chain_floor(row, n_iter, F, N),
+                        "frames_per_launch": Fh, "lds_floor_ms": t_floor * 1e3, "longest_row": row, "chain_floor_ms": chain_floor(row, n_iter, Fh, N),
                         "algorithmic_hbm_bytes_per_iteration_frame": algorithmic_bytes_per_iter(N, 2, dims, Vs)},
            "build_ms_per_batch": build_ms, "prepare_ms_per_batch": prepare_ms,
            "end_to_end": {"one_launch_ms_per_batch": run_ms, "one_launch_engine": run_engine, "fallback_frames": fb,
@@ -556,7 +569,8 @@ def slam_subrecord(pkg, wl, torch, dev, name, steps=10, warmup=3, distinct=32):
         tr = pmc_traffic(ptag, "k_fused")
         rec["roofline"].update({"profile": "profiles/%s (kernel_stats.csv: the launch duration; pmc_summary.csv: FETCH x2 + WRITE)" % ptag,
                                 "traffic": tr, "hbm_counter_frac": (tr / (inf_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if tr else None})
-    b.close()
+    for bh in bs:
+        bh.close()
     del d_feats, d_label, d_np
     torch.cuda.empty_cache()
     return rec
@@ -1027,6 +1041,8 @@ def main():
     ap.add_argument("--host-to-host", action="store_true", help="only the pipelined host-to-host record (end_to_end.host_to_host)")
     ap.add_argument("--full-json", default=os.path.join(ROOT, "bench_full.json"),
                     help="where the complete nested record goes (the LAST stdout line is the compact one the driver parses)")
+    ap.add_argument("--handles", type=int, default=0,
+                    help="batch handles (each with its own stream) that share the frames in flight; 0 = 2 for SLAM workloads of >= 512 frames, else 1")
     ap.add_argument("--lite", action="store_true",
                     help="counter-collection runs (rocprofv3 --pmc serialises every dispatch): one event-timed launch instead of "
                          "five, two one-launch batches instead of many -- the timed region itself is unchanged")
@@ -1077,6 +1093,14 @@ def main():
     distinct = 1 if name == "c5" else min(F, args.distinct)
     pbs, idx, feats, label, dims, weights = make_batch(wl, name, F, rank, distinct)
     L = 2
+    # The batch is held by H handles of F / H frames each, every one on a stream of its own: a step launches all of them, so the tail of
+    # one launch (its last workgroups, CUs going idle one by one: half a workgroup's 53 us on average) runs under the head of the
+    # next handle's launch -- what a replay loop over many batches does anyway (tools/host_pipeline.cpp: 3-4 handles round-robin).
+    # C2, same box: 1 x 16384 frames 4.83e7, 2 x 8192 5.02e7, 4 x 4096 4.88e7 iterations/s (scripts/two_handles_probe.py).
+    H = args.handles or (1 if (name == "c5" or F < 512) else 2)
+    if F % H:
+        raise SystemExit("--frames %d is not a multiple of --handles %d" % (F, H))
+    Fh = F // H
 
     # inputs resident in HBM before the timed region (torch = allocator plumbing)
     d_feats = [torch.from_numpy(f).to(dev) for f in feats]
@@ -1084,49 +1108,66 @@ def main():
     d_np = torch.full((F,), N, dtype=torch.int32, device=dev)
     torch.cuda.synchronize()
 
-    b = pkg.BatchCRF(F, N, L, dims, weights, device=local_rank)
-    b.set_engine(args.engine)
-    b.bind_inputs_device(F, d_np.data_ptr(), [t.data_ptr() for t in d_feats], d_label=d_label.data_ptr(),
-                         conf=pbs[0]["conf"])
-    b.build()                                        # first build: also allocates and zeroes the lattice arrays
-    b.synchronize()
-    b.build()                                        # steady state (what a replay loop pays per batch)
-    b.synchronize()
-    build_ms = b.last_timing()["build_ms"]
+    class Lane:                                      # one handle: its slice of the frames, its stream, its label gather
+        pass
+    lanes = []
+    for h in range(H):
+        ln = Lane()
+        lo, hi = h * Fh, (h + 1) * Fh
+        ln.lo, ln.hi = lo, hi
+        ln.b = pkg.BatchCRF(Fh, N, L, dims, weights, device=local_rank)
+        ln.b.set_engine(args.engine)
+        ln.b.bind_inputs_device(Fh, d_np[lo:hi].data_ptr(), [t[lo:hi].data_ptr() for t in d_feats], d_label=d_label[lo:hi].data_ptr(),
+                                conf=pbs[0]["conf"])
+        ln.b.build()                                 # first build: also allocates and zeroes the lattice arrays
+        ln.b.synchronize()
+        ln.b.build()                                 # steady state (what a replay loop pays per batch)
+        ln.b.synchronize()
+        ln.build_ms = ln.b.last_timing()["build_ms"]
+        # (one handle: torch's current stream, as before; several: a stream each)
+        ln.stream = torch.cuda.current_stream(dev) if H == 1 else torch.cuda.Stream(dev)
+        bits_ptr, words = ln.b.device_label_bits()
+        ln.bits_view = torch.as_tensor(CudaView(bits_ptr, (Fh, words), "<i8"), device=dev)
+        # The label gather of step i overlaps the inference of step i+1 (lc-crf-slam_amd/sharding.py: OverlappedLabelGather):
+        # the bits a launch wrote are copied (device to device) into one of two staging buffers on the compute stream and the
+        # all_gather of that buffer runs asynchronously on the collective's own stream.
+        ln.gather = sh.OverlappedLabelGather(ln.bits_view, world, serial=args.serial_gather) if world > 1 else None
+        lanes.append(ln)
+    b = lanes[0].b
+    build_ms = sum(ln.build_ms for ln in lanes)
     engine = b.engine()
-    Vs = [float(b.lattice_sizes(k).astype(np.float64).mean()) for k in range(len(dims))]
-
-    bits_ptr, words = b.device_label_bits()
-    bits_view = torch.as_tensor(CudaView(bits_ptr, (F, words), "<i8"), device=dev)
-    # The label gather of step i overlaps the inference of step i+1 (lc-crf-slam_amd/sharding.py: OverlappedLabelGather):
-    # the bits a launch wrote are copied (device to device) into one of two staging buffers on the compute stream and the
-    # all_gather of that buffer runs asynchronously on the collective's own stream.
-    gather = sh.OverlappedLabelGather(bits_view, world, serial=args.serial_gather) if world > 1 else None
-    # the library's kernels, the staging copy and the collective's wait all go through torch's current stream
-    stream = torch.cuda.current_stream(dev).cuda_stream
+    Vs = [float(np.concatenate([ln.b.lattice_sizes(k) for ln in lanes]).astype(np.float64).mean()) for k in range(len(dims))]
 
     def barrier():
-        if gather is not None:                      # every gather of the timed region has finished when the clock stops
-            gather.wait_all()
+        for ln in lanes:
+            if ln.gather is not None:               # every gather of the timed region has finished when the clock stops
+                with torch.cuda.stream(ln.stream):
+                    ln.gather.wait_all()
         # The host polls for the end of the queued work before the (contractual) barrier + synchronize: a thread that SLEEPS in
         # hipDeviceSynchronize wakes up tens of microseconds to a millisecond after the GPU has finished, which a 38 ms timed
         # region of 20 steps reads as up to 4 % (profiles/r5_fused_c2/bench_repeat.txt, first run of a process).
-        ev = torch.cuda.Event()
-        ev.record()
-        while not ev.query():
+        evs = []
+        for ln in lanes:
+            ev = torch.cuda.Event()
+            ev.record(ln.stream)
+            evs.append(ev)
+        while not all(ev.query() for ev in evs):
             pass
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
     def step():
-        b.inference(n_iter, True, stream=stream)
-        if gather is not None:                      # the one collective of the path: the label gather, every batch (RCCL)
-            gather.push()
+        for ln in lanes:
+            with torch.cuda.stream(ln.stream):      # the library's kernels, the staging copy and the collective's wait all go through this stream
+                ln.b.inference(n_iter, True, stream=ln.stream.cuda_stream)
+                if ln.gather is not None:           # the one collective of the path: the label gather, every batch (RCCL)
+                    ln.gather.push()
 
     # the timed region records no HIP events between its launches (LCCRF_OPT_EVENT_TIMING = 0: what a replay loop that does not read
     # per-batch timings sets); the kernel's own duration is event-timed afterwards, on the same stream
-    b.set_option(pkg.BatchCRF.OPT_EVENT_TIMING, 0)
+    for ln in lanes:
+        ln.b.set_option(pkg.BatchCRF.OPT_EVENT_TIMING, 0)
     for _ in range(args.warmup):                    # (RCCL sets its rings up on first use)
         step()
     barrier()
@@ -1135,9 +1176,11 @@ def main():
         step()
     barrier()
     t1 = time.perf_counter()
-    b.set_option(pkg.BatchCRF.OPT_EVENT_TIMING, 1)
+    for ln in lanes:
+        ln.b.set_option(pkg.BatchCRF.OPT_EVENT_TIMING, 1)
     dt = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
     multi = None
+    words = lanes[0].bits_view.shape[1]
     if world > 1:
         # what every rank measured (the value uses the slowest), what the collective library itself spans, and the label
         # gather's own cost: the same steps once more with gather-then-launch instead of the overlapped form
@@ -1146,8 +1189,9 @@ def main():
         ones = torch.ones(1, dtype=torch.int32, device=dev)
         dist.all_reduce(ones)                           # a sum over the communicator of the timed region: N iff it spans N ranks
         dist.all_reduce(dt, op=dist.ReduceOp.MAX)
-        other = sh.OverlappedLabelGather(bits_view, world, serial=not args.serial_gather)
-        main_gather, gather = gather, other
+        main_gathers = [ln.gather for ln in lanes]
+        for ln in lanes:
+            ln.gather = sh.OverlappedLabelGather(ln.bits_view, world, serial=not args.serial_gather)
         for _ in range(2):
             step()
         barrier()
@@ -1157,24 +1201,28 @@ def main():
         barrier()
         dts = torch.tensor([time.perf_counter() - t0s], dtype=torch.float64, device=dev)
         dist.all_reduce(dts, op=dist.ReduceOp.MAX)
-        gather = main_gather
+        for ln, g in zip(lanes, main_gathers):
+            ln.gather = g
         ser, ovl = (float(dt.item()), float(dts.item())) if args.serial_gather else (float(dts.item()), float(dt.item()))
         multi = {"ms_per_step_by_rank": [float(x.item()) / args.steps * 1e3 for x in per_rank],
                  "ranks_in_collective": int(ones.item()), "backend": dist.get_backend(),
                  "label_gather": {"serial_ms_per_step": ser / args.steps * 1e3, "overlapped_ms_per_step": ovl / args.steps * 1e3,
                                   "exposed_ms_per_step": (ser - ovl) / args.steps * 1e3,
-                                  "bytes_per_rank": int(F * words * 8)}}
+                                  "bytes_per_rank": int(F * words * 8), "collectives_per_step": H}}
         if multi["ranks_in_collective"] != world:
             raise SystemExit("the collective spans %d ranks, not %d" % (multi["ranks_in_collective"], world))
     dt = float(dt.item())
 
     gather_ok = None
     if world > 1:                                   # every rank's slot of the gathered buffer holds that rank's labels
-        mine = sh.unpack_label_bits(gather.last()[rank], N)
-        map_ptr, _ = b.device_buffers()
-        gather_ok = bool(torch.equal(mine, torch.as_tensor(CudaView(map_ptr, (F, N), "<i2"), device=dev)))
+        gather_ok = True
+        for ln in lanes:
+            mine = sh.unpack_label_bits(ln.gather.last()[rank], N)
+            map_ptr, _ = ln.b.device_buffers()
+            gather_ok = gather_ok and bool(torch.equal(mine, torch.as_tensor(CudaView(map_ptr, (Fh, N), "<i2"), device=dev)))
 
-    # HIP-event duration of the inference launch(es), on the stream they are launched on
+    # HIP-event duration of ONE handle's inference launch, on the stream it is launched on, with nothing else on the GPU
+    stream = lanes[0].stream.cuda_stream
     kernel_ms = []
     for _ in range(1 if args.lite else 5):
         if not args.lite:
@@ -1185,21 +1233,27 @@ def main():
     inf_shape = b.fused_shape()            # (lanes per frame, frames per CU) of the inference kernel just timed
     # the fused engine's prepared launch records (include/lccrf.h: lccrf_batch_last_prepare): written once behind the build, by the
     # second inference on its lattices (inside the warm-up here) -- part of the lattice construction, reported beside build_ms
-    prepare_ms, prepare_runs = b.last_prepare()
+    prepare_ms = sum(ln.b.last_prepare()[0] for ln in lanes)
+    prepare_runs = sum(ln.b.last_prepare()[1] for ln in lanes)
 
     # end to end per frame = PottsPotential ctors + inference, as the reference pays per frame: ONE launch per frame
     run_ms = None
     if name != "c5":
         n_run = 1 if args.lite else max(args.steps // 2, 3)
+
+        def run_all():
+            for ln in lanes:
+                ln.b.run(n_iter, True, stream=ln.stream.cuda_stream)
         for _ in range(1 if args.lite else 2):
-            b.run(n_iter, True, stream=stream)
+            run_all()
         torch.cuda.synchronize()
         t0r = time.perf_counter()
         for _ in range(n_run):
-            b.run(n_iter, True, stream=stream)
-        b.synchronize()
+            run_all()
+        for ln in lanes:
+            ln.b.synchronize()
         run_ms = (time.perf_counter() - t0r) / n_run * 1e3
-        run_engine, run_fallback = b.engine(), b.fallback_frames()
+        run_engine, run_fallback = b.engine(), sum(ln.b.fallback_frames() for ln in lanes)
         run_shape = b.fused_shape()
 
     # parity gate on the timed configuration: labels vs the CPU reference path
@@ -1207,26 +1261,29 @@ def main():
     max_dq = None
     frames_checked = tiles_ok = None
     if rank == 0 and not args.no_check:
-        M, Q = b.map(), b.probability()
+        M = np.concatenate([ln.b.map() for ln in lanes])
+        Q = np.concatenate([ln.b.probability() for ln in lanes])
         frames_checked, label_match, max_dq = check_distinct_frames(pbs[:distinct], idx, M, Q, n_iter)   # EVERY distinct frame ...
-        tiles_ok = tiles_identical(torch, b, dev, F, N, idx)                                             # ... and every tile of each
+        tiles_ok = all(tiles_identical(torch, ln.b, dev, Fh, N, idx[ln.lo:ln.hi]) for ln in lanes)      # ... and every tile of each
+        if H > 1:                                        # (a lane's tiles are compared among themselves: one frame across the lanes too)
+            tiles_ok = tiles_ok and all(np.array_equal(Q[ln.lo + idx[ln.lo:ln.hi].index(idx[0])].view(np.int32), Q[0].view(np.int32)) for ln in lanes if idx[0] in idx[ln.lo:ln.hi])
 
     if rank == 0:
         total_iters = float(F) * n_iter * args.steps * world
         value = total_iters / dt
         bytes_iter = algorithmic_bytes_per_iter(N, L, dims, Vs)
-        alg_launch = bytes_iter * n_iter * F
+        alg_launch = bytes_iter * n_iter * Fh            # (per LAUNCH: one handle's frames)
         launch_s = inf_ms * 1e-3
         if engine == 2:
             # The one-workgroup-per-frame engine keeps the mean-field state in registers and LDS: HBM carries the
             # per-frame records once per launch.  Its roof is the CU's LDS pipe.
             chain0 = True                                           # SLAM frames: the appearance kernel takes the chain path
-            lanes, per_cu = inf_shape
+            wg_lanes, per_cu = inf_shape
             lean = per_cu == 2 and N > 1024                         # (frames of up to 1024 points share a CU on the 137 KB plan's small form)
             lds_bytes, lds_clocks, by = fused_lds_model(N, dims, Vs, chain0, lean)
             row = longest_rows(pkg, pbs)
-            lds_launch = lds_bytes * n_iter * F
-            t_floor = lds_clocks * n_iter * F / N_CU / CLK_HZ       # every CU streaming at the per-instruction peak
+            lds_launch = lds_bytes * n_iter * Fh
+            t_floor = lds_clocks * n_iter * Fh / N_CU / CLK_HZ      # every CU streaming at the per-instruction peak
             achieved = lds_launch / launch_s / 1e9
             peak = lds_launch / t_floor / 1e9
             ptag = latest_profile("fused_c2") if (name, F) == ("c2", DEFAULT_FRAMES) else None
@@ -1240,8 +1297,8 @@ def main():
                                             "x 4 clocks / (256 CUs x 4 SIMDs x 2.4 GHz) against the launch -- context beside the LDS roof, "
                                             "which stays the reported bound"} if valu else None),
                     "kernel": "inference launch (start + %d mean-field iterations + map), HIP events" % n_iter,
-                    "launch_ms": inf_ms, "lds_bytes_per_iteration_frame": lds_bytes, "lanes_per_frame": lanes, "frames_per_cu": per_cu,
-                    "lds_floor_ms": t_floor * 1e3, "longest_row": row, "chain_floor_ms": chain_floor(row, n_iter, F, N),
+                    "launch_ms": inf_ms, "frames_per_launch": Fh, "lds_bytes_per_iteration_frame": lds_bytes, "lanes_per_frame": wg_lanes, "frames_per_cu": per_cu,
+                    "lds_floor_ms": t_floor * 1e3, "longest_row": row, "chain_floor_ms": chain_floor(row, n_iter, Fh, N),
                     "chain_floor_note": "the appearance kernel's longest row is a strictly sequential fp32 sum (one lane per label): 5.1 cycles "
                                         "x longest row x n_iter per frame / 2.4 GHz x frames / 256 CUs -- the latency floor of ONE frame per CU next to the LDS "
                                         "floor (lds_floor_ms); with frames_per_cu = 2 one frame's chain runs under the other frame's point phases",
@@ -1273,11 +1330,11 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": desc, "frames_in_flight_per_gpu": F, "distinct_frames": distinct, "n_points": N,
+            "config": {"workload": desc, "frames_in_flight_per_gpu": F, "handles": H, "distinct_frames": distinct, "n_points": N,
                        "n_iters": n_iter, "n_labels": L, "kernel_dims": dims, "mean_lattice_vertices": Vs,
                        "engine": {1: "streaming", 2: "fused"}.get(engine, str(engine)),
                        "sharding": "frames over ranks, no data-path collective; one RCCL all_gather of the bit-packed "
-                                   "labels per step (%d bytes per rank), %s" % (F * words * 8, "serial" if args.serial_gather else "overlapped with the next step's launch (double-buffered)")},
+                                   "labels per handle and step (%d bytes per rank and step), %s" % (F * words * 8, "serial" if args.serial_gather else "overlapped with the next step's launch (double-buffered)")},
             "roofline": roof,
             "build_ms_per_batch": build_ms,
             "prepare_ms_per_batch": prepare_ms,      # once per build: the launch records every later inference on these lattices starts from
@@ -1307,7 +1364,8 @@ def main():
         if multi is not None:
             out["multi_gpu"] = multi
         if world == 1 and not args.no_extras:
-            b.close()
+            for ln in lanes:
+                ln.b.close()
             del d_feats, d_label
             torch.cuda.empty_cache()
             if name == "c2":                            # every other configuration of BASELINE.json (+ the live-SLAM size) in the same line
