@@ -495,7 +495,7 @@ def slam_subrecord(pkg, wl, torch, dev, name, steps=10, warmup=3, distinct=32, h
     torch.cuda.synchronize()
     H = handles                                          # (as the main record: handles of F / H frames, a stream each)
     Fh = F // H
-    bs, streams, build_ms = [], [], 0.0
+    bs, build_ms = [], 0.0
     for h in range(H):
         lo, hi = h * Fh, (h + 1) * Fh
         bh = pkg.BatchCRF(Fh, N, 2, dims, weights, device=dev.index)
@@ -504,14 +504,13 @@ def slam_subrecord(pkg, wl, torch, dev, name, steps=10, warmup=3, distinct=32, h
         build_ms += bh.last_timing()["build_ms"]
         bh.set_option(pkg.BatchCRF.OPT_EVENT_TIMING, 0)
         bs.append(bh)
-        streams.append(torch.cuda.Stream(dev))
     b = bs[0]
     engine = b.engine()
     Vs = [float(np.concatenate([bh.lattice_sizes(k) for bh in bs]).astype(np.float64).mean()) for k in range(len(dims))]
 
-    def all_of(what):
-        for bh, st in zip(bs, streams):
-            (bh.inference if what == "inference" else bh.run)(n_iter, True, stream=st.cuda_stream)
+    def all_of(what):                                    # (every handle on its own stream: include/lccrf.h, lccrf_batch_get_stream)
+        for bh in bs:
+            (bh.inference if what == "inference" else bh.run)(n_iter, True)
     for _ in range(warmup):
         all_of("inference")
     torch.cuda.synchronize()
@@ -1124,8 +1123,10 @@ def main():
         ln.b.build()                                 # steady state (what a replay loop pays per batch)
         ln.b.synchronize()
         ln.build_ms = ln.b.last_timing()["build_ms"]
-        # (one handle: torch's current stream, as before; several: a stream each)
-        ln.stream = torch.cuda.current_stream(dev) if H == 1 else torch.cuda.Stream(dev)
+        # The handle's OWN stream (wrapped for torch: the label gather's copy and the collective's wait are ordered on it).  Two torch-made
+        # streams may land on one of HIP's four hardware queues and then run their kernels one after the other (1.73 instead of 1.63 ms
+        # per step, depending on what else the process has created: scripts/two_handles_probe.py); the handles' streams do not.
+        ln.stream = torch.cuda.ExternalStream(ln.b.own_stream(), device=dev)
         bits_ptr, words = ln.b.device_label_bits()
         ln.bits_view = torch.as_tensor(CudaView(bits_ptr, (Fh, words), "<i8"), device=dev)
         # The label gather of step i overlaps the inference of step i+1 (lc-crf-slam_amd/sharding.py: OverlappedLabelGather):

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define LCCRF_ABI_VERSION 3   /* 3: lccrf_batch_last_prepare, LCCRF_OPT_EVENT_TIMING, lccrf_batch_synchronize scoped to the batch's streams; 2: lccrf_batch_get_fused_shape, the asynchronous host path of the batch API, lccrf_set_option's option 3 (LCCRF_OPT_COPY_THREADS) */
+#define LCCRF_ABI_VERSION 3   /* 3: lccrf_batch_last_prepare, lccrf_batch_get_stream, LCCRF_OPT_EVENT_TIMING, lccrf_batch_synchronize scoped to the batch's streams; 2: lccrf_batch_get_fused_shape, the asynchronous host path of the batch API, lccrf_set_option's option 3 (LCCRF_OPT_COPY_THREADS) */
 #define LCCRF_MAX_KERNELS 8      /* pairwise terms per CRF                        */
 #define LCCRF_MAX_DIMS    8      /* feature dimensions per kernel (reference uses <= 6) */
 #define LCCRF_MAX_LABELS  64
@@ -290,6 +290,12 @@ int  lccrf_batch_get_locality_mode(lccrf_batch_handle b, int *internal_point_ord
 /* Measurement support for bench.py: HIP-event time of the last lccrf_batch_inference()
  * on its stream, the number of launches of the dominant kernel and their summed
  * duration as seen by events around them (0 if not instrumented).                       */
+/* The batch's own stream (a hipStream_t; what `stream = NULL` means in the calls above), for a caller that orders its own work -- a
+ * collective on the label bits, a copy -- behind the batch's kernels.  Several batches kept in flight overlap best on their OWN
+ * streams: each was created with its handle, one after the other, and HIP spreads streams over its (four) hardware queues in that
+ * order, whereas two caller-made streams may share a queue and then run their kernels one after the other (measured: bench.py with two
+ * handles, 5.04e7 iterations/s on the handles' streams, 4.7-5.0e7 on two torch streams depending on what else the process created). */
+int  lccrf_batch_get_stream(lccrf_batch_handle b, void **stream);
 int  lccrf_batch_last_timing(lccrf_batch_handle b, float *inference_ms, float *build_ms);
 /* Batches of >= 256 two-kernel frames of 513 .. 2048 points run their inference two frames per CU from PREPARED launch records: what
  * the kernel's prologue would derive from the lattices in every launch (the ranking and placement of the appearance kernel's rows,

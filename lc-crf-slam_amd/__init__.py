@@ -130,6 +130,7 @@ def lib():
     L.lccrf_batch_pose_set_crf_counts.argtypes = [vp, vp]
     L.lccrf_batch_last_timing.argtypes = [vp, _f32p, _f32p]
     L.lccrf_batch_last_prepare.argtypes = [vp, _f32p, C.POINTER(C.c_int)]
+    L.lccrf_batch_get_stream.argtypes = [vp, C.POINTER(vp)]
     L.lccrf_batch_time_blur_pass.argtypes = [vp, C.c_int, C.c_int, _f32p, C.POINTER(C.c_int64)]
     L.lccrf_bf_match.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_double, _i32p, _i32p]
     L.lccrf_pose_optimization.argtypes = [C.c_int, C.c_int, _f32p, _f32p, _f32p, _f32p, C.c_void_p, _i16p, _f32p, C.c_float,
@@ -500,6 +501,12 @@ class BatchCRF:
         a, b = C.c_float(0), C.c_float(0)
         _check(lib().lccrf_batch_last_timing(self.h, C.byref(a), C.byref(b)))
         return dict(inference_ms=a.value, build_ms=b.value)
+
+    def own_stream(self):
+        """The batch's own hipStream_t as an integer (what stream=None means): wrap it with torch.cuda.ExternalStream to order torch work behind it."""
+        p = C.c_void_p()
+        _check(lib().lccrf_batch_get_stream(self.h, C.byref(p)))
+        return p.value
 
     def last_prepare(self):
         """(prepare_ms, runs) of the two-frames-per-CU kernel's prepared launch records (include/lccrf.h: lccrf_batch_last_prepare)."""

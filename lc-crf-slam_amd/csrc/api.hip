@@ -2468,6 +2468,14 @@ int lccrf_batch_last_timing(lccrf_batch_handle b, float *inference_ms, float *bu
     return LCCRF_OK;
 }
 
+int lccrf_batch_get_stream(lccrf_batch_handle b, void **stream)
+{
+    CHECK_H(b);
+    if (!stream) return fail(LCCRF_E_INVALID, "stream is NULL");
+    *stream = static_cast<void *>(b->eng.stream);
+    return LCCRF_OK;
+}
+
 int lccrf_batch_last_prepare(lccrf_batch_handle b, float *prepare_ms, int *runs)
 {
     CHECK_H(b);

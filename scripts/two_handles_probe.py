@@ -1,3 +1,5 @@
+"""Probe (GPU box): the C2 batch held by 1 / 2 / 4 handles on streams of their own -- does a launch's tail run under the next handle's
+head?  Variants: streams created after all handles / interleaved with them; launches inside `with torch.cuda.stream(...)` or not."""
 import importlib, sys, time, os
 sys.path.insert(0, os.getcwd())
 import numpy as np, torch
@@ -13,22 +15,61 @@ def make(F, rank=0):
     b.build(); b.synchronize()
     b.set_option(pkg.BatchCRF.OPT_EVENT_TIMING, 0)
     return b, (d_feats, d_label, d_np)
-def run(handles, streams, steps=20, warm=5):
+def run(handles, streams, ctx, steps=20, warm=5):
     def step():
         for h, s in zip(handles, streams):
-            h.inference(5, True, stream=s.cuda_stream)
+            if ctx:
+                with torch.cuda.stream(s):
+                    h.inference(5, True, stream=s.cuda_stream)
+            else:
+                h.inference(5, True, stream=s.cuda_stream)
     for _ in range(warm): step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps): step()
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / steps
-for nh in (1, 2, 4):
+for nh, interleave, ctx in ((1, False, False), (2, False, False), (2, True, False), (2, False, True), (2, True, True), (4, False, False)):
     F = 16384 // nh
-    hs = [make(F) for _ in range(nh)]
-    ss = [torch.cuda.Stream() for _ in range(nh)]
-    for rep in range(2):
-        dt = run([h[0] for h in hs], ss)
-        print("handles %d x %d frames: %.4f ms per step, %.4g iters/s" % (nh, F, dt * 1e3, 16384 * 5 / dt))
+    hs, ss = [], []
+    for _ in range(nh):
+        hs.append(make(F))
+        if interleave: ss.append(torch.cuda.Stream(dev))
+    if not interleave: ss = [torch.cuda.Stream(dev) for _ in range(nh)]
+    dts = [run([h[0] for h in hs], ss, ctx) for rep in range(3)]
+    print("handles %d x %5d frames, streams %s, %s: %s ms per step, best %.4g iters/s" % (nh, F, "interleaved" if interleave else "after", "ctx" if ctx else "plain", " ".join("%.4f" % (d * 1e3) for d in dts), 16384 * 5 / min(dts)), [s.cuda_stream for s in ss])
     for h in hs: h[0].close()
     del hs; torch.cuda.empty_cache()
+
+# ... and as bench.py sets its handles up: ONE set of input tensors, each handle bound to a slice of it
+def make_sliced(F, H, twice, getters):
+    pbs, idx, feats, label, dims, weights = bench.make_batch(wl, "c2", F, 0, 64)
+    d_feats = [torch.from_numpy(f).to(dev) for f in feats]; d_label = torch.from_numpy(label).to(dev)
+    d_np = torch.full((F,), 2000, dtype=torch.int32, device=dev)
+    Fh, out = F // H, []
+    for h in range(H):
+        lo, hi = h * Fh, (h + 1) * Fh
+        b = pkg.BatchCRF(Fh, 2000, 2, dims, weights, device=0)
+        b.set_engine(0)
+        b.bind_inputs_device(Fh, d_np[lo:hi].data_ptr(), [t[lo:hi].data_ptr() for t in d_feats], d_label=d_label[lo:hi].data_ptr(), conf=pbs[0]["conf"])
+        b.build(); b.synchronize()
+        if twice:
+            b.build(); b.synchronize()
+        if getters:
+            b.engine(); b.lattice_sizes(0); b.device_label_bits()
+        b.set_option(pkg.BatchCRF.OPT_EVENT_TIMING, 0)
+        out.append(b)
+    return out, (d_feats, d_label, d_np)
+class Own:                                               # "the handle's own stream"
+    cuda_stream = None
+for twice, getters in ((False, False), (True, False), (True, True)):
+    hs, keep = make_sliced(16384, 2, twice, getters)
+    ss = [torch.cuda.Stream(dev) for _ in range(2)]
+    dts = [run(hs, ss, True) for rep in range(3)]
+    print("sliced inputs, build twice %s, getters %s: %s ms per step" % (twice, getters, " ".join("%.4f" % (d * 1e3) for d in dts)))
+    dts = [run(hs, [Own, Own], False) for rep in range(3)]
+    print("   ... on the handles' own streams: %s ms per step" % " ".join("%.4f" % (d * 1e3) for d in dts))
+    dts = [run(hs, ss, True) for rep in range(2)]
+    print("   ... torch streams again: %s ms per step" % " ".join("%.4f" % (d * 1e3) for d in dts))
+    for h in hs: h.close()
+    del hs, keep; torch.cuda.empty_cache()
