@@ -286,7 +286,7 @@ __device__ __forceinline__ void exp_and_normalize_reg(const float (&in)[L], floa
 // omr = 1 - relax, formed once by the caller (the same fp32 subtraction as densecrf3d.h:94, (1 - relax): a uniform value the
 // kernels would otherwise keep in a vector register for the whole launch)
 #ifndef LCCRF_QUOT_STEPS
-#define LCCRF_QUOT_STEPS 1                // A/B (scripts/gpu_ab_build.sh "-DLCCRF_QUOT_STEPS=2" ""): residual corrections per quotient
+#define LCCRF_QUOT_STEPS 2                // A/B (scripts/gpu_ab_build.sh "" "-DLCCRF_QUOT_STEPS=1"): residual corrections per quotient
 #endif
 __device__ __forceinline__ float2 softmax2_fresh(float a, float b)
 {
@@ -296,10 +296,11 @@ __device__ __forceinline__ float2 softmax2_fresh(float a, float b)
     // The two IEEE divisions 1/tt and e/tt, written out: tt is in [1, 2] and e in {0} U [2^-29, 1], a range in which
     // hipcc's own expansion of x/y (v_div_scale, v_rcp, Newton step, quotient + two residual corrections, v_div_fmas,
     // v_div_fixup) scales nothing and fixes nothing up -- what is left is this sequence, with the refined reciprocal
-    // shared by both quotients.  Round 6: ONE residual correction per quotient instead of the expansion's two -- both
-    // quotients are functions of e alone (tt = fl(1 + e)), and scripts/ubench/quotcheck.hip compares them with IEEE division
-    // for EVERY float e in {0} U [2^-60, 1] (4.9e8 values, v_rcp_f32 of this very GPU): 0 differences.  9 instructions
-    // instead of 22 (13 with two corrections); tests compare Q bit for bit.
+    // shared by both quotients (13 instructions instead of 22; same bits, tests compare Q bit for bit).
+    // (Round 6: ONE residual correction per quotient would do -- both quotients are functions of e alone, and
+    // scripts/ubench/quotcheck.hip finds 0 differences from IEEE division over EVERY float e in {0} U [2^-60, 1] -- but the
+    // four instructions it saves per point bought nothing measurable (C2 +-0, C4 / N500 +0.4 %) and cost two frame-kernel
+    // variants 8-12 bytes of scratch: LCCRF_QUOT_STEPS stays 2.)
     const float r0 = __builtin_amdgcn_rcpf(tt);
     const float r = __builtin_fmaf(__builtin_fmaf(-tt, r0, 1.0f), r0, r0);
     auto quot = [&](float n) {

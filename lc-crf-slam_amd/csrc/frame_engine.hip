@@ -29,9 +29,6 @@
 // What must match the reference exactly does: the point records (point_record<2>, quirks Q1-Q4, phantom
 // points of the last block of four included), the set of vertices (V is reported and tested against the
 // reference's M_), the order of every sum.  ref: permutohedral_cpu.h:241-424,634-699; densecrf_base.h:65-91.
-// (the two-label softmax's quotients keep both residual corrections in this translation unit: with one, device_math.h's default
-//  since round 6, the register allocator spills 8-12 bytes per lane in two of the variants below -- tests/test_kernel_resources.py)
-#define LCCRF_QUOT_STEPS 2
 #include "engine.h"
 #include "device_math.h"
 #include "fused_loop.h"

@@ -20,9 +20,6 @@
 // fit -- key range too wide for the id map, an appearance lattice too large for the chain lanes, coordinates near the int16 wrap --
 // flags itself and runs on the other paths with identical results.  The vertex numbering is this kernel's own (cell order): the
 // mean-field result does not depend on it (frame_engine.hip), V is reported and tested against the reference's M_.
-// (the two-label softmax's quotients keep both residual corrections in this translation unit: with one, device_math.h's default
-//  since round 6, the register allocator spills 12 bytes per lane in the 2-points-per-lane variant -- tests/test_kernel_resources.py)
-#define LCCRF_QUOT_STEPS 2
 #include "frame_build.h"
 #include "fused_lean.h"
 
