@@ -813,6 +813,43 @@ def test_event_timing_option_only_switches_the_events_off(po, wl):
     b.close()
 
 
+def test_two_handles_on_their_own_streams_give_each_its_results(po, wl):
+    """Round 6: the frames in flight held by two handles whose launches alternate on the handles' OWN streams (`lccrf_batch_get_stream`;
+    what `bench.py`'s `two_handles` record and a replay loop do): nothing is ordered between the handles, every handle must still hold
+    its own frames' results -- against the oracle, after many interleaved launches, through inference and through the one-launch path."""
+    F, maxN = 264, 2048
+    sets = [[wl.slam_problem(n, seed=9960 + 10 * h + i) for i, n in enumerate([2000, 1300, 1999, 1100, 2048, 1537, 3, 0])] for h in range(2)]
+    bs = [_batch_of([sets[h][f % 8] for f in range(F)], maxN=maxN) for h in range(2)]
+    streams = [b.own_stream() for b in bs]
+    assert all(streams) and streams[0] != streams[1]
+    for b in bs:
+        b.set_option(pkg.BatchCRF.OPT_EVENT_TIMING, 0)
+        b.build()
+    for rep in range(6):
+        for b in bs:
+            b.inference(5, True)
+    for h, b in enumerate(bs):
+        b.synchronize()
+        assert b.engine() == 2 and b.fused_shape() == (512, 2) and b.last_prepare()[1] == 1
+        Q, M = b.probability(), b.map()
+        for i, pb in enumerate(sets[h]):
+            o = cc.setup(po.OracleCRF, pb)
+            o.inference_native(5, True)
+            for f in (i, F - 8 + i):
+                assert cc.same_bits(Q[f, :pb["N"]], o.probability()) and np.array_equal(M[f, :pb["N"]], o.map()), (h, f)
+            o.close()
+    for rep in range(3):
+        for b in bs:
+            b.run(5, True)
+    for h, b in enumerate(bs):
+        Q = b.probability()
+        o = cc.setup(po.OracleCRF, sets[h][0])
+        o.inference_native(5, True)
+        assert b.engine() == 3 and cc.same_bits(Q[0, :2000], o.probability()) and cc.same_bits(Q[F - 8, :2000], o.probability()), h
+        o.close()
+        b.close()
+
+
 def test_full_size_frames_share_a_cu_in_the_one_launch_kernel(po, wl):
     """Round 5: lccrf_batch_run on batches of >= 256 full-size two-kernel frames (1025 .. 2048 points) runs the WHOLE frame -- both
     lattice builds, normalisation, inference -- in 512-lane workgroups on half a CU (csrc/frame_lean.hip: LDS scratch laid out by
