@@ -681,7 +681,6 @@ struct Engine {
         sizes_known = true;
         lean_prep.valid = false;                           // (every path that changes a lattice clears sizes_known and so comes through here)
         lean_prep.seen_key = 0;
-        lean_prep.split_valid = lean_prep.no_split = false;
         sized_engine = 1;
         if (engine_pref != 1 && !perm_on && fused_supported(crf, kdevs.data(), maxV.data(), maxRow.data(), &fused_lds)) sized_engine = 2;
         if (engine_pref == 2 && sized_engine != 2)
@@ -873,12 +872,10 @@ struct Engine {
                 lean_prep.valid = false;
                 lean_prep.buf = nullptr;                       // (an outgrown block stays with the arena until the handle goes)
                 lean_prep.bytes = 0;
-                lean_prep.unfit = nullptr;
                 unsigned char *p = nullptr;
-                if (mem.alloc(&p, prep_need + 256, false) == LCCRF_OK) {
+                if (mem.alloc(&p, prep_need, false) == LCCRF_OK) {
                     lean_prep.buf = p;
                     lean_prep.bytes = prep_need;
-                    lean_prep.unfit = reinterpret_cast<int *>(p + prep_need);      // (the split plan's "does not fit" word)
                 } else {
                     (void)hipGetLastError();                   // no room: the self-contained kernel runs instead, same results
                 }

@@ -213,8 +213,6 @@ struct LeanPrep {
     bool valid = false, timed = false;
     unsigned long long key = 0, seen_key = 0;   // the plan / shape the blocks were written for; ... the last inference ran with (blocks are written by the second)
     unsigned runs = 0;                    // how many times the blocks were (re)written: tests
-    int *unfit = nullptr;                 // device word behind the blocks: the split plan's prepare launch (fused_split.h) raises it
-    bool split_valid = false, no_split = false;   // the blocks hold the split plan's records / some frame did not fit it (until the next build)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
 size_t lean_prep_bytes(const CrfDev &c, const KernelDev *kds, const int *maxV, const int *maxRow);

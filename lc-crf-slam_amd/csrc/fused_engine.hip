@@ -22,7 +22,6 @@
 #include "device_math.h"
 #include "fused_loop.h"
 #include "fused_lean.h"
-#include "fused_split.h"
 
 #include <algorithm>
 #include <cstdio>
@@ -47,7 +46,6 @@ struct FusedArgs {
     unsigned char *prep;                  // lean plan: the frames' prepared launch records (fused_lean.h: LeanPrepPlan), prep_stride bytes each
     int prep_stride;
     int Vcap[kMaxFusedK];                 // the vertex counts the LDS plan was sized for (maxima over the batch)
-    int *prep_unfit;                      // split plan (fused_split.h), prepare launch: set to 1 by a frame whose row regions do not fit the plane
 };
 
 // One workgroup per frame.  Lane t owns points t, t+NT, ... (PPT of them); the per-frame records a build
@@ -59,12 +57,9 @@ struct FusedArgs {
 //   MODE  0 / 1 / 2: the self-contained kernel / its prologue only, into the frame's prepared block / the run from that block
 //         (fused_lean.h: LeanPrepPlan -- the same blocks as k_fused_lean's: what chain_setup and place_products derive from the
 //         lattices is written once behind a build)
-//   SPLIT (1024 lanes, K = 2, chain kernel, MODE 1 / 2 only): the plan of fused_split.h -- kernel 1's products in a buffer of their own, the
-//         chain kernel's plane holding half the points' products at a time -- for frames whose two buffers do not fit side by side
-template <int NT, int PPT, int K, int CH, int MODE, bool SPLIT = false>
+template <int NT, int PPT, int K, int CH, int MODE>
 __global__ void __launch_bounds__(NT, 4) k_fused(CrfDev c, FusedArgs a)
 {
-    static_assert(!SPLIT || (NT == kNT && K == 2 && CH == 1 && MODE != 0), "the split plan: 1024 lanes, two kernels, kernel 0 a chain kernel, from prepared launch records");
     constexpr int D1 = kD1;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int f = blockIdx.x;
@@ -131,7 +126,7 @@ __global__ void __launch_bounds__(NT, 4) k_fused(CrfDev c, FusedArgs a)
                 if (b < pp.row_bytes[k]) *reinterpret_cast<pf_u4 *>(smem + lay.row[k] + b) = trow[k][r];
                 if (b < pp.nbr_bytes[k]) *reinterpret_cast<pf_u4 *>(smem + lay.nbr[k] + b) = tnbr[k][r];
             }
-        if (tid < (SPLIT ? 32 : 16)) reinterpret_cast<float *>(smem + lay.zero)[tid] = 0.0f;   // (the split plan's ring reads 128 bytes of zeros)
+        if (tid < 16) reinterpret_cast<float *>(smem + lay.zero)[tid] = 0.0f;
         if (tid == 0) {
 #pragma unroll
             for (int k = 0; k < K; ++k) {
@@ -145,14 +140,13 @@ __global__ void __launch_bounds__(NT, 4) k_fused(CrfDev c, FusedArgs a)
             for (int k = 0; k < K; ++k) pr.wn[s][k] = a.kd[k].w * pr.wn[s][k];   // pairwise3d.h:77 (w_*norm_[i])
         __syncthreads();
         FL_PSTAMP();
-        ChainLane cl{clw.x, clw.y};
+        const ChainLane cl{clw.x, clw.y};
         start_inference<PPT, K, NT>(pr, N, tid);
         FL_STAMP();
         float alpha[K];
 #pragma unroll
         for (int k = 0; k < K; ++k) alpha[k] = a.kd[k].alpha;
-        if constexpr (SPLIT) mean_field_split<PPT, NT>(smem, lay, V, N, tid, pr, cl, alpha, a.n_iter, a.relax, ins);
-        else mean_field<PPT, K, CH, NT, true>(smem, lay, V, N, tid, pr, cl, alpha, a.n_iter, a.relax, ins);
+        mean_field<PPT, K, CH, NT, true>(smem, lay, V, N, tid, pr, cl, alpha, a.n_iter, a.relax, ins);
         store_results<PPT, K, NT>(c, f, N, tid, pr, a.with_map);
         FL_STAMP();
         if (kInstr && a.timing && (int)blockIdx.x == a.timing_block && tid == a.timing_lane) a.timing[63] = ins.n;
@@ -249,14 +243,10 @@ __global__ void __launch_bounds__(NT, 4) k_fused(CrfDev c, FusedArgs a)
     // on their way.  Rank the chain rows (four barriers, LDS atomics -- needs the row table only) before anything touches
     // a point record, so that this work runs under the tail of the loads instead of behind it.
     ChainLane cl{0u, 0u};
-    if constexpr (SPLIT) {
-        if (!split_prepare<PPT, NT>(smem, lay, V, N, tid, pk, pr, cl) && tid == 0) *a.prep_unfit = 1;     // (the host then keeps the shared-buffer plan)
-    } else {
-        if (CH != 0 && chain_k<CH>(lay, 0)) cl = chain_setup(smem, lay, V[0], tid);
-        FL_PSTAMP();
-        if (MODE != 1) start_inference<PPT, K, NT>(pr, N, tid);
-        place_products<PPT, K, CH, NT>(smem, lay, N, tid, pk, pr);
-    }
+    if (CH != 0 && chain_k<CH>(lay, 0)) cl = chain_setup(smem, lay, V[0], tid);
+    FL_PSTAMP();
+    if (MODE != 1) start_inference<PPT, K, NT>(pr, N, tid);
+    place_products<PPT, K, CH, NT>(smem, lay, N, tid, pk, pr);
     FL_STAMP();
     if constexpr (MODE == 1) {
         // ---- the prepared block of this frame: ix words, chain lanes, LDS tables (LeanPrepPlan) ---------------------------------------
@@ -662,23 +652,6 @@ void launch_fused_ppt(const CrfDev &c, const FusedArgs &a, hipStream_t s, int mo
     }
 }
 
-// the split plan (fused_split.h): 1024 lanes, two kernels, kernel 0 a chain kernel, 3 or 4 points per lane; mode 1 (prepare) or 2
-template <int PPT>
-void launch_split_ppt(const CrfDev &c, const FusedArgs &a, hipStream_t s, int mode)
-{
-    auto launch = [&](auto fn) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit);
-        fn<<<dim3(c.F), dim3(kNT), a.lay.total, s>>>(c, a);
-    };
-    if (mode == 1) launch(k_fused<kNT, PPT, 2, 1, 1, true>);
-    else launch(k_fused<kNT, PPT, 2, 1, 2, true>);
-}
-void launch_split(const CrfDev &c, const FusedArgs &a, hipStream_t s, int mode, int NAp)
-{
-    if (NAp <= 3 * kNT) launch_split_ppt<3>(c, a, s, mode);
-    else launch_split_ppt<4>(c, a, s, mode);
-}
-
 // the shape launch_inference_fused has chosen, in one of the three modes
 void launch_shape(const CrfDev &c, const FusedArgs &a, hipStream_t s, int mode, int NAp, bool small, bool lean)
 {
@@ -734,11 +707,7 @@ size_t lean_prep_bytes(const CrfDev &c, const KernelDev *kds, const int *maxV, c
     const FusedShape sh = choose_shape(c, kds, maxV, maxRow, &lay);
     if (!sh.ok || c.F < kPrepMinFrames) return 0;
     const LeanPrepPlan pp = lean_prep_plan(lay, c.K, maxV, sh.nt, sh.ppt);
-    size_t per_frame = (size_t)pp.total;
-    FusedLayout lb;                                       // (the split plan's blocks take the same area: fused_split.h)
-    if (!sh.small && !sh.lean && c.K == 2 && lay.chain0 && !lay.prod_all && layout_split(c.activeN > 0 ? c.activeN : c.maxN, maxV, maxRow ? maxRow[0] : 0, &lb))
-        per_frame = std::max(per_frame, (size_t)lean_prep_plan(lb, c.K, maxV, kNT, sh.ppt).total);
-    return per_frame * (size_t)c.F;
+    return (size_t)pp.total * (size_t)c.F;
 }
 
 int launch_inference_fused(const CrfDev &c, const KernelDev *kds, const int *maxV, const int *maxRow, int n_iter,
@@ -800,47 +769,7 @@ int launch_inference_fused(const CrfDev &c, const KernelDev *kds, const int *max
             prep->seen_key = key;                            // the first one
         }
     }
-    // Frames whose two product buffers do not fit side by side (the 1024-lane shape with ONE shared buffer: 3000 keypoints) run from the
-    // second inference on with the chain kernel's plane split in two (fused_split.h): kernel 1's row sums beside the first half of the chain.
-    static const bool no_split = ab_env("LCCRF_NO_SPLIT") != nullptr;       // A/B switch (instrumented library): same results either way
-    bool split_run = false;
-    if (mode != 0 && !small && !lean && c.K == 2 && a.lay.chain0 && !a.lay.prod_all && NAp > 2 * kNT && prep->unfit && !prep->no_split && !no_split) {
-        FusedArgs b = a;
-        if (layout_split(NAp, a.Vcap, maxRow ? maxRow[0] : 0, &b.lay)) {
-            const LeanPrepPlan pb = lean_prep_plan(b.lay, c.K, b.Vcap, kNT, sh.ppt);
-            bool ok = (size_t)pb.total * (size_t)c.F <= prep->bytes;
-            for (int k = 0; k < c.K; ++k) ok = ok && pb.row_bytes[k] <= 2 * kNT * 16 && pb.nbr_bytes[k] <= 2 * kNT * 16;
-            if (ok) {
-                b.prep_stride = pb.total;
-                b.prep_unfit = prep->unfit;
-                if (!prep->split_valid) {                       // (the blocks were just written for the shared-buffer plan, or are: write them for this one)
-                    (void)hipMemsetAsync(prep->unfit, 0, sizeof(int), s);
-                    if (prep->ev0) (void)hipEventRecord(prep->ev0, s);
-                    launch_split(c, b, s, 1, NAp);
-                    if (prep->ev1) (void)hipEventRecord(prep->ev1, s);
-                    int unfit = 1;
-                    if (hipStreamSynchronize(s) == hipSuccess) (void)hipMemcpy(&unfit, prep->unfit, sizeof(int), hipMemcpyDeviceToHost);
-                    if (unfit) {
-                        prep->no_split = true;                  // some frame's rows are too lopsided for the half plane: the shared-buffer plan stays
-                        prep->valid = false;                    // (its blocks were overwritten: the next lines write them again)
-                    } else {
-                        prep->split_valid = true;
-                    }
-                }
-                if (prep->split_valid) {
-                    launch_split(c, b, s, 2, NAp);
-                    split_run = true;
-                }
-            }
-        }
-    }
-    if (!split_run) {
-        if (mode == 2 && !prep->valid) {                        // (a failed split prepare overwrote the blocks)
-            launch_shape(c, a, s, 1, NAp, small, lean);
-            prep->valid = true;
-        }
-        launch_shape(c, a, s, mode, NAp, small, lean);
-    }
+    launch_shape(c, a, s, mode, NAp, small, lean);
     if (a.timing) {                       // debug only: synchronous read-back of workgroup 0's phase stamps
         long long h[64];
         (void)hipStreamSynchronize(s);

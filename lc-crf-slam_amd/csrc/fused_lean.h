@@ -127,10 +127,9 @@ __host__ __device__ inline bool layout_lean(int NA, int K, const int *V, int row
 // keep0 / keep1: two values of the caller that must survive the ring (the chain lane's two words).  They pass through the asm statement as operands, which pins
 // them to registers the ring does not clobber; left to itself the register allocator parks loop-long values (the chain lane's two
 // words) in v96..v127 and spills them to scratch around the ring.
-// acc0: the value the sum starts from (+0; the split plan of fused_split.h continues a row across two halves of its products)
-__device__ __forceinline__ float chain_rows_sel(unsigned addr, int bytes, unsigned trips, unsigned &keep0, unsigned &keep1, float acc0 = 0.0f)
+__device__ __forceinline__ float chain_rows_sel(unsigned addr, int bytes, unsigned trips, unsigned &keep0, unsigned &keep1)
 {
-    float acc = acc0;
+    float acc = 0.0f;
     if (trips == 0) return acc;
     unsigned sa, sb;
     asm volatile(
@@ -163,9 +162,9 @@ __device__ __forceinline__ float chain_rows_sel(unsigned addr, int bytes, unsign
 }
 
 // chain_rows (fused_loop.h) with the same two pass-through operands
-__device__ __forceinline__ float chain_rows_keep(unsigned addr, unsigned end, unsigned trips, unsigned &keep0, unsigned &keep1, float acc0 = 0.0f)
+__device__ __forceinline__ float chain_rows_keep(unsigned addr, unsigned end, unsigned trips, unsigned &keep0, unsigned &keep1)
 {
-    float acc = acc0;
+    float acc = 0.0f;
     if (trips == 0) return acc;
     const unsigned e1 = end - 32u, e2 = end - 64u, e3 = end - 96u;
     unsigned sel;

@@ -60,7 +60,6 @@ struct FusedLayout {                      // byte offsets into dynamic LDS
     int chain0;                           // 1: kernel 0 has long splat rows, S runs chain_rows on them
     int pstart;                           // lean plan only (fused_lean.h): u16 [V_0+2] first product slot of every chain row
     int total;
-    int split0, half;                     // split plan only (fused_split.h): the chain kernel's plane holds the products of the points below / from `half` in turn
 };
 
 // Instrumented builds only: shader-clock stamps of one workgroup and the timing experiments of LCCRF_FUSED_DBG
