@@ -154,6 +154,7 @@ def compact_line(full):
             line["host_to_host_frac_of_link"] = _r(h2h.get("best_frac_of_link"))
     if "two_handles" in full:
         line["two_handles"] = {"value": g("two_handles", "value"), "ms_per_step": g("two_handles", "ms_per_step"),
+                               "frames_per_s_end_to_end": g("two_handles", "frames_per_s_end_to_end"),
                                "label_match": g("two_handles", "label_match_vs_cpu_reference")}
     for sub in ("c1", "c3", "c4", "n500"):                       # the other SLAM configurations: value, LDS fraction, end to end
         if sub in full:
@@ -613,12 +614,27 @@ def two_handles_record(pkg, wl, torch, dev, name, F, steps=20, warmup=5, distinc
     M = np.concatenate([bh.map() for bh in bs])
     Q = np.concatenate([bh.probability() for bh in bs])
     fc, lm, dq = check_distinct_frames(pbs[:distinct], idx, M, Q, n_iter)
+    # ... and end to end (one launch per frame: both lattice builds + inference) on the same two handles
+    n_run = max(steps // 2, 3)
+    for _ in range(2):
+        for bh in bs:
+            bh.run(n_iter, True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n_run):
+        for bh in bs:
+            bh.run(n_iter, True)
+    torch.cuda.synchronize()
+    run_dt = (time.perf_counter() - t0) / n_run
+    _, rlm, rdq = check_distinct_frames(pbs[:distinct], idx, np.concatenate([bh.map() for bh in bs]), np.concatenate([bh.probability() for bh in bs]), n_iter)
     for bh in bs:
         bh.close()
     del d_feats, d_label, d_np
     torch.cuda.empty_cache()
     return {"handles": 2, "frames_per_handle": Fh, "value": F * n_iter / dt, "unit": "iters/s", "ms_per_step": dt * 1e3,
-            "ms_per_step_both_runs": [d * 1e3 for d in dts], "label_match_vs_cpu_reference": lm, "max_abs_dQ_vs_cpu_reference": dq}
+            "ms_per_step_both_runs": [d * 1e3 for d in dts], "label_match_vs_cpu_reference": lm, "max_abs_dQ_vs_cpu_reference": dq,
+            "frames_per_s_end_to_end": F / run_dt, "one_launch_ms_per_step": run_dt * 1e3,
+            "end_to_end_label_match_vs_cpu_reference": rlm, "end_to_end_max_abs_dQ_vs_cpu_reference": rdq}
 
 
 def image_demo_record(pkg, wl, reps=5):
