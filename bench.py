@@ -160,10 +160,13 @@ def compact_line(full):
         if sub in full:
             ms = _pick(full, sub, "end_to_end", "one_launch_ms_per_batch")
             fr = _pick(full, sub, "frames_in_flight")
-            line[sub] = {"value": g(sub, "value"), "frac": g(sub, "roofline", "frac"),
+            line[sub] = {"value": g(sub, "value"), "frac": g(sub, "roofline", "frac"), "cpu_value": g(sub, "cpu_baseline", "value"),
                          "frames_per_cu": g(sub, "roofline", "frames_per_cu"),
                          "frames_per_s_end_to_end": _r(fr / (ms * 1e-3)) if (ms and fr) else None,
                          "label_match": g(sub, "label_match_vs_cpu_reference"), "max_abs_dQ": g(sub, "max_abs_dQ_vs_cpu_reference")}
+    if _pick(full, "c4", "eight_frames_in_flight"):
+        line["c4"]["eight_frames_us"] = g("c4", "eight_frames_in_flight", "us_per_batch_host_to_host")
+        line["c4"]["eight_frames_value"] = g("c4", "eight_frames_in_flight", "value")
     if "c5" in full:
         c5 = full["c5"]
         line["c5"] = {"frames_in_flight": g("c5", "frames_in_flight"), "value": g("c5", "value"),
@@ -567,6 +570,35 @@ def slam_subrecord(pkg, wl, torch, dev, name, steps=10, warmup=3, distinct=32, h
                           "frames_per_s": F / (run_ms * 1e-3), "two_kernel_ms_per_batch": build_ms + prepare_ms + inf_ms},
            "label_match_vs_cpu_reference": label_match, "max_abs_dQ_vs_cpu_reference": max_dq,
            "frames_checked": frames_checked, "tiles_identical": tiles_ok}
+    # the reference's CPU path on this configuration (one pinned core, a short sample: the headline's cpu_baseline is the long one)
+    try:
+        cores = sorted(os.sched_getaffinity(0))
+        saved = os.sched_getaffinity(0)
+        slim = [dict(N=pb["N"], L=pb["L"], label=pb["label"], conf=pb["conf"], kernels=pb["kernels"]) for pb in pbs[:4]]
+        frames, t_inf, t_all, kind = _cpu_frames(slim, n_iter, 2.0, cores[-1])
+        os.sched_setaffinity(0, saved)
+        rec["cpu_baseline"] = {"value": frames * n_iter / t_inf, "unit": "iters/s", "cores": 1, "kind": kind,
+                               "frames_per_s_end_to_end": frames / t_all, "sample": "%d frames, one pinned core, %.1f s" % (frames, t_all)}
+    except Exception as e:                              # (the headline's baseline stands on its own)
+        rec["cpu_baseline"] = {"error": repr(e)}
+    if name == "c4":
+        # BASELINE config 4 as written: EIGHT 3000-keypoint frames in flight (one per GPU of an 8-GPU node; here all eight on this GPU):
+        # one lccrf_batch_run (both lattice builds + inference; two workgroups per frame) + the labels, host to host
+        small = pkg.BatchCRF(8, N, 2, dims, weights, device=dev.index)
+        sf = [np.ascontiguousarray(f[:8]) for f in feats]
+        small.set_inputs_host([N] * 8, sf, label=np.ascontiguousarray(label[:8]), conf=pbs[0]["conf"])
+        for _ in range(5):
+            small.run(n_iter, True); small.map()
+        ts = []
+        for _ in range(40):
+            t0 = time.perf_counter(); small.run(n_iter, True); m8 = small.map(); ts.append(time.perf_counter() - t0)
+        q8 = small.probability()
+        small.close()
+        _, lm8, dq8 = check_distinct_frames(pbs[:8], idx[:8], m8, q8, n_iter)
+        med = float(np.median(ts))
+        rec["eight_frames_in_flight"] = {"frames": 8, "us_per_batch_host_to_host": med * 1e6, "value": 8 * n_iter / med, "unit": "iters/s",
+                                         "frames_per_s_end_to_end": 8 / med, "label_match_vs_cpu_reference": lm8, "max_abs_dQ_vs_cpu_reference": dq8,
+                                         "what": "lccrf_batch_run (lattice builds + inference, one launch, two workgroups per frame) + lccrf_batch_get_map_host, median of 40"}
     ptag = latest_profile({"c1": "small_c1", "c4": "fused_c4"}.get(name, "none"))      # committed rocprofv3 summary of `bench.py --workload <name>`
     if ptag:
         tr = pmc_traffic(ptag, "k_fused")
