@@ -307,7 +307,7 @@ __device__ __forceinline__ ChainLane chain_setup_lean(unsigned char *smem, const
     __syncthreads();
     // wavefront pair p = (2p, 2p+1) owns labels 0 and 1 of a rank range (chain_setup): pair 0 the kChainTop longest rows
     const int l = (tid >> 6) & 1, pr = tid >> 7, ln = tid & 63;
-    const int r = pr == 0 ? (((ln & 0x18) == 0) ? ((ln & 7) | ((ln >> 5) << 3)) : V0) : kChainTop + ((pr - 1) << 6) + ln;
+    const int r = pr == 0 ? (chain_top_rank(ln) >= 0 ? chain_top_rank(ln) : V0) : kChainTop + ((pr - 1) << 6) + ln;
     unsigned quads = 0, addr = 0;
     if (r < V0) {
         const int v = srt[r];

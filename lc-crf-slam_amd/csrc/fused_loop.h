@@ -26,7 +26,19 @@ constexpr int kNT = 1024;                 // lanes per workgroup (16 wavefronts)
 constexpr int kMaxFusedK = 2;
 constexpr int kD1 = 3;                    // 2-D kernels: three simplex corners per point
 constexpr int kChainGap = 14;             // product slots reserved per chain row beyond its products (see pst)
-constexpr int kChainTop = 16;             // rows of the first chain wavefront pair (see chain_setup)
+#ifndef LCCRF_CHAIN_TOP
+#define LCCRF_CHAIN_TOP 16                // A/B (scripts/gpu_ab_build.sh "" "-DLCCRF_CHAIN_TOP=32"): 8, 16 or 32
+#endif
+constexpr int kChainTop = LCCRF_CHAIN_TOP; // rows of the first chain wavefront pair (see chain_setup)
+// which of the first pair's kChainTop rows lane `ln` of its wavefront sums (-1: none): the same number of lanes in each of the four
+// 16-lane groups a ds_read_b128 is served in
+__host__ __device__ constexpr int chain_top_rank(int ln)
+{
+    return kChainTop == 32 ? (((ln & 8) == 0) ? ((ln & 7) | ((ln >> 4) << 3)) : -1)
+         : kChainTop == 8  ? (((ln & 0x1c) == 0) ? ((ln & 3) | ((ln >> 5) << 2)) : -1)
+                           : (((ln & 0x18) == 0) ? ((ln & 7) | ((ln >> 5) << 3)) : -1);
+}
+static_assert(kChainTop == 8 || kChainTop == 16 || kChainTop == 32, "chain_top_rank");
 constexpr size_t kLdsLimit = 160 * 1024;  // MI355X: 160 KiB LDS per CU, one workgroup may own it all
 constexpr int kChainMinRow = 64;          // kernel 0 runs chain_rows when its longest splat row has at least this many products ...
 // ... and it has at most this many vertices (one lane per (vertex,label) row: wavefront pair 0 takes the kChainTop longest
@@ -306,7 +318,7 @@ __device__ __forceinline__ ChainLane chain_setup(unsigned char *smem, const Fuse
     // bank conflicts among the ACTIVE lanes (~75 cycles with 16 rows, ~110 with 64), and it is
     // the longest rows' wavefront that everybody waits for.  Pair p >= 1: 64 rows each.
     const int l = (tid >> 6) & 1, pr = tid >> 7, ln = tid & 63;
-    const int r = pr == 0 ? (((ln & 0x18) == 0) ? ((ln & 7) | ((ln >> 5) << 3)) : V0) : kChainTop + ((pr - 1) << 6) + ln;
+    const int r = pr == 0 ? (chain_top_rank(ln) >= 0 ? chain_top_rank(ln) : V0) : kChainTop + ((pr - 1) << 6) + ln;
     unsigned nblk = 0, addr = 0;
     if (r < V0) {
         const int v = srt[r];
