@@ -348,9 +348,13 @@ __device__ void block_sum28(double (&v)[28], double *red /* [kRedDoubles] */)
     for (int k = 0; k < 28; ++k) v[k] = red[kWaves * 28 + k];
 }
 
+// (The branch must be UNIFORM: a lane-divergent `threadIdx.x == 0` next to the reductions' lane exchanges -- v_permlane*_swap, DPP -- let the
+//  compiler run part of the butterfly under a partial EXEC mask in the instrumented build: the pose never moved from its initial value for
+//  frames of ten edges and more (found in round 6 by running the GPU suite on the instrumented twin).  Every lane of wavefront 0 adds the same
+//  delta to the same word.)
 #define POSE_PROF(slot)                                                                                         \
     do {                                                                                                       \
-        if (kInstr && a.prof && blockIdx.x == 0 && threadIdx.x == 0) {                                         \
+        if (kInstr && a.prof && blockIdx.x == 0 && __builtin_amdgcn_readfirstlane((int)threadIdx.x) == 0) {    \
             const long long now_ = clock64();                                                                  \
             a.prof[slot] += now_ - prof_t; a.prof[8 + (slot)] += 1; prof_t = now_;                             \
         }                                                                                                      \

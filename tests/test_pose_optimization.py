@@ -8,6 +8,9 @@ GPU part: the HIP kernel (csrc/pose_opt.hip) against that restatement -- identic
 poses equal as float32 up to 2 ulp (the 6x6 sums are taken in a different order), and the batch entry point that reads
 the CRF's labels where the inference kernel left them."""
 import importlib
+import os
+import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -187,3 +190,32 @@ def test_hip_pose_optimization_survives_trim_and_growth(po, wl):
     s = wl.pose_scene(3000, seed=77)
     To, oo, no, _ = _run_oracle(po, s)
     assert out[1][2] == no and np.array_equal(out[1][1][s["valid"] == 1], oo[s["valid"] == 1])
+
+
+@pytest.mark.gpu
+def test_instrumented_twin_runs_the_same_pose_kernel(po, wl):
+    """Round 6: the instrumented library (liblccrf_hip_instr.so) differs from the release one by profiling hooks only -- and its pose kernel's
+    hook, a lane-divergent branch beside the reductions' lane exchanges, made the butterfly run under a partial EXEC mask: the pose of
+    every frame with ten edges or more stayed at its initial value.  Found by running the whole GPU suite on the twin; the hook's branch
+    is uniform now.  Same scene through both libraries: same bits."""
+    import crf_cases as cc
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import importlib, sys, numpy as np
+sys.path.insert(0, %r)
+pkg = importlib.import_module("lc-crf-slam_amd"); wl = importlib.import_module("lc-crf-slam_amd.workloads")
+for n in (2000, 500, 64, 9):
+    s = wl.pose_scene(n, seed=n + 1, noise=0.7, outlier_frac=0.15, mono_frac=0.2, n_invalid=0)
+    T, o, ninl = pkg.pose_optimization(s["Xw"], s["kp"], s["u_right"], s["inv_sigma2"], s["K4"], s["bf"], s["T_init"], valid=s["valid"])
+    print(n, ninl, int(o.sum()), " ".join("%%08x" %% x for x in np.asarray(T, np.float32).reshape(-1).view(np.uint32)))
+""" % root
+    outs = []
+    for env in (dict(os.environ), cc.switch_env(LCCRF_POSE_TWIN="1")):     # (any switch selects the twin)
+        env.pop("LCCRF_LIB", None) if env.get("LCCRF_POSE_TWIN") is None else None
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(r.stdout.strip().splitlines()[-4:])
+    assert outs[0] == outs[1], (outs[0], outs[1])
+    s = wl.pose_scene(2000, seed=2001, noise=0.7, outlier_frac=0.15, mono_frac=0.2, n_invalid=0)
+    To, oo, no, _ = _run_oracle(po, s)
+    assert int(outs[0][0].split()[1]) == no                  # ... and it is the restatement's answer
