@@ -142,7 +142,7 @@ struct Totals {
 // One GPU's share of the replay.  Every rank walks the same groups and the same number of rounds per group (a rank whose
 // share of the last round is short pads with empty frames), so the collectives line up.
 //
-// Three rounds are in flight per rank, each on a batch handle and a stream of its own (slot = round mod 3):
+// Three rounds are in flight per rank, each on a batch handle and that handle's own stream (slot = round mod 3):
 //     iteration t:   stage + upload + launch round t        lccrf_batch_set_inputs_host_async -> lccrf_batch_run
 //                    settle + gather round t-1              lccrf_batch_synchronize: the host waits for round t-1's OWN streams (its kernel
 //                                                           has been running under the staging of round t) and re-runs the frames the
@@ -180,8 +180,13 @@ void rank_main(int rank, int G, int B, bool single_wg, bool serial, const std::v
         Slot slots[kSlots];
         int words = 0;
         for (Slot &sl : slots) {
-            TRY_HIP(hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking));
             TRY_LCCRF(lccrf_batch_create(&sl.b, rank, &desc));
+            // the batch's OWN stream carries its kernels, the gather and the copy: streams created with the handles, one after the other,
+            // land on different hardware queues; caller-made ones may share one and then run the slots' kernels one after the other
+            // (include/lccrf.h: lccrf_batch_get_stream)
+            void *own = nullptr;
+            TRY_LCCRF(lccrf_batch_get_stream(sl.b, &own));
+            sl.stream = static_cast<hipStream_t>(own);
             if (single_wg) TRY_LCCRF(lccrf_batch_set_option(sl.b, LCCRF_OPT_SINGLE_WORKGROUP, 1));
             TRY_LCCRF(lccrf_batch_device_label_bits(sl.b, &sl.d_bits, &words));
         }
@@ -298,8 +303,7 @@ void rank_main(int rank, int G, int B, bool single_wg, bool serial, const std::v
             if (sl.stream) (void)hipStreamSynchronize(sl.stream);
             (void)hipFree(sl.d_all);
             (void)hipHostFree(sl.h_all);
-            lccrf_batch_destroy(sl.b);
-            if (sl.stream) (void)hipStreamDestroy(sl.stream);
+            lccrf_batch_destroy(sl.b);                   // (takes its stream with it)
         }
     }
     tot.rank_seconds[rank] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_rank0).count();
