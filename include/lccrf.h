@@ -248,9 +248,9 @@ int  lccrf_batch_inference(lccrf_batch_handle b, int n_iterations, int with_map,
  * are gathered, re-run on the two-kernel path and scattered back -- a batch with one outlier pays for one frame.
  * The device buffers of lccrf_batch_device_buffers / _label_bits are complete behind that synchronisation point.
  * Memory: the first lccrf_batch_run of a handle whose frames qualify for the two-frames-per-CU kernel (>= 256 frames, two 2-D kernels,
- * <= 2048 points) allocates that kernel's per-point record area ON THAT CALL (a synchronous hipMalloc): 96 KB per frame of the
- * handle's max_frames -- 1.6 GB for 16384 frames, 400 MB for 4096 -- kept until lccrf_batch_destroy.  Create a handle with the
- * max_frames it will use, and expect the first run of a handle to be slower than the following ones.  */
+ * <= 2048 points) allocates that kernel's per-point record area ON THAT CALL (a synchronous hipMalloc): 96 KB per frame BOUND at that
+ * moment (1.6 GB for 16384 frames, 400 MB for 4096), kept until lccrf_batch_destroy; a later run with more frames allocates a larger
+ * area (the smaller one stays with the handle).  Expect the first run of a handle to be slower than the following ones.  */
 int  lccrf_batch_run(lccrf_batch_handle b, int n_iterations, int with_map, float relax, void *stream);
 /* How many frames of the last lccrf_batch_run had to be re-run on the two-kernel path (0 = every frame fitted). */
 int  lccrf_batch_get_fallback_frames(lccrf_batch_handle b, int *n_frames);

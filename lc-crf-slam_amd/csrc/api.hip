@@ -197,7 +197,8 @@ struct Engine {
     bool frame_small_used = false;     //   more than 1/8 of a batch's frames did not fit that plan
     bool frame_lean_ok = true;         // ... and so may batches of full-size frames (frame_lean.hip), under the same rule
     bool frame_lean_used = false;
-    unsigned char *lean_rec = nullptr; //   [Fcap][kLeanRecBytes] per-point records of that kernel (lazy)
+    unsigned char *lean_rec = nullptr; //   [lean_rec_frames][kLeanRecBytes] per-point records of that kernel (lazy, sized for the frames bound)
+    int lean_rec_frames = 0;
     static constexpr int kDualMaxFrames = 64;    // (measured, `scripts/small_batch_latency.py`: 4 frames 98 -> 86 us, 32 frames 93 -> 83 us, 128 frames 112 -> 114 us)
     bool opt_single_wg = false;        // LCCRF_OPT_SINGLE_WORKGROUP: never the two-workgroup form (lccrf_set_option)
     int opt_vertex_order = 0;          // LCCRF_OPT_VERTEX_ORDER: 0 automatic (= on), 1 on, 2 off -- locality mode's sorted build
@@ -774,11 +775,19 @@ struct Engine {
         labels_armed = done_armed && with_map && L == 2 && map_host && map_host == crf.map && activeN > 0;
         if (labels_armed) memset(map_host, 0xff, (size_t)activeN * sizeof(int16_t));
         // full-size frames, two per CU (frame_lean.hip): the record area its loop re-reads is allocated when a batch first wants it
-        if (frame_lean_ok && !lean_rec && frame_lean_wanted(crf)) {
+        // (sized for the frames BOUND, not for the handle's capacity -- 96 KB per frame: a handle created for 16384 frames that runs 1024 takes
+        //  0.1 GB, not 1.6; a later, larger batch gets a new area, the old one stays with the handle until it is destroyed -- ADVICE r5)
+        if (frame_lean_ok && lean_rec_frames < F && frame_lean_wanted(crf)) {
             // (no memory for the area: the batch keeps the one-frame-per-CU kernel, which needs none)
-            if (mem.alloc(reinterpret_cast<char **>(&lean_rec), frame_lean_rec_bytes(Fcap), false)) {   // (written before it is read: no zeroing)
+            lean_rec = nullptr;
+            lean_rec_frames = 0;
+            const int want = std::min(Fcap, std::max(F, 256));
+            if (mem.alloc(reinterpret_cast<char **>(&lean_rec), frame_lean_rec_bytes(want), false)) {   // (written before it is read: no zeroing)
+                lean_rec = nullptr;
                 frame_lean_ok = false;
                 (void)hipGetLastError();
+            } else {
+                lean_rec_frames = want;
             }
         }
         const int shape = launch_frame(crf, kdevs.data(), n_iter, with_map, relax, late_status, frame_status,

@@ -852,6 +852,37 @@ def test_two_handles_on_their_own_streams_give_each_its_results(po, wl):
         b.close()
 
 
+def test_one_launch_record_area_grows_with_the_frames_bound(po, wl):
+    """The half-CU one-launch kernel's record area (96 KB per frame) is sized for the frames BOUND, not for the handle's capacity
+    (ADVICE r5): a handle for 1024 frames runs 264, then 520 (a larger area), then 264 again -- each batch against the oracle."""
+    base = [wl.slam_problem(n, seed=9980 + i) for i, n in enumerate([2000, 1300, 1999, 1100, 2048, 1537, 3, 0])]
+    refs = []
+    for pb in base:
+        o = cc.setup(po.OracleCRF, pb)
+        o.inference_native(5, True)
+        refs.append((o.probability().copy(), o.map().copy()))
+        o.close()
+    maxN = 2048
+    b = pkg.BatchCRF(1024, maxN, 2, [2, 2], [float(base[0]["kernels"][k][1]) for k in range(2)])
+    for F in (264, 520, 264):
+        feats = [np.zeros((F, maxN, 2), np.float32) for _ in range(2)]
+        label = np.full((F, maxN), -1, np.int16)
+        for f in range(F):
+            pb = base[f % 8]
+            label[f, :pb["N"]] = pb["label"]
+            for k in range(2):
+                feats[k][f, :pb["N"]] = pb["kernels"][k][0]
+        b.set_inputs_host([base[f % 8]["N"] for f in range(F)], feats, label=label, conf=base[0]["conf"])
+        b.run(5, True)
+        Q, M = b.probability(), b.map()
+        assert b.engine() == 3 and b.fused_shape() == (512, 2), (F, b.engine(), b.fused_shape())
+        for f in list(range(8)) + list(range(F - 8, F)):
+            q, m = refs[f % 8]
+            n = base[f % 8]["N"]
+            assert cc.same_bits(Q[f, :n], q) and np.array_equal(M[f, :n], m), (F, f)
+    b.close()
+
+
 def test_full_size_frames_share_a_cu_in_the_one_launch_kernel(po, wl):
     """Round 5: lccrf_batch_run on batches of >= 256 full-size two-kernel frames (1025 .. 2048 points) runs the WHOLE frame -- both
     lattice builds, normalisation, inference -- in 512-lane workgroups on half a CU (csrc/frame_lean.hip: LDS scratch laid out by
